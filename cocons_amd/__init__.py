@@ -1,0 +1,22 @@
+"""cocons_amd -- MI355X-native dense hot path of the R package blasif/cocons.
+
+Host-side mirror of the reference's operator interface for this path (same
+names and argument meaning as the R functions) over the C ABI in
+include/cocons_hip.h.  See DESIGN.md / INTEGRATION.md.
+"""
+from .host import (  # noqa: F401
+    ASPECTS,
+    CoconsFit,
+    GetNeg2loglikelihood,
+    GetNeg2loglikelihoodProfile,
+    GetNeg2loglikelihoodREML,
+    cocoPredict_dense,
+    cov_rns,
+    cov_rns_classic,
+    cov_rns_pred,
+    getModelLists,
+    getPen,
+    getScale,
+    sumsmoothlone,
+)
+from ._lib import CholeskyError, CoconsHipError  # noqa: F401

@@ -1,0 +1,93 @@
+"""ctypes binding of libcocons_hip.so (the C ABI declared in include/cocons_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or a call fails, an
+exception is raised.  The library is built in-tree by `__graft_entry__.build()`
+(or `make -C cocons_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcocons_hip.so")
+P_MAX = 32
+
+_lib = None
+
+c_dp = ctypes.POINTER(ctypes.c_double)
+c_int = ctypes.c_int
+c_vp = ctypes.c_void_p
+
+
+class CoconsHipError(RuntimeError):
+    pass
+
+
+class CholeskyError(CoconsHipError):
+    """Leading minor not positive (the reference's `chol` error condition)."""
+
+    def __init__(self, k):
+        super().__init__("Cholesky error (leading minor %d not positive)" % k)
+        self.minor = k
+
+
+# every symbol include/cocons_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "cocons_last_error": (ctypes.c_char_p, []),
+    "cocons_abi_version": (c_int, []),
+    "cocons_device_count": (c_int, []),
+    "cocons_cov_rns": (c_int, [c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "cocons_cov_rns_classic": (c_int, [c_int, c_int, c_dp, c_dp, c_dp, c_dp]),
+    "cocons_cov_rns_pred": (c_int, [c_int, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "cocons_sumsmoothlone": (ctypes.c_double, [c_dp, c_int, ctypes.c_double, ctypes.c_double]),
+    "cocons_fit_create": (c_vp, [c_int, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_int]),
+    "cocons_fit_destroy": (None, [c_vp]),
+    "cocons_neg2loglik_dense": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
+    "cocons_neg2loglik_profile": (c_int, [c_vp, c_dp, c_dp, c_dp]),
+    "cocons_neg2loglik_reml": (c_int, [c_vp, c_dp, c_int, c_dp, c_dp]),
+    "cocons_predict_dense": (c_int, [c_vp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_dp, c_dp]),
+    "cocons_chol_solve": (c_int, [c_int, c_dp, c_int, c_dp, c_dp, c_dp, c_dp]),
+    "cocons_fit_profile": (c_int, [c_vp, c_dp, c_dp, c_int, c_dp]),
+    "cocons_shard_begin": (c_int, [c_vp, c_dp, c_dp, c_int, c_int]),
+    "cocons_shard_panel_factor": (c_int, [c_vp, c_int]),
+    "cocons_shard_panel_buffer": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(ctypes.c_longlong)]),
+    "cocons_shard_panel_apply": (c_int, [c_vp, c_int]),
+    "cocons_shard_finish": (c_int, [c_vp, c_dp, ctypes.POINTER(c_int)]),
+    "cocons_shard_num_panels": (c_int, [c_vp]),
+    "cocons_shard_exchange_bytes": (ctypes.c_longlong, [c_vp]),
+    "cocons_shard_set_exchange": (c_int, [c_vp, c_vp, c_vp, ctypes.c_longlong]),
+    "cocons_fit_stream": (c_vp, [c_vp]),
+    "cocons_fit_set_stream": (c_int, [c_vp, c_vp]),
+    "cocons_fit_sync": (c_int, [c_vp]),
+}
+
+
+def load():
+    """Load the HIP library (no HIP call is made by loading it)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CoconsHipError(
+                "HIP extension not built: %s is missing (run __graft_entry__.build() or "
+                "`make -C cocons_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return load().cocons_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    """0 -> ok; k>0 -> CholeskyError(k); <0 -> CoconsHipError."""
+    if rc == 0:
+        return
+    if rc > 0:
+        raise CholeskyError(rc)
+    raise CoconsHipError("%s failed (%d): %s" % (what, rc, last_error()))

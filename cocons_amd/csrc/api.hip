@@ -1,0 +1,870 @@
+// api.hip -- C ABI of the dense hot path (see include/cocons_hip.h for the contract and the
+// reference interface each entry point replaces).
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "matern_device.hpp"   // PairMode, LOCP_FIELDS (host-visible enums)
+
+using namespace cocons;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, const char *what = "")
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, fmt, what);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                              \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess) {                                                  \
+            char b__[512];                                                        \
+            snprintf(b__, sizeof b__, "%s failed: %s (%s:%d)", #expr,             \
+                     hipGetErrorString(e__), __FILE__, __LINE__);                 \
+            g_err = b__;                                                          \
+            return -100 - (int)e__;                                               \
+        }                                                                         \
+    } while (0)
+
+extern "C" const char *cocons_last_error(void) { return g_err.c_str(); }
+extern "C" int cocons_abi_version(void) { return 1; }
+
+extern "C" int cocons_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { g_err = hipGetErrorString(e); return -1; }
+    return n;
+}
+
+// src/cocons_full.cpp:12-30 -- O(p) host arithmetic, kept on the host.
+extern "C" double cocons_sumsmoothlone(const double *x, int len, double lambda, double alpha)
+{
+    double sum = 0;
+    for (int w = 0; w < len; ++w) {
+        if (std::abs(x[w]) > 1e-4)
+            sum = sum + std::abs(x[w]);
+        else
+            sum = sum + std::pow(alpha, -1) * (std::log(1 + std::exp(-alpha * x[w])) + std::log(1 + std::exp(alpha * x[w])));
+    }
+    return lambda * sum;
+}
+
+// ---------------------------------------------------------------------------
+// theta -> kernel arguments, exactly the host-side preamble of the reference functions
+enum { TH_SD = 0, TH_SCALE = 1, TH_ANISO = 2, TH_TILT = 3, TH_SMOOTH = 4, TH_NUGGET = 5 };
+
+struct ModeSel {
+    int mode;          // PairMode
+    int smooth_kind;   // SmoothKind
+    double nu_fixed;
+    double gr;
+};
+
+static void make_theta_vecs(const double *theta, int p, ThetaVecs &tv)
+{
+    memset(&tv, 0, sizeof tv);
+    for (int i = 0; i < p; ++i) {
+        double sje = (i == 0) ? 0.0 : theta[TH_SCALE * p + i];      // cocons_full.cpp:49,64
+        tv.tilt[i] = theta[TH_TILT * p + i];
+        tv.two_scale_je[i] = 2 * sje;                               // :101
+        tv.aniso[i] = theta[TH_ANISO * p + i];
+        tv.sqrt_vector[i] = 2 * sje + theta[TH_ANISO * p + i];      // :66
+        tv.half_sd[i] = 0.5 * theta[TH_SD * p + i];                 // :104
+        tv.nugget[i] = theta[TH_NUGGET * p + i];
+        tv.smooth[i] = theta[TH_SMOOTH * p + i];
+        tv.sd[i] = theta[TH_SD * p + i];
+    }
+}
+
+// which = 0 cov_rns, 1 cov_rns_classic, 2 cov_rns_pred
+static ModeSel select_mode(const double *theta, int p, const double *smooth_limits, int which)
+{
+    ModeSel m;
+    m.gr = 1 / std::exp(-2 * theta[TH_SCALE * p + 0]);              // :62, :351, :501
+    m.nu_fixed = 0.0;
+    if (which == 1) { m.mode = MODE_MEAN; m.smooth_kind = SMOOTH_EXP; return m; }
+    if (which == 2) { m.mode = MODE_GEOM; m.smooth_kind = SMOOTH_LOGISTIC_SQRT; return m; }
+    bool fix = true;                                                // allzeroelements, types.h:56-63
+    for (int i = 1; i < p; ++i)
+        if (theta[TH_SMOOTH * p + i] != 0) fix = false;
+    if (fix && smooth_limits[0] == smooth_limits[1]) {              // :85-88
+        double v = smooth_limits[0];
+        m.nu_fixed = v;
+        m.smooth_kind = SMOOTH_ZERO;
+        if (std::fabs(v - 0.5) < 1e-6) m.mode = MODE_HALF;          // types.h:65-70
+        else if (std::fabs(v - 1.5) < 1e-6) m.mode = MODE_THREEHALF;
+        else if (std::fabs(v - 2.5) < 1e-6) m.mode = MODE_FIVEHALF;
+        else m.mode = MODE_GEOM;   // quirk: zero smooth vector -> u = 0 -> every entry = diag_ii
+    } else {
+        m.mode = MODE_GEOM;
+        m.smooth_kind = SMOOTH_LOGISTIC_SQRT;
+    }
+    return m;
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------
+struct cocons_fit {
+    int n, p, r, q, device;
+    pid_t pid;
+    int npad, nt;            // padded order, tiles of 128
+    int rhs_cap;             // rows reserved under the matrix (multiple of 128)
+    size_t lda;
+    hipStream_t stream;
+    bool own_stream;
+    double *dX, *dlocs, *dz, *dxb;
+    double *dloc;            // LOCP_FIELDS x npad
+    double *dA;
+    double *dinv;            // 2 x 8 x 256
+    int *dinfo;
+    double *dout;            // reductions
+    double *hout;            // pinned mirror
+    int *hinfo;
+    double smooth_limits[2];
+    size_t out_cap;
+    // predict scratch
+    double *dlocp, *dXp, *dlocsp, *dstoch, *dquad;
+    int pred_cap;
+    // sharded state
+    int rank, world, nrhs_cur;
+    double *xbuf[2];
+    size_t xbuf_bytes;
+    bool xbuf_own;
+    hipEvent_t ev[8];
+};
+
+static int fit_check(cocons_fit *f)
+{
+    if (!f) return fail(-1, "null fit handle");
+    if (f->pid != getpid())
+        return fail(-2, "fit handle was created in another process (fork); create it in the worker");
+    hipError_t e = hipSetDevice(f->device);
+    if (e != hipSuccess) return fail(-3, "hipSetDevice: %s", hipGetErrorString(e));
+    return 0;
+}
+
+static int fit_alloc_matrix(cocons_fit *f, int rhs_rows)
+{
+    int cap = round_up(rhs_rows > 0 ? rhs_rows : 1, TILE);
+    if (f->dA && cap <= f->rhs_cap) return 0;
+    if (f->dA) { HIPCHK(hipFree(f->dA)); f->dA = nullptr; }
+    f->rhs_cap = cap;
+    f->lda = (size_t)f->npad + cap;
+    HIPCHK(hipMalloc(&f->dA, f->lda * (size_t)f->npad * sizeof(double)));
+    return 0;
+}
+
+extern "C" void cocons_fit_destroy(cocons_fit *f)
+{
+    if (!f) return;
+    if (f->pid == getpid()) {
+        hipSetDevice(f->device);
+        if (f->stream) hipStreamSynchronize(f->stream);
+        hipFree(f->dX); hipFree(f->dlocs); hipFree(f->dz); hipFree(f->dxb); hipFree(f->dloc);
+        hipFree(f->dA); hipFree(f->dinv); hipFree(f->dinfo); hipFree(f->dout);
+        hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad);
+        if (f->xbuf_own) { hipFree(f->xbuf[0]); hipFree(f->xbuf[1]); }
+        hipHostFree(f->hout); hipHostFree(f->hinfo);
+        for (auto &e : f->ev) if (e) hipEventDestroy(e);
+        if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
+    }
+    delete f;
+}
+
+extern "C" cocons_fit *cocons_fit_create(int n, int p, int r, int q, const double *locs,
+                                         const double *X, const double *z, const double *x_betas,
+                                         const double *smooth_limits, int device)
+{
+    if (n <= 0 || p <= 0 || p > COCONS_P_MAX || r < 0 || q < 0 || !locs || !X || !smooth_limits ||
+        (r > 0 && !z) || (q > 0 && !x_betas)) {
+        fail(-1, "cocons_fit_create: bad argument");
+        return nullptr;
+    }
+    cocons_fit *f = new cocons_fit();
+    memset(f, 0, sizeof *f);
+    f->n = n; f->p = p; f->r = r; f->q = q;
+    f->device = device < 0 ? 0 : device;
+    f->pid = getpid();
+    f->npad = round_up(n, TILE);
+    f->nt = f->npad / TILE;
+    f->smooth_limits[0] = smooth_limits[0];
+    f->smooth_limits[1] = smooth_limits[1];
+    f->world = 1;
+#define CK(expr)                                                                  \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess) {                                                  \
+            fail(-100, "cocons_fit_create: %s", hipGetErrorString(e__));          \
+            cocons_fit_destroy(f);                                                \
+            return nullptr;                                                       \
+        }                                                                         \
+    } while (0)
+    CK(hipSetDevice(f->device));
+    CK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    f->own_stream = true;
+    CK(hipMalloc(&f->dX, (size_t)n * p * sizeof(double)));
+    CK(hipMalloc(&f->dlocs, (size_t)n * 2 * sizeof(double)));
+    CK(hipMemcpy(f->dX, X, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice));
+    CK(hipMemcpy(f->dlocs, locs, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice));
+    if (r > 0) {
+        CK(hipMalloc(&f->dz, (size_t)n * r * sizeof(double)));
+        CK(hipMemcpy(f->dz, z, (size_t)n * r * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (q > 0) {
+        CK(hipMalloc(&f->dxb, (size_t)n * q * sizeof(double)));
+        CK(hipMemcpy(f->dxb, x_betas, (size_t)n * q * sizeof(double), hipMemcpyHostToDevice));
+    }
+    CK(hipMalloc(&f->dloc, (size_t)LOCP_FIELDS * f->npad * sizeof(double)));
+    CK(hipMalloc(&f->dinv, 2 * 8 * 256 * sizeof(double)));
+    CK(hipMalloc(&f->dinfo, sizeof(int)));
+    int nr_max = r + (q > p ? q : p);
+    f->out_cap = (size_t)(1 + nr_max * nr_max) * (size_t)(f->nt + 2);
+    CK(hipMalloc(&f->dout, f->out_cap * sizeof(double)));
+    CK(hipHostMalloc(&f->hout, f->out_cap * sizeof(double)));
+    CK(hipHostMalloc(&f->hinfo, sizeof(int)));
+    for (auto &e : f->ev) CK(hipEventCreate(&e));
+    if (fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
+#undef CK
+    return f;
+}
+
+extern "C" void *cocons_fit_stream(cocons_fit *f) { return f ? (void *)f->stream : nullptr; }
+
+extern "C" int cocons_fit_set_stream(cocons_fit *f, void *stream)
+{
+    if (int rc = fit_check(f)) return rc;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (f->own_stream) { HIPCHK(hipStreamDestroy(f->stream)); f->own_stream = false; }
+    f->stream = (hipStream_t)stream;
+    return 0;
+}
+
+extern "C" int cocons_fit_sync(cocons_fit *f)
+{
+    if (int rc = fit_check(f)) return rc;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// assembly of Sigma (+ identity padding) into the factorisation buffer, lower triangle.
+// bj0 / ncols restrict the 64-wide tile columns (sharded path); full range otherwise.
+static void assemble_sigma(cocons_fit *f, const double *theta, int which, int col0, int col1)
+{
+    ThetaVecs tv;
+    make_theta_vecs(theta, f->p, tv);
+    ModeSel ms = select_mode(theta, f->p, f->smooth_limits, which);
+    LocArgs la;
+    la.n = f->n; la.p = f->p;
+    la.X = f->dX; la.ldx = f->n;
+    la.locs = f->dlocs; la.ldl = f->n;
+    la.out = f->dloc; la.stride = f->npad;
+    la.smooth_kind = ms.smooth_kind;
+    la.smooth_min = f->smooth_limits[0]; la.smooth_max = f->smooth_limits[1];
+    la.th = tv;
+    launch_loc_params(la, f->stream);
+    PairArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.n = f->n; pa.m = f->n;
+    pa.rows = f->dloc; pa.cols = f->dloc;
+    pa.stride = f->npad; pa.stride_rows = f->npad;
+    pa.out = f->dA; pa.ld = f->lda;
+    pa.nrows_out = f->npad; pa.ncols_out = col1;
+    pa.bj0 = col0 / 64;
+    pa.gr = ms.gr; pa.nu_fixed = ms.nu_fixed;
+    launch_pair_sym(ms.mode, false, pa, f->stream);
+}
+
+// right-hand-side rows under the matrix: rows npad.. : z columns (minus trend), then xb columns
+static void assemble_rhs(cocons_fit *f, const double *mean, bool use_trend, const double *xb, int nxb,
+                         int col0, int col1)
+{
+    RhsArgs ra;
+    memset(&ra, 0, sizeof ra);
+    ra.n = f->n; ra.p = f->p; ra.X = f->dX; ra.ldx = f->n;
+    ra.use_trend = use_trend ? 1 : 0;
+    if (use_trend) for (int i = 0; i < f->p; ++i) ra.mean[i] = mean[i];
+    ra.src = f->dz; ra.lds = f->n;
+    ra.out = f->dA; ra.ld = f->lda;
+    ra.row0 = f->npad; ra.nrows = f->r;
+    ra.nrows_zero = (nxb > 0) ? 0 : f->rhs_cap - f->r;
+    ra.col0 = col0; ra.ncols_out = col1;
+    launch_rhs_rows(ra, f->stream);
+    if (nxb > 0) {
+        ra.use_trend = 0;
+        ra.src = xb; ra.lds = f->n;
+        ra.row0 = f->npad + f->r; ra.nrows = nxb;
+        ra.nrows_zero = f->rhs_cap - f->r - nxb;
+        launch_rhs_rows(ra, f->stream);
+    }
+}
+
+// Bordered right-looking factorisation, outer block = 2 tiles (256 columns):
+//   potrf(k) | trsm(k) | update tile column k+1 (K=128) | potrf(k+1) | trsm(k+1) |
+//   trailing update of everything right of the block with K = 256.
+// mt = total tile rows (matrix + rhs rows).  Optional per-launch timing of the trailing
+// update via events (ev_upd != nullptr): appended pairs (start, stop).
+static void factorize(cocons_fit *f, int mt, std::vector<hipEvent_t> *ev_upd)
+{
+    const int nt = f->nt;
+    double *A = f->dA;
+    const size_t lda = f->lda;
+    hipStream_t s = f->stream;
+    for (int k = 0; k < nt; k += 2) {
+        double *di0 = f->dinv, *di1 = f->dinv + 8 * 256;
+        launch_potrf_tile(A, lda, k * TILE, di0, f->dinfo, s);
+        launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, mt * TILE, di0, s);
+        if (k + 1 < nt) {
+            launch_update(A, lda, k * TILE, TILE, k + 1, mt, k + 1, k + 2, true, s);
+            launch_potrf_tile(A, lda, (k + 1) * TILE, di1, f->dinfo, s);
+            launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, mt * TILE, di1, s);
+            if (k + 2 < nt) {
+                if (ev_upd) {
+                    hipEvent_t a, b;
+                    hipEventCreate(&a); hipEventCreate(&b);
+                    hipEventRecord(a, s);
+                    launch_update(A, lda, k * TILE, 2 * TILE, k + 2, mt, k + 2, nt, true, s);
+                    hipEventRecord(b, s);
+                    ev_upd->push_back(a); ev_upd->push_back(b);
+                } else {
+                    launch_update(A, lda, k * TILE, 2 * TILE, k + 2, mt, k + 2, nt, true, s);
+                }
+            }
+        }
+    }
+}
+
+static int reset_info(cocons_fit *f)
+{
+    HIPCHK(hipMemsetAsync(f->dinfo, 0x7f, sizeof(int), f->stream));
+    return 0;
+}
+
+// enqueue one full evaluation with nrhs right-hand-side rows; results land in hout/hinfo
+static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, bool use_trend,
+                        const double *xb, int nxb, std::vector<hipEvent_t> *ev_upd, bool stage_events)
+{
+    const int nrhs = f->r + nxb;
+    if (int rc = fit_alloc_matrix(f, nrhs)) return rc;
+    const int mt = f->nt + f->rhs_cap / TILE;
+    if (stage_events) hipEventRecord(f->ev[0], f->stream);
+    if (int rc = reset_info(f)) return rc;
+    assemble_sigma(f, theta, 0, 0, f->npad);
+    assemble_rhs(f, mean, use_trend, xb, nxb, 0, f->npad);
+    if (stage_events) hipEventRecord(f->ev[1], f->stream);
+    factorize(f, mt, ev_upd);
+    if (stage_events) hipEventRecord(f->ev[2], f->stream);
+    launch_finalize(f->dA, f->lda, f->n, f->npad, nrhs, f->dout, f->stream);
+    HIPCHK(hipMemcpyAsync(f->hout, f->dout, (size_t)(1 + nrhs * nrhs) * sizeof(double),
+                          hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    if (stage_events) hipEventRecord(f->ev[3], f->stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int info_status(cocons_fit *f)
+{
+    int info = *f->hinfo;
+    if (info != 0x7f7f7f7f) {
+        if (info > f->n) info = f->n;   // failure reported inside the identity padding cannot happen; clamp anyway
+        g_err = "leading minor not positive";
+        return info;
+    }
+    return 0;
+}
+
+static const double LOG_2PI = 1.8378770664093454835606594728112;
+
+extern "C" int cocons_neg2loglik_dense(cocons_fit *f, const double *theta, const double *mean,
+                                       double *sum_logliks, double *parts)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!theta || !mean || !sum_logliks) return fail(-1, "cocons_neg2loglik_dense: null argument");
+    if (f->r < 1) return fail(-1, "cocons_neg2loglik_dense: fit has no z");
+    if (int rc = enqueue_eval(f, theta, mean, true, nullptr, 0, nullptr, false)) return rc;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (int st = info_status(f)) return st;
+    const int nr = f->r;
+    double logdet = f->hout[0], total = 0.0;
+    for (int k = 0; k < nr; ++k) {                                   // R/neg2loglikelihood.R:212-218
+        double quad = f->hout[1 + k * nr + k];
+        total += f->n * LOG_2PI + 2 * logdet + quad;
+        if (parts) parts[1 + k] = quad;
+    }
+    if (parts) parts[0] = logdet;
+    *sum_logliks = total;
+    return 0;
+}
+
+// small dense SPD solve on the host (q x q, q <= COCONS_P_MAX): W = C C^T, returns
+// sum(log(diag(C))) and solves W x = b in place for nb right-hand sides.
+static int host_spd_solve(int q, std::vector<double> &W, int nb, std::vector<double> &B, double *logdet_half)
+{
+    double ld = 0;
+    for (int j = 0; j < q; ++j) {
+        double d = W[j + j * q];
+        for (int k = 0; k < j; ++k) d -= W[j + k * q] * W[j + k * q];
+        if (!(d > 0)) return j + 1;
+        d = std::sqrt(d);
+        W[j + j * q] = d;
+        ld += std::log(d);
+        for (int i = j + 1; i < q; ++i) {
+            double s = W[i + j * q];
+            for (int k = 0; k < j; ++k) s -= W[i + k * q] * W[j + k * q];
+            W[i + j * q] = s / d;
+        }
+    }
+    for (int c = 0; c < nb; ++c) {
+        double *b = &B[(size_t)c * q];
+        for (int i = 0; i < q; ++i) {
+            double s = b[i];
+            for (int k = 0; k < i; ++k) s -= W[i + k * q] * b[k];
+            b[i] = s / W[i + i * q];
+        }
+        for (int i = q - 1; i >= 0; --i) {
+            double s = b[i];
+            for (int k = i + 1; k < q; ++k) s -= W[k + i * q] * b[k];
+            b[i] = s / W[i + i * q];
+        }
+    }
+    *logdet_half = ld;
+    return 0;
+}
+
+// shared tail of Profile / REML: Gram matrix G of [y_1..y_r, Y] (Y = L^-1 Xb) ->
+// quad_k = G_kk - g_k' W^-1 g_k with W = Y'Y, g_k = Y'y_k.
+static int profile_tail(cocons_fit *f, int nxb, double n_eff, bool reml, double *sum_logliks, double *parts)
+{
+    const int r = f->r, nr = r + nxb;
+    const double *G = f->hout + 1;
+    std::vector<double> W((size_t)nxb * nxb), Bv((size_t)nxb * r);
+    for (int a = 0; a < nxb; ++a)
+        for (int b = 0; b < nxb; ++b) W[a + (size_t)b * nxb] = G[(r + a) * nr + (r + b)];
+    for (int k = 0; k < r; ++k)
+        for (int a = 0; a < nxb; ++a) Bv[(size_t)k * nxb + a] = G[k * nr + (r + a)];
+    std::vector<double> g = Bv;
+    double ldW = 0;
+    if (host_spd_solve(nxb, W, r, Bv, &ldW)) return fail(-4, "X' Sigma^-1 X is not positive definite");
+    double logdet = f->hout[0], total = 0.0;
+    for (int k = 0; k < r; ++k) {
+        double corr = 0;
+        for (int a = 0; a < nxb; ++a) corr += g[(size_t)k * nxb + a] * Bv[(size_t)k * nxb + a];
+        double quad = G[k * nr + k] - corr;
+        total += n_eff * LOG_2PI + 2 * logdet + (reml ? 2 * ldW : 0.0) + quad;
+        if (parts) parts[2 + k] = quad;
+    }
+    if (parts) { parts[0] = logdet; parts[1] = ldW; }
+    *sum_logliks = total;
+    return 0;
+}
+
+extern "C" int cocons_neg2loglik_profile(cocons_fit *f, const double *theta, double *sum_logliks, double *parts)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!theta || !sum_logliks) return fail(-1, "cocons_neg2loglik_profile: null argument");
+    if (f->r < 1 || f->q < 1) return fail(-1, "cocons_neg2loglik_profile: fit needs z and x_betas");
+    if (int rc = enqueue_eval(f, theta, nullptr, false, f->dxb, f->q, nullptr, false)) return rc;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (int st = info_status(f)) return st;
+    return profile_tail(f, f->q, (double)f->n, false, sum_logliks, parts);   // R/neg2loglikelihood.R:155-160
+}
+
+extern "C" int cocons_neg2loglik_reml(cocons_fit *f, const double *theta, int rank, double *sum_logliks, double *parts)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!theta || !sum_logliks) return fail(-1, "cocons_neg2loglik_reml: null argument");
+    if (f->r < 1) return fail(-1, "cocons_neg2loglik_reml: fit has no z");
+    if (int rc = enqueue_eval(f, theta, nullptr, false, f->dX, f->p, nullptr, false)) return rc;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (int st = info_status(f)) return st;
+    return profile_tail(f, f->p, (double)(f->n - rank), true, sum_logliks, parts);   // :283-287
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int cocons_fit_profile(cocons_fit *f, const double *theta, const double *mean, int reps, double *ms)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!theta || !mean || !ms || reps < 1) return fail(-1, "cocons_fit_profile: bad argument");
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int it = 0; it < reps; ++it) {
+        std::vector<hipEvent_t> ev;
+        if (int rc = enqueue_eval(f, theta, mean, true, nullptr, 0, &ev, true)) return rc;
+        HIPCHK(hipStreamSynchronize(f->stream));
+        float t01, t12, t23, t03;
+        HIPCHK(hipEventElapsedTime(&t01, f->ev[0], f->ev[1]));
+        HIPCHK(hipEventElapsedTime(&t12, f->ev[1], f->ev[2]));
+        HIPCHK(hipEventElapsedTime(&t23, f->ev[2], f->ev[3]));
+        HIPCHK(hipEventElapsedTime(&t03, f->ev[0], f->ev[3]));
+        acc[0] += t01; acc[1] += t12; acc[2] += t23; acc[3] += t03;
+        double sum = 0;
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float t;
+            HIPCHK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            sum += t;
+        }
+        acc[6] += sum;
+        acc[5] = (double)(ev.size() / 2);
+        for (auto e : ev) hipEventDestroy(e);
+    }
+    for (int i = 0; i < 4; ++i) ms[i] = acc[i] / reps;
+    ms[5] = acc[5];
+    ms[6] = acc[6] / reps;
+    ms[4] = acc[5] > 0 ? ms[6] / acc[5] : 0.0;
+    return info_status(f);
+}
+
+// ---------------------------------------------------------------------------
+// stateless covariance entry points
+static int cov_common(int which, int n, int m, int p, const double *theta, const double *locs,
+                      const double *locs_pred, const double *X, const double *X_pred,
+                      const double *smooth_limits, double *out)
+{
+    if (n <= 0 || p <= 0 || p > COCONS_P_MAX || !theta || !locs || !X || !out || (which != 1 && !smooth_limits) ||
+        (which == 2 && (m <= 0 || !locs_pred || !X_pred)))
+        return fail(-1, "cov_rns*: bad argument");
+    double sl_dummy[2] = {0.0, 0.0};
+    const double *sl = smooth_limits ? smooth_limits : sl_dummy;
+    ThetaVecs tv;
+    make_theta_vecs(theta, p, tv);
+    ModeSel ms = select_mode(theta, p, sl, which);
+    hipStream_t s = nullptr;
+    double *dX = nullptr, *dl = nullptr, *dloc = nullptr, *dXp = nullptr, *dlp = nullptr, *dlocp = nullptr, *dout = nullptr;
+    const size_t rows = which == 2 ? (size_t)m : (size_t)n;
+    int rc = 0;
+#define CKG(expr)                                                                 \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess) {                                                  \
+            rc = fail(-100 - (int)e__, "cov_rns*: %s", hipGetErrorString(e__));   \
+            goto done;                                                            \
+        }                                                                         \
+    } while (0)
+    CKG(hipMalloc(&dX, (size_t)n * p * sizeof(double)));
+    CKG(hipMalloc(&dl, (size_t)n * 2 * sizeof(double)));
+    CKG(hipMalloc(&dloc, (size_t)LOCP_FIELDS * n * sizeof(double)));
+    CKG(hipMalloc(&dout, rows * (size_t)n * sizeof(double)));
+    CKG(hipMemcpy(dX, X, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice));
+    CKG(hipMemcpy(dl, locs, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice));
+    {
+        LocArgs la;
+        la.n = n; la.p = p; la.X = dX; la.ldx = n; la.locs = dl; la.ldl = n;
+        la.out = dloc; la.stride = n; la.smooth_kind = ms.smooth_kind;
+        la.smooth_min = sl[0]; la.smooth_max = sl[1]; la.th = tv;
+        launch_loc_params(la, s);
+        PairArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.n = n; pa.cols = dloc; pa.stride = n; pa.out = dout; pa.gr = ms.gr; pa.nu_fixed = ms.nu_fixed;
+        if (which == 2) {
+            CKG(hipMalloc(&dXp, (size_t)m * p * sizeof(double)));
+            CKG(hipMalloc(&dlp, (size_t)m * 2 * sizeof(double)));
+            CKG(hipMalloc(&dlocp, (size_t)LOCP_FIELDS * m * sizeof(double)));
+            CKG(hipMemcpy(dXp, X_pred, (size_t)m * p * sizeof(double), hipMemcpyHostToDevice));
+            CKG(hipMemcpy(dlp, locs_pred, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice));
+            LocArgs lp = la;
+            lp.n = m; lp.X = dXp; lp.ldx = m; lp.locs = dlp; lp.ldl = m; lp.out = dlocp; lp.stride = m;
+            launch_loc_params(lp, s);
+            pa.m = m; pa.rows = dlocp; pa.stride_rows = m; pa.ld = m; pa.nrows_out = m; pa.ncols_out = n;
+            launch_pair_rect(ms.mode, pa, s);
+        } else {
+            pa.m = n; pa.rows = dloc; pa.stride_rows = n; pa.ld = n; pa.nrows_out = n; pa.ncols_out = n;
+            launch_pair_sym(ms.mode, true, pa, s);
+        }
+    }
+    CKG(hipGetLastError());
+    CKG(hipMemcpy(out, dout, rows * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+done:
+    hipFree(dX); hipFree(dl); hipFree(dloc); hipFree(dXp); hipFree(dlp); hipFree(dlocp); hipFree(dout);
+#undef CKG
+    return rc;
+}
+
+extern "C" int cocons_cov_rns(int n, int p, const double *theta, const double *locs, const double *X,
+                              const double *smooth_limits, double *out)
+{
+    return cov_common(0, n, 0, p, theta, locs, nullptr, X, nullptr, smooth_limits, out);
+}
+
+extern "C" int cocons_cov_rns_classic(int n, int p, const double *theta, const double *locs, const double *X, double *out)
+{
+    return cov_common(1, n, 0, p, theta, locs, nullptr, X, nullptr, nullptr, out);
+}
+
+extern "C" int cocons_cov_rns_pred(int n, int m, int p, const double *theta, const double *locs,
+                                   const double *locs_pred, const double *X, const double *X_pred,
+                                   const double *smooth_limits, double *out)
+{
+    return cov_common(2, n, m, p, theta, locs, locs_pred, X, X_pred, smooth_limits, out);
+}
+
+// ---------------------------------------------------------------------------
+// kriging core: rows under the matrix = [ (z - X mean)' ; cov_rns_pred (m x n) ]
+extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const double *mean, int z_col,
+                                    int m, const double *locs_pred, const double *X_pred,
+                                    double *stochastic, double *quadform)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!theta || !mean || m <= 0 || !locs_pred || !X_pred || !stochastic || !quadform || z_col < 0 || z_col >= f->r)
+        return fail(-1, "cocons_predict_dense: bad argument");
+    const int p = f->p, n = f->n;
+    if (m > f->pred_cap) {
+        hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad);
+        f->dlocp = f->dXp = f->dlocsp = f->dstoch = f->dquad = nullptr;
+        f->pred_cap = 0;
+        HIPCHK(hipMalloc(&f->dlocp, (size_t)LOCP_FIELDS * m * sizeof(double)));
+        HIPCHK(hipMalloc(&f->dXp, (size_t)m * p * sizeof(double)));
+        HIPCHK(hipMalloc(&f->dlocsp, (size_t)m * 2 * sizeof(double)));
+        HIPCHK(hipMalloc(&f->dstoch, (size_t)m * sizeof(double)));
+        HIPCHK(hipMalloc(&f->dquad, (size_t)m * sizeof(double)));
+        f->pred_cap = m;
+    }
+    if (int rc = fit_alloc_matrix(f, m + 1)) return rc;
+    const int mt = f->nt + f->rhs_cap / TILE;
+    hipStream_t s = f->stream;
+    HIPCHK(hipMemcpyAsync(f->dXp, X_pred, (size_t)m * p * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(f->dlocsp, locs_pred, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (int rc = reset_info(f)) return rc;
+    assemble_sigma(f, theta, 0, 0, f->npad);
+    // row npad: residual of realization z_col; rows npad+1 .. npad+m: cross-covariance
+    {
+        RhsArgs ra;
+        memset(&ra, 0, sizeof ra);
+        ra.n = n; ra.p = p; ra.X = f->dX; ra.ldx = n; ra.use_trend = 1;
+        for (int i = 0; i < p; ++i) ra.mean[i] = mean[i];
+        ra.src = f->dz + (size_t)z_col * n; ra.lds = n;
+        ra.out = f->dA; ra.ld = f->lda; ra.row0 = f->npad; ra.nrows = 1;
+        ra.nrows_zero = f->rhs_cap - 1;      // also clears padding rows and columns >= n
+        ra.col0 = 0; ra.ncols_out = f->npad;
+        launch_rhs_rows(ra, s);
+        ThetaVecs tv;
+        make_theta_vecs(theta, p, tv);
+        ModeSel ms = select_mode(theta, p, f->smooth_limits, 2);
+        LocArgs lp;
+        lp.n = m; lp.p = p; lp.X = f->dXp; lp.ldx = m; lp.locs = f->dlocsp; lp.ldl = m;
+        lp.out = f->dlocp; lp.stride = m; lp.smooth_kind = ms.smooth_kind;
+        lp.smooth_min = f->smooth_limits[0]; lp.smooth_max = f->smooth_limits[1]; lp.th = tv;
+        launch_loc_params(lp, s);
+        // the observation-side SoA must use the pred-branch smoothness (always logistic+sqrt, :381)
+        LocArgs lo = lp;
+        lo.n = n; lo.X = f->dX; lo.ldx = n; lo.locs = f->dlocs; lo.ldl = n; lo.out = f->dloc; lo.stride = f->npad;
+        PairArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.n = n; pa.m = m; pa.rows = f->dlocp; pa.stride_rows = m; pa.cols = f->dloc; pa.stride = f->npad;
+        pa.out = f->dA + f->npad + 1; pa.ld = f->lda; pa.nrows_out = m; pa.ncols_out = n;
+        pa.gr = ms.gr; pa.nu_fixed = 0.0;
+        // Sigma was assembled from dloc above (stream order); rebuild dloc only if cov_rns used a
+        // different smoothness vector (fixed-nu branch) than cov_rns_pred does.
+        ModeSel ms0 = select_mode(theta, p, f->smooth_limits, 0);
+        if (ms0.smooth_kind != ms.smooth_kind) launch_loc_params(lo, s);
+        launch_pair_rect(MODE_GEOM, pa, s);
+    }
+    factorize(f, mt, nullptr);
+    launch_row_reduce(f->dA, f->lda, n, f->npad, f->npad + 1, m, f->dstoch, f->dquad, s);
+    HIPCHK(hipMemcpyAsync(stochastic, f->dstoch, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(quadform, f->dquad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    return info_status(f);
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int cocons_chol_solve(int n, const double *Ain, int nrhs, const double *rhs,
+                                 double *L, double *Y, double *logdet_half)
+{
+    if (n <= 0 || !Ain || nrhs < 0 || (nrhs > 0 && !rhs)) return fail(-1, "cocons_chol_solve: bad argument");
+    // reuse the fit machinery with a dummy 1-column design
+    std::vector<double> locs((size_t)2 * n, 0.0), X((size_t)n, 1.0);
+    double sl[2] = {0.5, 0.5};
+    cocons_fit *f = cocons_fit_create(n, 1, 0, 0, locs.data(), X.data(), nullptr, nullptr, sl, -1);
+    if (!f) return -1;
+    int rc = 0;
+    do {
+        if ((rc = fit_alloc_matrix(f, nrhs > 0 ? nrhs : 1))) break;
+        hipStream_t s = f->stream;
+        const int mt = f->nt + f->rhs_cap / TILE;
+        // identity everywhere in the padded square, zero rhs rows, then copy A and rhs^T in
+        std::vector<double> hostA(f->lda * (size_t)f->npad, 0.0);
+        for (int c = 0; c < f->npad; ++c) hostA[(size_t)c + (size_t)c * f->lda] = 1.0;
+        for (int c = 0; c < n; ++c) {
+            for (int r_ = c; r_ < n; ++r_) hostA[(size_t)r_ + (size_t)c * f->lda] = Ain[(size_t)r_ + (size_t)c * n];
+            for (int k = 0; k < nrhs; ++k) hostA[(size_t)(f->npad + k) + (size_t)c * f->lda] = rhs[(size_t)c + (size_t)k * n];
+        }
+        hipError_t e = hipMemcpy(f->dA, hostA.data(), hostA.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { rc = fail(-100, "cocons_chol_solve: %s", hipGetErrorString(e)); break; }
+        if ((rc = reset_info(f))) break;
+        factorize(f, mt, nullptr);
+        launch_finalize(f->dA, f->lda, n, f->npad, 0, f->dout, s);
+        e = hipMemcpy(hostA.data(), f->dA, hostA.size() * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(-100, "cocons_chol_solve: %s", hipGetErrorString(e)); break; }
+        hipMemcpy(f->hout, f->dout, sizeof(double), hipMemcpyDeviceToHost);
+        hipMemcpy(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost);
+        if ((rc = info_status(f))) break;
+        if (logdet_half) *logdet_half = f->hout[0];
+        if (L)
+            for (int c = 0; c < n; ++c)
+                for (int r_ = 0; r_ < n; ++r_)
+                    L[(size_t)r_ + (size_t)c * n] = (r_ >= c) ? hostA[(size_t)r_ + (size_t)c * f->lda] : 0.0;
+        if (Y)
+            for (int k = 0; k < nrhs; ++k)
+                for (int c = 0; c < n; ++c) Y[(size_t)c + (size_t)k * n] = hostA[(size_t)(f->npad + k) + (size_t)c * f->lda];
+    } while (0);
+    cocons_fit_destroy(f);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// column-panel sharded evaluation.  Panel = 2 tiles (256 columns); owner(k) = k % world.
+static const int PT = 2;     // tiles per panel
+
+extern "C" int cocons_shard_num_panels(cocons_fit *f) { return f ? (f->nt + PT - 1) / PT : -1; }
+
+extern "C" long long cocons_shard_exchange_bytes(cocons_fit *f)
+{
+    if (!f) return -1;
+    size_t rows = (size_t)f->npad + round_up(f->r > 0 ? f->r : 1, TILE);
+    return (long long)(rows * PT * TILE * sizeof(double));
+}
+
+// the caller may hand in two exchange buffers it owns (e.g. torch tensors, so that
+// torch.distributed can broadcast them); otherwise the library allocates them.
+extern "C" int cocons_shard_set_exchange(cocons_fit *f, void *buf0, void *buf1, long long bytes)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (bytes < cocons_shard_exchange_bytes(f)) return fail(-1, "cocons_shard_set_exchange: buffer too small");
+    if (f->xbuf_own) { hipFree(f->xbuf[0]); hipFree(f->xbuf[1]); f->xbuf_own = false; }
+    f->xbuf[0] = (double *)buf0; f->xbuf[1] = (double *)buf1; f->xbuf_bytes = (size_t)bytes;
+    return 0;
+}
+
+extern "C" int cocons_shard_begin(cocons_fit *f, const double *theta, const double *mean, int rank, int world)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!theta || !mean || world < 1 || rank < 0 || rank >= world) return fail(-1, "cocons_shard_begin: bad argument");
+    if (f->r < 1) return fail(-1, "cocons_shard_begin: fit has no z");
+    f->rank = rank; f->world = world; f->nrhs_cur = f->r;
+    if (int rc = fit_alloc_matrix(f, f->r)) return rc;
+    if (!f->xbuf[0]) {
+        size_t bytes = (size_t)cocons_shard_exchange_bytes(f);
+        HIPCHK(hipMalloc(&f->xbuf[0], bytes));
+        HIPCHK(hipMalloc(&f->xbuf[1], bytes));
+        f->xbuf_bytes = bytes; f->xbuf_own = true;
+    }
+    if (int rc = reset_info(f)) return rc;
+    const int np = cocons_shard_num_panels(f);
+    // per-location vectors are replicated; each rank assembles only its own column panels
+    bool first = true;
+    for (int k = rank; k < np; k += world) {
+        int c0 = k * PT * TILE, c1 = c0 + PT * TILE;
+        if (c1 > f->npad) c1 = f->npad;
+        if (first) { assemble_sigma(f, theta, 0, c0, c1); first = false; }
+        else {
+            // loc params already on the device: pair kernel only
+            ModeSel ms = select_mode(theta, f->p, f->smooth_limits, 0);
+            PairArgs pa;
+            memset(&pa, 0, sizeof pa);
+            pa.n = f->n; pa.m = f->n; pa.rows = f->dloc; pa.cols = f->dloc;
+            pa.stride = f->npad; pa.stride_rows = f->npad; pa.out = f->dA; pa.ld = f->lda;
+            pa.nrows_out = f->npad; pa.ncols_out = c1; pa.bj0 = c0 / 64;
+            pa.gr = ms.gr; pa.nu_fixed = ms.nu_fixed;
+            launch_pair_sym(ms.mode, false, pa, f->stream);
+        }
+        assemble_rhs(f, mean, true, nullptr, 0, c0, c1);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static inline size_t panel_rows(cocons_fit *f, int k) { return f->lda - (size_t)k * PT * TILE; }
+
+extern "C" int cocons_shard_panel_buffer(cocons_fit *f, int k, void **dev_ptr, long long *bytes)
+{
+    if (!f || k < 0 || k >= cocons_shard_num_panels(f)) return fail(-1, "cocons_shard_panel_buffer: bad argument");
+    int w = (f->nt - k * PT) < PT ? (f->nt - k * PT) : PT;
+    if (dev_ptr) *dev_ptr = f->xbuf[k & 1];
+    if (bytes) *bytes = (long long)(panel_rows(f, k) * (size_t)w * TILE * sizeof(double));
+    return 0;
+}
+
+extern "C" int cocons_shard_panel_factor(cocons_fit *f, int k)
+{
+    if (int rc = fit_check(f)) return rc;
+    const int np = cocons_shard_num_panels(f);
+    if (k < 0 || k >= np) return fail(-1, "cocons_shard_panel_factor: bad panel");
+    const int mt = f->nt + f->rhs_cap / TILE;
+    const int t0 = k * PT;
+    hipStream_t s = f->stream;
+    double *A = f->dA;
+    launch_potrf_tile(A, f->lda, t0 * TILE, f->dinv, f->dinfo, s);
+    launch_trsm_tile(A, f->lda, t0 * TILE, (t0 + 1) * TILE, mt * TILE, f->dinv, s);
+    int w = 1;
+    if (t0 + 1 < f->nt) {
+        w = 2;
+        launch_update(A, f->lda, t0 * TILE, TILE, t0 + 1, mt, t0 + 1, t0 + 2, true, s);
+        launch_potrf_tile(A, f->lda, (t0 + 1) * TILE, f->dinv + 8 * 256, f->dinfo, s);
+        launch_trsm_tile(A, f->lda, (t0 + 1) * TILE, (t0 + 2) * TILE, mt * TILE, f->dinv + 8 * 256, s);
+    }
+    // pack rows [t0*128, lda) of the panel's columns into the exchange buffer (ld = rows)
+    size_t rows = panel_rows(f, k);
+    HIPCHK(hipMemcpy2DAsync(f->xbuf[k & 1], rows * sizeof(double),
+                            A + (size_t)t0 * TILE + (size_t)t0 * TILE * f->lda, f->lda * sizeof(double),
+                            rows * sizeof(double), (size_t)w * TILE, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int cocons_shard_panel_apply(cocons_fit *f, int k)
+{
+    if (int rc = fit_check(f)) return rc;
+    const int np = cocons_shard_num_panels(f);
+    if (k < 0 || k >= np) return fail(-1, "cocons_shard_panel_apply: bad panel");
+    const int mt = f->nt + f->rhs_cap / TILE;
+    const int t0 = k * PT;
+    const int w = (f->nt - t0) < PT ? (f->nt - t0) : PT;
+    if (t0 + w >= f->nt) return 0;      // nothing to the right
+    size_t rows = panel_rows(f, k);
+    // operand pointer such that P[row + kk*rows] addresses GLOBAL row `row`
+    const double *P = f->xbuf[k & 1] - (size_t)t0 * TILE;
+    launch_update_from(f->dA, f->lda, P, rows, w * TILE, t0 + w, mt, t0 + w, f->nt, true, f->stream,
+                       PT, f->world, f->rank);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// partial[0] = sum over OWN columns of log(diag); partial[1 + a*r + b] = own-column part of the
+// Gram matrix of the rhs rows.  The caller sums the partials over ranks (all-reduce) and takes
+// the minimum of info (0x7f7f7f7f = ok).
+extern "C" int cocons_shard_finish(cocons_fit *f, double *partial, int *info)
+{
+    if (int rc = fit_check(f)) return rc;
+    const int np = cocons_shard_num_panels(f);
+    const int nr = f->nrhs_cur, len = 1 + nr * nr;
+    int cnt = 0;
+    for (int k = f->rank; k < np; k += f->world, ++cnt) {
+        int c0 = k * PT * TILE, c1 = c0 + PT * TILE;
+        if ((size_t)(cnt + 1) * len > f->out_cap) return fail(-1, "cocons_shard_finish: reduction buffer too small");
+        launch_finalize_cols(f->dA, f->lda, c0, c1, f->n, f->npad, nr, f->dout + (size_t)cnt * len, f->stream);
+    }
+    if (cnt > 0)
+        HIPCHK(hipMemcpyAsync(f->hout, f->dout, (size_t)cnt * len * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    for (int i = 0; i < len; ++i) partial[i] = 0.0;
+    for (int c = 0; c < cnt; ++c)
+        for (int i = 0; i < len; ++i) partial[i] += f->hout[(size_t)c * len + i];
+    if (info) *info = *f->hinfo;
+    return 0;
+}

@@ -1,0 +1,236 @@
+// assemble.hip -- covariance assembly kernels (gfx950).
+//
+//   loc_params_kernel : per-location link functions, replaces the loops at
+//                       src/cocons_full.cpp:92-107 / :374-405 / :517-527 and the
+//                       inline functions of src/cocons_types.h:12-47.
+//   pair_sym_kernel   : n x n symmetric assembly over 64x64 tiles of the lower
+//                       triangle (optionally mirrored), replaces the pair loops of
+//                       cov_rns (:117-315) and cov_rns_classic (:529-591).
+//   pair_rect_kernel  : m x n cross-covariance, replaces cov_rns_pred :407-468.
+//
+// Layout: per-location SoA, LOCP_FIELDS arrays of length `stride` (coalesced:
+// lane = location).  Output is column-major; lanes run along rows so every wave
+// store is 512 contiguous bytes.  The kernels are fp64-VALU bound in the general
+// (Bessel) modes and HBM-write bound in the closed-form modes.
+//
+// Compile with -ffp-contract=off (see matern_device.hpp).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "matern_device.hpp"
+
+namespace cocons {
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+loc_params_kernel(LocArgs a)
+{
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.n) return;
+    const int p = a.p;
+    double t_tilt = 0, t_rd = 0, t_an = 0, t_dets = 0, t_sig = 0, t_ng = 0, t_sm = 0, t_sd = 0;
+    for (int i = 0; i < p; ++i) {           // fma chains in column order, types.h:14-16
+        double x = a.X[w + (size_t)i * a.ldx];
+        t_tilt = fma(x, a.th.tilt[i], t_tilt);
+        t_rd = fma(x, a.th.two_scale_je[i], t_rd);
+        t_an = fma(x, a.th.aniso[i], t_an);
+        t_dets = fma(x, a.th.sqrt_vector[i], t_dets);
+        t_sig = fma(x, a.th.half_sd[i], t_sig);
+        t_ng = fma(x, a.th.nugget[i], t_ng);
+        t_sm = fma(x, a.th.smooth[i], t_sm);
+        t_sd = fma(x, a.th.sd[i], t_sd);
+    }
+    const double pi = 3.14159265358979323846;
+    double tilt = pi / (1 + exp(-1 * t_tilt));          // types.h:46
+    double rd = 1 / exp(-1 * t_rd);                     // types.h:17
+    double an = 1 / exp(-1 * t_an);
+    double dets = 1 / exp(-1 * t_dets);
+    double sigma = 1 / exp(-1 * t_sig);
+    double ng = 1 / exp(-1 * t_ng);
+    double snu;
+    if (a.smooth_kind == SMOOTH_LOGISTIC_SQRT)          // cocons_full.cpp:93, :381, :401
+        snu = sqrt((a.smooth_max - a.smooth_min) / (1 + exp(-1 * t_sm)) + a.smooth_min);
+    else if (a.smooth_kind == SMOOTH_EXP)               // :524
+        snu = 1 / exp(-1 * t_sm);
+    else                                                // fixed-nu branch leaves zeros, :83-88
+        snu = 0.0;
+    double st = sin(tilt), ct = cos(tilt);
+    double *o = a.out;
+    size_t s = a.stride;
+    o[w + 0 * s] = a.locs[w];
+    o[w + 1 * s] = a.locs[w + (size_t)a.ldl];
+    o[w + 2 * s] = rd;
+    o[w + 3 * s] = an * an;
+    o[w + 4 * s] = rd * an;
+    o[w + 5 * s] = ct;
+    o[w + 6 * s] = st;
+    o[w + 7 * s] = dets;
+    o[w + 8 * s] = dets * st;
+    o[w + 9 * s] = sigma;
+    o[w + 10 * s] = snu;
+    o[w + 11 * s] = (1 / exp(-1 * t_sd)) + ng;          // :111
+}
+
+__device__ __forceinline__ LocP load_locp(const double *base, size_t stride, int w)
+{
+    LocP r;
+    r.x = base[w + 0 * stride];
+    r.y = base[w + 1 * stride];
+    r.rd = base[w + 2 * stride];
+    r.an2 = base[w + 3 * stride];
+    r.ra = base[w + 4 * stride];
+    r.ct = base[w + 5 * stride];
+    r.st = base[w + 6 * stride];
+    r.dets = base[w + 7 * stride];
+    r.ds = base[w + 8 * stride];
+    r.sigma = base[w + 9 * stride];
+    r.snu = base[w + 10 * stride];
+    r.diag = base[w + 11 * stride];
+    return r;
+}
+
+constexpr int TS = 64;   // pair tile edge
+
+// Symmetric assembly.  One workgroup (256 threads) per 64x64 tile (bi >= bj) of the
+// lower triangle, tile columns from a.bj0 up to ncols_out; lane = row, each wave sweeps 16 columns whose parameters are
+// wave-uniform (scalar loads).  Entry (r,c), r>c, is evaluated with ii=c, jj=r --
+// the reference's (ii<jj) orientation.  npad rows/cols beyond n are written as the
+// identity (unit diagonal, zero elsewhere) for the padded factorisation buffer.
+template <int MODE, bool MIRROR>
+__global__ void __launch_bounds__(256)
+pair_sym_kernel(PairArgs a)
+{
+    __shared__ double tile[MIRROR ? TS * (TS + 1) : 1];
+    // 2-D grid over 64x64 tiles; only the lower triangle (bi >= bj) does work
+    const int bi = blockIdx.x, bj = a.bj0 + blockIdx.y;
+    if (bj > bi) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = bi * TS + lane;
+    const int n = a.n;
+    LocP R;
+    if (r < n) R = load_locp(a.rows, a.stride, r);
+    for (int cc = 0; cc < TS / 4; ++cc) {
+        int cl = wave * (TS / 4) + cc;
+        int c = bj * TS + cl;
+        if (c >= a.ncols_out) break;
+        double v;
+        if (r >= n || c >= n) {
+            v = (r == c) ? 1.0 : 0.0;
+        } else if (r == c) {
+            v = R.diag;
+        } else {
+            LocP C = load_locp(a.rows, a.stride, c);     // wave-uniform -> scalar loads
+            v = (r > c) ? pair_value<MODE>(C, R, a.gr, a.nu_fixed)
+                        : pair_value<MODE>(R, C, a.gr, a.nu_fixed);
+        }
+        if (r < a.nrows_out) a.out[(size_t)r + (size_t)c * a.ld] = v;
+        if (MIRROR) tile[cl * (TS + 1) + lane] = v;
+    }
+    if (MIRROR && bi != bj) {
+        __syncthreads();
+        // transposed write: out[c_global, r_global] for the mirrored tile, coalesced along c
+        int c = bj * TS + lane;
+        for (int rr = 0; rr < TS / 4; ++rr) {
+            int rl = wave * (TS / 4) + rr;
+            int rg = bi * TS + rl;
+            if (c < a.nrows_out && rg < a.ncols_out)
+                a.out[(size_t)c + (size_t)rg * a.ld] = tile[lane * (TS + 1) + rl];
+        }
+    }
+}
+
+// Rectangular cross-covariance: rows = prediction locations (first / "ii" side),
+// columns = observation locations.  Exact coordinate match -> prediction-side
+// diagonal value (cocons_full.cpp:410-414).
+template <int MODE>
+__global__ void __launch_bounds__(256)
+pair_rect_kernel(PairArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * TS + lane;          // prediction location
+    const int m = a.m;
+    LocP R;
+    if (r < m) R = load_locp(a.rows, a.stride_rows, r);
+    for (int cc = 0; cc < TS / 4; ++cc) {
+        int c = blockIdx.y * TS + wave * (TS / 4) + cc;
+        if (c >= a.ncols_out) break;
+        double v = 0.0;
+        if (r < m && c < a.n) {
+            LocP C = load_locp(a.cols, a.stride, c);
+            if (R.x == C.x && R.y == C.y) v = R.diag;
+            else v = pair_value<MODE>(R, C, a.gr, a.nu_fixed);
+        }
+        if (r < a.nrows_out) a.out[(size_t)r + (size_t)c * a.ld] = v;
+    }
+}
+
+// rows of right-hand sides under the matrix: out[row0 + k, c] = src[c + k*lds] - trend[c]
+// (trend = X %*% mean, R/neg2loglikelihood.R:210,213), zero beyond n.
+__global__ void __launch_bounds__(256)
+rhs_rows_kernel(RhsArgs a)
+{
+    int c = a.col0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.ncols_out) return;
+    double trend = 0.0;
+    if (a.use_trend && c < a.n) {
+        // R's %*% is a plain dot product; order i ascending
+        for (int i = 0; i < a.p; ++i) trend += a.X[c + (size_t)i * a.ldx] * a.mean[i];
+    }
+    for (int k = 0; k < a.nrows; ++k) {
+        double v = 0.0;
+        if (c < a.n) v = a.src[c + (size_t)k * a.lds] - trend;
+        a.out[(size_t)(a.row0 + k) + (size_t)c * a.ld] = v;
+    }
+    for (int k = a.nrows; k < a.nrows + a.nrows_zero; ++k)
+        a.out[(size_t)(a.row0 + k) + (size_t)c * a.ld] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+void launch_loc_params(const LocArgs &a, hipStream_t s)
+{
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(loc_params_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+}
+
+template <bool MIRROR>
+static void launch_sym_mode(int mode, const PairArgs &a, dim3 g, hipStream_t s)
+{
+    dim3 b(256);
+    switch (mode) {
+    case MODE_HALF: hipLaunchKernelGGL((pair_sym_kernel<MODE_HALF, MIRROR>), g, b, 0, s, a); break;
+    case MODE_THREEHALF: hipLaunchKernelGGL((pair_sym_kernel<MODE_THREEHALF, MIRROR>), g, b, 0, s, a); break;
+    case MODE_FIVEHALF: hipLaunchKernelGGL((pair_sym_kernel<MODE_FIVEHALF, MIRROR>), g, b, 0, s, a); break;
+    case MODE_MEAN: hipLaunchKernelGGL((pair_sym_kernel<MODE_MEAN, MIRROR>), g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL((pair_sym_kernel<MODE_GEOM, MIRROR>), g, b, 0, s, a); break;
+    }
+}
+
+void launch_pair_sym(int mode, bool mirror, const PairArgs &a, hipStream_t s)
+{
+    int ext = a.nrows_out > a.ncols_out ? a.nrows_out : a.ncols_out;
+    if (ext <= 0) return;
+    int T = (ext + TS - 1) / TS;
+    int tj1 = (a.ncols_out + TS - 1) / TS;
+    if (tj1 <= a.bj0) return;
+    dim3 g(T, tj1 - a.bj0);
+    if (mirror) launch_sym_mode<true>(mode, a, g, s);
+    else launch_sym_mode<false>(mode, a, g, s);
+}
+
+void launch_pair_rect(int mode, const PairArgs &a, hipStream_t s)
+{
+    if (a.nrows_out <= 0 || a.ncols_out <= 0) return;
+    dim3 g((a.nrows_out + TS - 1) / TS, (a.ncols_out + TS - 1) / TS), b(256);
+    if (mode == MODE_MEAN) hipLaunchKernelGGL((pair_rect_kernel<MODE_MEAN>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((pair_rect_kernel<MODE_GEOM>), g, b, 0, s, a);
+}
+
+void launch_rhs_rows(const RhsArgs &a, hipStream_t s)
+{
+    int nc = a.ncols_out - a.col0;
+    if (nc <= 0 || a.nrows + a.nrows_zero <= 0) return;
+    hipLaunchKernelGGL(rhs_rows_kernel, dim3((nc + 255) / 256), dim3(256), 0, s, a);
+}
+
+}  // namespace cocons

@@ -1,0 +1,100 @@
+// kernels.h -- argument blocks and launchers shared by the HIP sources and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "../../include/cocons_hip.h"
+
+namespace cocons {
+
+enum SmoothKind : int {
+    SMOOTH_ZERO = 0,           // fixed-smoothness branch: vector stays zero (cocons_full.cpp:83-88)
+    SMOOTH_LOGISTIC_SQRT = 1,  // sqrt(Pexpfma_new_smoothness) (:93)
+    SMOOTH_EXP = 2             // classic: Pexpfma_new(smooth) (:524)
+};
+
+// theta-derived coefficient vectors, formed on the host exactly as the reference forms
+// them (2*scale_je, 2*scale_je+aniso, 0.5*std.dev; cocons_full.cpp:64-66,101-104) and
+// passed by value in the kernel-argument segment (no per-evaluation H2D copy).
+struct ThetaVecs {
+    double tilt[COCONS_P_MAX];
+    double two_scale_je[COCONS_P_MAX];
+    double aniso[COCONS_P_MAX];
+    double sqrt_vector[COCONS_P_MAX];
+    double half_sd[COCONS_P_MAX];
+    double nugget[COCONS_P_MAX];
+    double smooth[COCONS_P_MAX];
+    double sd[COCONS_P_MAX];
+};
+
+struct LocArgs {
+    int n, p;
+    const double *X; int ldx;       // n x p column-major
+    const double *locs; int ldl;    // n x 2 column-major
+    double *out; size_t stride;     // LOCP_FIELDS x stride SoA
+    int smooth_kind;
+    double smooth_min, smooth_max;
+    ThetaVecs th;
+};
+
+struct PairArgs {
+    int n;                 // number of (column-side) locations
+    int m;                 // rect only: number of row-side locations
+    const double *rows;    // SoA of the row side (== cols for the symmetric kernel)
+    const double *cols;    // SoA of the column side
+    size_t stride;         // SoA stride of the column side (and rows for sym)
+    size_t stride_rows;    // SoA stride of the row side (rect)
+    double *out; size_t ld;
+    int nrows_out, ncols_out;   // extent to write (>= n pads with identity / zeros)
+    int bj0;               // sym: first 64-wide tile column to assemble (sharded path), else 0
+    double gr;             // global_range
+    double nu_fixed;       // closed-form modes
+};
+
+struct RhsArgs {
+    int n, p;
+    const double *X; int ldx;
+    double mean[COCONS_P_MAX];
+    int use_trend;
+    const double *src; int lds;     // n x nrows column-major (z or x_betas)
+    double *out; size_t ld;
+    int row0, nrows;       // nrows source rows, written at out rows row0..
+    int nrows_zero;        // further rows (row0+nrows ..) cleared to zero
+    int col0, ncols_out;   // column range [col0, ncols_out)
+};
+
+void launch_loc_params(const LocArgs &a, hipStream_t s);
+void launch_pair_sym(int mode, bool mirror, const PairArgs &a, hipStream_t s);
+void launch_pair_rect(int mode, const PairArgs &a, hipStream_t s);
+void launch_rhs_rows(const RhsArgs &a, hipStream_t s);
+
+// ---- factorisation (chol.hip) -------------------------------------------------
+constexpr int TILE = 128;          // tile edge of the blocked factorisation
+
+// Factor the 128x128 diagonal tile at (c0,c0) in place (lower), write the inverses of
+// its eight 16x16 diagonal blocks to dinv (8*256 doubles).  info: atomicMin of the
+// 1-based failing column (initialise to INT_MAX).
+void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, hipStream_t s);
+// rows [r0, r1) x cols [c0, c0+128):  X <- X * L(c0)^{-T}, L read from A(c0,c0)
+void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s);
+// C(i,j) -= sum_{k in [k0,k0+K)} A(i,k) A(j,k) for tiles with tile-row in [ti0,ti1),
+// tile-col in [tj0,tj1); lower_only keeps ti >= tj.  All tile indices in units of TILE.
+void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
+                   bool lower_only, hipStream_t s);
+// like launch_update but the (i,k) and (j,k) operands come from a separate packed
+// panel buffer P (ldp rows, row index = global row), used by the sharded path.
+// (ptiles, world, rank): when world > 1 only tile columns tj with (tj / ptiles) % world == rank
+// are updated (block-cyclic panel ownership).
+void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
+                        int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
+                        int ptiles, int world, int rank);
+
+// reductions: out[0] = sum_{i<n} log(A(i,i)); out[1 + a*nr + b] = sum_{c<n} A(row0+a,c) A(row0+b,c)
+void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s);
+// partial version over columns [c0,c1) accumulating into out (atomic adds), sharded path
+void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
+                          double *out, hipStream_t s);
+// per-row reductions for predict: stoch[i] = sum_c A(rowy,c) A(row0+i,c); quad[i] = sum_c A(row0+i,c)^2
+void launch_row_reduce(const double *A, size_t lda, int n, int rowy, int row0, int m,
+                       double *stoch, double *quad, hipStream_t s);
+
+}  // namespace cocons

@@ -1,0 +1,154 @@
+/*
+ * cocons_hip.h -- C ABI of the MI355X-native dense hot path of blasif/cocons.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / Rcpp types.
+ * Every entry point names the reference interface it replaces (paths relative to
+ * the reference tree).  The R-side `.Call` glue a maintainer would add is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - matrices are column-major (R layout); `locs` is n x 2, `X` is n x p.
+ *   - `theta` is a 6 x p row-major table in the order of the reference's
+ *     dictionary minus "mean" (R/profile.R:5-7): std.dev, scale, aniso, tilt,
+ *     smooth, nugget -- i.e. what `theta_list[-1]` carries by name
+ *     (src/cocons_full.cpp:47-54).
+ *   - return value: 0 ok; k > 0 = leading minor of order k is not positive
+ *     (LAPACK dpotrf convention; the glue maps it to the reference's 1e+06
+ *     sentinel or stop("Cholesky error"), R/neg2loglikelihood.R:200-206);
+ *     < 0 = bad argument or HIP error, text in cocons_last_error().
+ *   - nothing throws, aborts or exits; no HIP call happens at load time
+ *     (fork-safe: the device context is created lazily per process).
+ */
+#ifndef COCONS_HIP_H
+#define COCONS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COCONS_P_MAX 32          /* max columns of the design matrix */
+
+typedef struct cocons_fit cocons_fit;   /* opaque: device-resident data of one model fit */
+
+/* library ------------------------------------------------------------------ */
+const char *cocons_last_error(void);
+int cocons_abi_version(void);
+/* number of visible HIP devices (>=0), or <0 on error */
+int cocons_device_count(void);
+
+/* ---- stateless covariance assembly (host buffers in, host buffer out) --------
+ * replaces .Call("_cocons_cov_rns", theta, locs, x_covariates, smooth_limits)
+ *   src/RcppExports.cpp:29-40 -> cov_rns, src/cocons_full.cpp:40-321          */
+int cocons_cov_rns(int n, int p, const double *theta, const double *locs,
+                   const double *X, const double *smooth_limits, double *out_nxn);
+/* replaces .Call("_cocons_cov_rns_classic", theta, locs, x_covariates)
+ *   src/RcppExports.cpp:59-69 -> cov_rns_classic, src/cocons_full.cpp:480-594  */
+int cocons_cov_rns_classic(int n, int p, const double *theta, const double *locs,
+                           const double *X, double *out_nxn);
+/* replaces .Call("_cocons_cov_rns_pred", theta, locs, locs_pred, x_covariates,
+ *                x_covariates_pred, smooth_limits)
+ *   src/RcppExports.cpp:43-56 -> cov_rns_pred, src/cocons_full.cpp:334-471
+ * out is m x n column-major, row = prediction location.                        */
+int cocons_cov_rns_pred(int n, int m, int p, const double *theta, const double *locs,
+                        const double *locs_pred, const double *X, const double *X_pred,
+                        const double *smooth_limits, double *out_mxn);
+/* replaces .Call("_cocons_sumsmoothlone", x, lambda, alpha)
+ *   src/RcppExports.cpp:16-26 -> sumsmoothlone, src/cocons_full.cpp:12-30 (host, O(p)) */
+double cocons_sumsmoothlone(const double *x, int len, double lambda, double alpha);
+
+/* ---- fit handle: everything that is constant over an optimisation -------------
+ * Created once per cocoOptim / getHessian call from the arguments the reference
+ * passes unchanged to every GetNeg2loglikelihood* evaluation
+ * (R/optim.R:237-259): locs, x_covariates (= mod_DM), z (n x r), optional
+ * x_betas (n x q, Profile only), smooth.limits.  After creation only O(p) bytes
+ * cross PCIe per evaluation.  `device` < 0 picks (pid-stable) device 0.
+ * `n_extra_rows` reserves room for cocons_predict_dense (0 if unused).          */
+cocons_fit *cocons_fit_create(int n, int p, int r, int q, const double *locs,
+                              const double *X, const double *z, const double *x_betas,
+                              const double *smooth_limits, int device);
+void cocons_fit_destroy(cocons_fit *fit);
+
+/* Fused -2 log-likelihood core: replaces the chain
+ *   cov_rns -> base::chol (dpotrf) -> sum(log(diag)) -> forwardsolve (dtrsm) -> crossprod
+ * of GetNeg2loglikelihood, R/neg2loglikelihood.R:195-218.
+ * `mean` (length p) is theta_list$mean.  Outputs:
+ *   *sum_logliks = sum_k [ n log(2 pi) + 2 logdet + || R^-T (z_k - X mean) ||^2 ]
+ *   parts[0] = sum(log(diag(chol))), parts[1..r] = the r quadratic forms (may be NULL)
+ * The penalty (.cocons.getPen, R/checkFunctions.R:474-492) is O(p) host work and
+ * stays with the caller.                                                         */
+int cocons_neg2loglik_dense(cocons_fit *fit, const double *theta, const double *mean,
+                            double *sum_logliks, double *parts);
+
+/* Profile / REML cores: replace R/neg2loglikelihood.R:132-160 and :254-287.
+ * Both avoid chol2inv and the n x n P_mat through
+ *   z' P z = ||L^-1 z||^2 - (Y'y)' (Y'Y)^-1 (Y'y),  Y = L^-1 Xb, y = L^-1 z.
+ * profile: Xb = x_betas given at fit creation (q columns);
+ * reml:    Xb = x_covariates (as the reference does, :273-276); `rank` = qr(X)$rank,
+ *          computed by the caller.  parts[0] = sum(log(diag(chol))),
+ * parts[1] = sum(log(diag(chol(W)))) (reml only), parts[2..] = quadratic forms. */
+int cocons_neg2loglik_profile(cocons_fit *fit, const double *theta,
+                              double *sum_logliks, double *parts);
+int cocons_neg2loglik_reml(cocons_fit *fit, const double *theta, int rank,
+                           double *sum_logliks, double *parts);
+
+/* Dense kriging core: replaces R/predict.R:136-183
+ *   observed_cov <- cov_rns(...); cov_pred <- cov_rns_pred(...);
+ *   inv_cov <- solve(observed_cov, t(cov_pred)); crossprod(resid, inv_cov);
+ *   rowSums(cov_pred * t(inv_cov))
+ * with one bordered Cholesky (Sigma is SPD) instead of LU.  Uses the first
+ * realization column `z_col` of the fit's z.  Outputs (length m):
+ *   stochastic[i] = c_i' Sigma^-1 (z - X mean),  quadform[i] = c_i' Sigma^-1 c_i     */
+int cocons_predict_dense(cocons_fit *fit, const double *theta, const double *mean,
+                         int z_col, int m, const double *locs_pred, const double *X_pred,
+                         double *stochastic, double *quadform);
+
+/* Dense Cholesky of a caller-supplied SPD matrix (host, n x n column-major, lower
+ * triangle read) with nrhs right-hand sides: replaces base::chol + forwardsolve
+ * (R/neg2loglikelihood.R:200,214) for callers that already hold Sigma.
+ * L (optional, n x n) receives the lower factor (= t(chol(Sigma))), Y (optional,
+ * n x nrhs) receives L^-1 rhs, logdet_half = sum(log(diag(L))).                   */
+int cocons_chol_solve(int n, const double *A, int nrhs, const double *rhs,
+                      double *L, double *Y, double *logdet_half);
+
+/* ---- measurement hooks (bench.py / rocprof): device-resident, no host copies ---
+ * Runs `reps` complete evaluations of cocons_neg2loglik_dense back to back on the
+ * fit's stream with HIP events around each stage.  ms[0]=assembly, ms[1]=Cholesky
+ * (+solve, fused), ms[2]=reductions, ms[3]=whole evaluation, ms[4]=average duration
+ * of one trailing-update (MFMA) launch, ms[5]=number of such launches per
+ * evaluation, ms[6]=sum of trailing-update launch durations per evaluation.      */
+int cocons_fit_profile(cocons_fit *fit, const double *theta, const double *mean,
+                       int reps, double *ms);
+
+/* ---- column-panel sharded evaluation across GPUs (one process per GPU) ---------
+ * The reference's chol reads the UPPER triangle of Sigma row by row; its row
+ * blocks are exactly the column panels of the lower factor kept here.  Panels
+ * are dealt block-cyclically over `world` ranks; the caller (torch.distributed
+ * over RCCL, see cocons_amd/shard.py) broadcasts each factored panel.
+ *   shard_begin : assemble the rank's own panels for this theta
+ *   shard_panel_factor(k) : owner only -- factor panel k in place (needs all
+ *                  updates from panels < k applied), pack it into the exchange buffer
+ *   shard_panel_buffer : device pointer + bytes of the exchange buffer for panel k
+ *   shard_panel_apply(k) : every rank, after the broadcast -- update own panels > k
+ *   shard_finish : local partial sums (logdet_half, Gram of the rhs rows) -> host  */
+int cocons_shard_begin(cocons_fit *fit, const double *theta, const double *mean,
+                       int rank, int world);
+int cocons_shard_panel_factor(cocons_fit *fit, int k);
+int cocons_shard_panel_buffer(cocons_fit *fit, int k, void **dev_ptr, long long *bytes);
+int cocons_shard_panel_apply(cocons_fit *fit, int k);
+int cocons_shard_finish(cocons_fit *fit, double *partial /* 1 + (r)(r) */, int *info);
+int cocons_shard_num_panels(cocons_fit *fit);
+/* bytes one exchange buffer must hold; optionally hand in two caller-owned device
+ * buffers (e.g. torch tensors, so torch.distributed can broadcast them in place) */
+long long cocons_shard_exchange_bytes(cocons_fit *fit);
+int cocons_shard_set_exchange(cocons_fit *fit, void *buf0, void *buf1, long long bytes);
+/* HIP stream the fit launches on (hipStream_t as void*), so the caller can order
+ * collectives against it. */
+void *cocons_fit_stream(cocons_fit *fit);
+/* launch on a caller-owned stream instead (hipStream_t as void*; NULL = default stream) */
+int cocons_fit_set_stream(cocons_fit *fit, void *stream);
+int cocons_fit_sync(cocons_fit *fit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COCONS_HIP_H */

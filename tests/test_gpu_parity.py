@@ -1,0 +1,235 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, the mpmath
+golden vectors and closed forms.  Run on the GPU box with `pytest -m gpu`.
+
+Tolerances (fp64 path; north star: -2 loglik within 1e-8 relative of the CPU path):
+  ENTRY_RTOL  entrywise Sigma vs oracle, relative to the entry (closed-form and Bessel modes)
+  N2LL_RTOL   -2 log-likelihood vs the CPU (LAPACK) path
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ENTRY_RTOL = 2e-12
+N2LL_RTOL = 1e-8
+
+
+def _problem(n, seed=0, scale0=np.log(0.2)):
+    from cocons_amd import workloads as wl
+    rng = np.random.default_rng(seed)
+    locs = rng.uniform(0, 1, size=(n, 2))
+    X = wl.design_from_locs(locs)["std.covs"]
+    th = wl.theta_full(scale0=scale0)
+    return locs, X, th, rng
+
+
+def _relerr(a, b, floor=1e-290):
+    a, b = np.asarray(a), np.asarray(b)
+    mask = np.abs(b) > floor
+    return float(np.max(np.abs(a[mask] - b[mask]) / np.abs(b[mask]))) if mask.any() else 0.0
+
+
+@pytest.mark.parametrize("nu", [0.5, 1.5, 2.5])
+def test_cov_rns_closed_form_modes(oracle, nu):
+    import cocons_amd as ca
+    locs, X, th, _ = _problem(301, seed=1)
+    th["smooth"] = np.zeros(3)
+    got = ca.cov_rns(th, locs, X, (nu, nu))
+    want = oracle.cov_rns(th, locs, X, (nu, nu))
+    assert got.shape == (301, 301)
+    assert np.array_equal(got, got.T)
+    assert _relerr(got, want) < ENTRY_RTOL
+
+
+def test_cov_rns_general_bessel(oracle):
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, _ = _problem(333, seed=2)
+    got = ca.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    want = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    assert np.array_equal(got, got.T)
+    assert _relerr(got, want) < ENTRY_RTOL
+
+
+def test_cov_rns_small_range_large_u(oracle):
+    """tiny range -> u up to and beyond 706 (asymptotic branch, cocons_full.cpp:301-305)."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, _ = _problem(200, seed=3, scale0=np.log(0.004))
+    got = ca.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    want = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    big = np.abs(want) > 1e-250
+    assert _relerr(got[big], want[big]) < ENTRY_RTOL
+    assert np.all(np.abs(got[~big] - want[~big]) < 1e-250)
+
+
+def test_cov_rns_fixed_nu_quirk(oracle):
+    """fixed smoothness not in {0.5,1.5,2.5}: the reference leaves the smooth vector at zero
+    and every off-diagonal equals the ii diagonal value (SURVEY 8a#6 quirk i)."""
+    import cocons_amd as ca
+    locs, X, th, _ = _problem(130, seed=4)
+    th["smooth"] = np.zeros(3)
+    got = ca.cov_rns(th, locs, X, (1.0, 1.0))
+    want = oracle.cov_rns(th, locs, X, (1.0, 1.0))
+    assert _relerr(got, want) < ENTRY_RTOL
+    i, j = 3, 77
+    assert got[j, i] == got[i, i]
+
+
+def test_cov_rns_no_nugget_and_duplicates(oracle):
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, _ = _problem(150, seed=5)
+    th["nugget"] = np.array([-np.inf, 0.0, 0.0])
+    locs[10] = locs[3]
+    X[10] = X[3]
+    got = ca.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    want = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    assert _relerr(got, want) < ENTRY_RTOL
+    assert got[10, 3] == got[3, 3]          # u <= eps -> diagonal value of ii
+
+
+def test_cov_rns_classic_and_pred(oracle):
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, rng = _problem(257, seed=6)
+    thc = dict(th)
+    thc["smooth"] = np.array([np.log(1.2), 0.2, -0.1])
+    got = ca.cov_rns_classic(thc, locs, X)
+    want = oracle.cov_rns_classic(thc, locs, X)
+    assert _relerr(got, want) < ENTRY_RTOL
+    m = 190
+    lp = rng.uniform(0, 1, size=(m, 2))
+    lp[5] = locs[17]
+    Xp = wl.design_from_locs(lp)["std.covs"]
+    gotp = ca.cov_rns_pred(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS)
+    wantp = oracle.cov_rns_pred(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS)
+    assert gotp.shape == (m, 257)
+    assert _relerr(gotp, wantp) < ENTRY_RTOL
+
+
+def test_golden_mpmath_n20(golden_dir):
+    import cocons_amd as ca
+    g = json.load(open(os.path.join(golden_dir, "cov_nonstat_n20.json")))
+
+    def dec(t):
+        return {k: np.array([float(v) for v in vs]) for k, vs in t.items()}
+
+    locs, X = np.array(g["locs"]), np.array(g["X"])
+    S = ca.cov_rns(dec(g["theta"]), locs, X, g["smooth_limits"])
+    assert _relerr(S, np.array(g["cov_rns"])) < 1e-13
+    Sc = ca.cov_rns_classic(dec(g["theta_classic"]), locs, X)
+    assert _relerr(Sc, np.array(g["cov_rns_classic"])) < 1e-13
+    C = ca.cov_rns_pred(dec(g["theta"]), locs, np.array(g["locs_pred"]), X, np.array(g["X_pred"]),
+                        g["smooth_limits"])
+    assert _relerr(C, np.array(g["cov_rns_pred"])) < 1e-13
+    n2 = json.load(open(os.path.join(golden_dir, "neg2loglik_n20.json")))
+    th = dec(g["theta"])
+    fit = ca.CoconsFit(locs, X, np.array(n2["z"]), g["smooth_limits"])
+    val, parts = fit.neg2loglik_core(th)
+    assert abs(parts[0] - n2["logdet_half"]) < 1e-12 * max(1, abs(n2["logdet_half"]))
+    assert abs(parts[1] - n2["quad"]) < 1e-11 * abs(n2["quad"])
+    assert abs(val - n2["neg2loglik_nopen"]) < 1e-12 * abs(n2["neg2loglik_nopen"])
+
+
+@pytest.mark.parametrize("n", [100, 128, 300, 513])
+def test_chol_solve_vs_long_double(oracle, n):
+    from cocons_amd import _lib
+    import ctypes
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n))
+    A = np.asfortranarray(B @ B.T + n * np.eye(n))
+    rhs = np.asfortranarray(rng.standard_normal((n, 3)))
+    L = np.zeros((n, n), order="F")
+    Y = np.zeros((n, 3), order="F")
+    ld = ctypes.c_double()
+    lib = _lib.load()
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib.cocons_chol_solve(n, A.ctypes.data_as(dp), 3, rhs.ctypes.data_as(dp), L.ctypes.data_as(dp),
+                               Y.ctypes.data_as(dp), ctypes.byref(ld))
+    assert rc == 0, _lib.last_error()
+    info, ld_true, quad, Ytrue = oracle.chol_ld(A, rhs)
+    assert info == 0
+    assert abs(ld.value - ld_true) < 1e-12 * abs(ld_true)
+    assert np.max(np.abs(Y - Ytrue)) < 1e-11 * np.max(np.abs(Ytrue))
+    assert np.max(np.abs(L @ L.T - A)) < 1e-12 * np.max(np.abs(A))
+
+
+def test_chol_not_positive_definite():
+    from cocons_amd import _lib
+    import ctypes
+    n = 200
+    A = np.asfortranarray(np.eye(n))
+    A[150, 150] = -1.0
+    lib = _lib.load()
+    dp = ctypes.POINTER(ctypes.c_double)
+    ld = ctypes.c_double()
+    rc = lib.cocons_chol_solve(n, A.ctypes.data_as(dp), 0, None, None, None, ctypes.byref(ld))
+    assert rc == 151
+
+
+@pytest.mark.parametrize("n", [300, 700])
+def test_neg2loglik_vs_cpu(oracle, n):
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, rng = _problem(n, seed=n)
+    z = rng.standard_normal((n, 2))
+    pp = wl.par_pos_full()
+    tv = wl.theta_vector_from_lists(th, pp)
+    lam = (0.1, 0.2, 0.3)
+    got = ca.GetNeg2loglikelihood(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+    want = oracle.GetNeg2loglikelihood(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+    assert abs(got - want) <= N2LL_RTOL * abs(want)
+
+
+def test_neg2loglik_safe_sentinel():
+    """Cholesky failure -> exactly 1e6 when safe, error otherwise (R/neg2loglikelihood.R:200-206)."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, rng = _problem(140, seed=9)
+    th["smooth"] = np.zeros(3)            # fixed nu = 1.0 quirk -> singular Sigma
+    pp = wl.par_pos_full()
+    pp["smooth"] = 0.0
+    tv = wl.theta_vector_from_lists(th, pp)
+    z = rng.standard_normal(140)
+    assert ca.GetNeg2loglikelihood(tv, pp, locs, X, (1.0, 1.0), z, 140, (0, 0, 0)) == 1e6
+    with pytest.raises(RuntimeError, match="Cholesky error"):
+        ca.GetNeg2loglikelihood(tv, pp, locs, X, (1.0, 1.0), z, 140, (0, 0, 0), safe=False)
+
+
+def test_profile_and_reml_vs_cpu(oracle):
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n = 260
+    locs, X, th, rng = _problem(n, seed=11)
+    z = rng.standard_normal((n, 2)) + 0.5
+    pp = wl.par_pos_full()
+    tv = wl.theta_vector_from_lists(th, pp)
+    lam = (0.1, 0.0, 0.3)
+    got = ca.GetNeg2loglikelihoodProfile(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam)
+    want = oracle.GetNeg2loglikelihoodProfile(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam)
+    assert abs(got - want) <= N2LL_RTOL * abs(want)
+    got = ca.GetNeg2loglikelihoodREML(tv, pp, locs, X, X, wl.SMOOTH_LIMITS, z, n, lam)
+    want = oracle.GetNeg2loglikelihoodREML(tv, pp, locs, X, X, wl.SMOOTH_LIMITS, z, n, lam)
+    assert abs(got - want) <= N2LL_RTOL * abs(want)
+
+
+def test_predict_vs_cpu(oracle):
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n, m = 280, 150
+    locs, X, th, rng = _problem(n, seed=12)
+    th["mean"] = np.array([0.2, -0.1, 0.05])
+    lp = rng.uniform(0, 1, size=(m, 2))
+    lp[7] = locs[30]
+    sc = wl.design_from_locs(locs)
+    Xp = wl.design_from_locs(lp, sc["mean.vector"], sc["sd.vector"])["std.covs"]
+    z = rng.standard_normal(n)
+    got = ca.cocoPredict_dense(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS, z)
+    want = oracle.cocoPredict_dense(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS, z)
+    assert np.allclose(got["systematic"], want["systematic"], rtol=1e-13, atol=0)
+    assert np.max(np.abs(got["stochastic"] - want["stochastic"])) < 1e-9 * np.max(np.abs(want["stochastic"]))
+    assert np.max(np.abs(got["sd.pred"] - want["sd.pred"])) < 1e-8 * np.max(np.abs(want["sd.pred"]))
