@@ -708,6 +708,8 @@ extern "C" int cocons_chol_solve(int n, const double *Ain, int nrhs, const doubl
         if ((rc = reset_info(f))) break;
         factorize(f, mt, nullptr);
         launch_finalize(f->dA, f->lda, n, f->npad, 0, f->dout, s);
+        e = hipStreamSynchronize(s);     // the fit's stream is non-blocking: order the copies below
+        if (e != hipSuccess) { rc = fail(-100, "cocons_chol_solve: %s", hipGetErrorString(e)); break; }
         e = hipMemcpy(hostA.data(), f->dA, hostA.size() * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rc = fail(-100, "cocons_chol_solve: %s", hipGetErrorString(e)); break; }
         hipMemcpy(f->hout, f->dout, sizeof(double), hipMemcpyDeviceToHost);

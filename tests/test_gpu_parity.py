@@ -232,4 +232,8 @@ def test_predict_vs_cpu(oracle):
     want = oracle.cocoPredict_dense(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS, z)
     assert np.allclose(got["systematic"], want["systematic"], rtol=1e-13, atol=0)
     assert np.max(np.abs(got["stochastic"] - want["stochastic"])) < 1e-9 * np.max(np.abs(want["stochastic"]))
-    assert np.max(np.abs(got["sd.pred"] - want["sd.pred"])) < 1e-8 * np.max(np.abs(want["sd.pred"]))
+    # compare predictive VARIANCES: at the coincident point the variance is rounding noise
+    # around 0 and the reference's sqrt(abs(.)) (R/predict.R:175-183) amplifies that noise
+    vg, vw = got["sd.pred"] ** 2, want["sd.pred"] ** 2
+    assert np.max(np.abs(vg - vw)) < 1e-11 * np.max(vw)
+    assert got["sd.pred"][7] < 1e-6 and want["sd.pred"][7] < 1e-6
