@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the dense hot path on MI355X.
+
+Metric (BASELINE.json): -2 log-likelihood evaluations per second at n = 10 000 (100 x 100
+grid, full nonstationary cov_rns: std.dev, scale, aniso, tilt, smooth ~ 1 + x + y, nu in
+[0.5, 2.5], nugget), i.e. one "step" = one GetNeg2loglikelihood core evaluation =
+covariance assembly + bordered Cholesky (factorisation + solve fused) + reductions, with the
+fit's inputs (locs, X, z) already resident in HBM.  Cholesky fp64 TFLOP/s is reported
+beside it (n^3/3 flop per evaluation).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n 10000] [--mode shard|replica]
+
+N = 1 : one GPU evaluates the whole thing.
+N > 1 : launched by torch.distributed.run, one rank per GPU (RCCL).  Default mode "shard":
+        Sigma's row blocks (= column panels of the factor) are dealt block-cyclically over
+        the ranks, panels are broadcast over xGMI (cocons_amd/shard.py); total work is fixed
+        -> "scaling": "strong".  Mode "replica": every rank evaluates its own theta (what
+        optimParallel's 1+2P finite-difference points are) -> "weak".
+
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (= fp64 vector peak): 256 CU x 4 SIMD
+#                                  x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 issues every 64 cycles
+
+
+def chol_flops(n):
+    return n ** 3 / 3.0
+
+
+def update_algorithmic_flops(n, r, tile=128, nb=256):
+    """Algorithmic flops of the trailing-update launches of one evaluation: for the outer
+    step at column c0 the update touches the lower triangle of the trailing block of order
+    m = n - c0 - nb with K = nb: m (m + 1) K flop, plus 2 r m K for the r rhs rows."""
+    total, launches = 0.0, 0
+    npad = (n + tile - 1) // tile * tile
+    for c0 in range(0, npad, nb):
+        if c0 + nb >= npad:
+            break
+        m = max(n - c0 - nb, 0)
+        total += m * (m + 1) * nb + 2.0 * r * m * nb
+        launches += 1
+    return total, launches
+
+
+def cpu_baseline(n, locs, X, th, z, want_value=True):
+    """The oracle (CPU restatement of src/cocons_full.cpp + LAPACK) timed on this box's host
+    cores, single-threaded like the reference's serial loop: ONE full evaluation at n."""
+    from oracle import oracle as O
+    from cocons_amd import workloads as wl
+    O.build()
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                      # pragma: no cover
+        threadpool_limits = None
+    from scipy.linalg import lapack, solve_triangular
+    t0 = time.perf_counter()
+    S = O.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    t1 = time.perf_counter()
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    try:
+        R, info = lapack.dpotrf(S, lower=0, clean=0, overwrite_a=1)
+        t2 = time.perf_counter()
+        y = solve_triangular(R, z - X @ th["mean"], trans="T", lower=False, check_finite=False)
+        t3 = time.perf_counter()
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    val = n * math.log(2 * math.pi) + 2 * float(np.sum(np.log(np.diag(R)))) + float(y @ y)
+    t_cov, t_chol, t_solve = t1 - t0, t2 - t1, t3 - t2
+    return {
+        "value": 1.0 / (t_cov + t_chol + t_solve), "unit": "evals/s", "cores": 1, "kind": "port",
+        "sample": "1 full evaluation at n=%d: oracle cov_rns (gcc -O2, serial like the reference) %.2fs + "
+                  "LAPACK dpotrf %.2fs + dtrtrs %.2fs, 1 thread" % (n, t_cov, t_chol, t_solve),
+        "host_cpus": os.cpu_count(),
+    }, (val if info == 0 else float("nan"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10000, help="number of locations (square grid edge^2)")
+    ap.add_argument("--mode", choices=["shard", "replica"], default="shard")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    g = int(round(math.sqrt(args.n)))
+    n = g * g
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    th = wl.theta_full()
+    z = wl.synthetic_z(n)
+    r = 1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    shard_mode = world > 1 and args.mode == "shard"
+    if shard_mode:
+        from cocons_amd.shard import ShardedFit, sharded_neg2loglik_core
+        fit = ShardedFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
+
+        def step():
+            return sharded_neg2loglik_core(fit, th, dist, rank, world)[0]
+    else:
+        fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
+        if world > 1:      # replica mode: every rank its own finite-difference point
+            th = {k: np.array(v, dtype=np.float64) for k, v in th.items()}
+            th["std.dev"][0] += 1.22e-4 * rank
+
+        def step():
+            return fit.neg2loglik_core(th)[0]
+
+    val = None
+    for _ in range(args.warmup):
+        val = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        val = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    evals = args.steps * (world if (world > 1 and not shard_mode) else 1)
+    evals_per_s = evals / dt
+    ms_per_step = 1e3 * dt / args.steps
+
+    out = None
+    if rank == 0:
+        stages = None
+        roofline = None
+        if not shard_mode:
+            st = fit.profile_stages(th, reps=3)
+            stages = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()}
+            flops, launches = update_algorithmic_flops(n, r)
+            if st["update_launches"] > 0 and st["update_sum_ms"] > 0:
+                achieved = flops / (st["update_sum_ms"] * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "kernel": "update_kernel (trailing SYRK/GEMM, v_mfma_f64_16x16x4_f64)",
+                            "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                            "flops_per_launch": flops / max(launches, 1),
+                            "launch_ms": round(st["update_avg_ms"], 4), "launches_per_eval": st["update_launches"],
+                            "traffic": None}
+        cpu = None
+        parity = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, cpu_val = cpu_baseline(n, locs, X, th, z)
+            parity = abs(val - cpu_val) / abs(cpu_val)
+        chol_tf = None
+        if stages is not None:
+            chol_tf = chol_flops(n) / (stages["cholesky_ms"] * 1e-3) / 1e12
+        out = {
+            "metric": "-2loglik evals/sec (dense cov_rns + Cholesky/solve/log-det, fp64) at n=%d" % n,
+            "value": round(evals_per_s, 4), "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong" if (shard_mode or world == 1) else "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3: %dx%d grid n=%d, p=3, full nonstationary cov_rns (Bessel-K branch), r=1, "
+                                   "dense -2loglik" % (g, g, n),
+                       "parallelism": ("panel-sharded x%d (RCCL broadcast)" % world) if shard_mode else
+                                      ("replica x%d" % world if world > 1 else "single GPU"),
+                       "target_8gpu_evals_per_s": 100},
+            "cholesky_tflops_fp64": None if chol_tf is None else round(chol_tf, 3),
+            "cholesky_frac_of_peak": None if chol_tf is None else round(chol_tf / (FP64_MFMA_PEAK_TFLOPS * world), 4),
+            "stages_ms": stages,
+            "neg2loglik": val,
+            "parity_rel_err_vs_cpu": parity,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
