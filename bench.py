@@ -172,7 +172,7 @@ def main():
         if not shard_mode:
             st = fit.profile_stages(th, reps=3)
             stages = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()}
-            flops, launches = update_algorithmic_flops(n, r)
+            flops, launches = st["update_flops"], st["update_launches"]
             if st["update_launches"] > 0 and st["update_sum_ms"] > 0:
                 achieved = flops / (st["update_sum_ms"] * 1e-3) / 1e12
                 roofline = {"bound": "mfma", "kernel": "update_kernel (trailing SYRK/GEMM, v_mfma_f64_16x16x4_f64)",

@@ -4,6 +4,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -144,6 +145,9 @@ struct cocons_fit {
     size_t xbuf_bytes;
     bool xbuf_own;
     hipEvent_t ev[8];
+    hipStream_t stream2;          // panel stream of the look-ahead schedule
+    std::vector<hipEvent_t> *la_ev;
+    double upd_flops;             // algorithmic flops of the event-timed trailing updates (profile runs)
 };
 
 static int fit_check(cocons_fit *f)
@@ -179,6 +183,8 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->xbuf_own) { hipFree(f->xbuf[0]); hipFree(f->xbuf[1]); }
         hipHostFree(f->hout); hipHostFree(f->hinfo);
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
+        if (f->la_ev) { for (auto e : *f->la_ev) hipEventDestroy(e); delete f->la_ev; }
+        if (f->stream2) hipStreamDestroy(f->stream2);
         if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     }
     delete f;
@@ -236,6 +242,8 @@ extern "C" cocons_fit *cocons_fit_create(int n, int p, int r, int q, const doubl
     CK(hipHostMalloc(&f->hout, f->out_cap * sizeof(double)));
     CK(hipHostMalloc(&f->hinfo, sizeof(int)));
     for (auto &e : f->ev) CK(hipEventCreate(&e));
+    CK(hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking));
+    f->la_ev = new std::vector<hipEvent_t>();
     if (fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
 #undef CK
     return f;
@@ -312,38 +320,93 @@ static void assemble_rhs(cocons_fit *f, const double *mean, bool use_trend, cons
     }
 }
 
-// Bordered right-looking factorisation, outer block = 2 tiles (256 columns):
-//   potrf(k) | trsm(k) | update tile column k+1 (K=128) | potrf(k+1) | trsm(k+1) |
-//   trailing update of everything right of the block with K = 256.
-// mt = total tile rows (matrix + rhs rows).  Optional per-launch timing of the trailing
-// update via events (ev_upd != nullptr): appended pairs (start, stop).
-static void factorize(cocons_fit *f, int mt, std::vector<hipEvent_t> *ev_upd)
+// Bordered right-looking factorisation, outer block = 2 tiles (256 columns).
+//   panel(k)  : potrf(k) | trsm(k) | update tile column k+1 (K=128) | potrf(k+1) | trsm(k+1)
+//   U1(k)     : update of the NEXT block's two tile columns with panel k (K = 256)
+//   U2(k)     : update of everything right of that
+// Look-ahead: panel(k+2) runs on a second stream as soon as U1(k) is done, concurrently
+// with U2(k) on the main stream; U1(k+2) waits for it.  mt = total tile rows (matrix + rhs
+// rows).  Optional per-launch timing of U2 via events (ev_upd): appended (start, stop).
+static void panel_ops(cocons_fit *f, int k, int mt, hipStream_t s)
 {
     const int nt = f->nt;
     double *A = f->dA;
     const size_t lda = f->lda;
-    hipStream_t s = f->stream;
-    for (int k = 0; k < nt; k += 2) {
-        double *di0 = f->dinv, *di1 = f->dinv + 8 * 256;
-        launch_potrf_tile(A, lda, k * TILE, di0, f->dinfo, s);
-        launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, mt * TILE, di0, s);
-        if (k + 1 < nt) {
-            launch_update(A, lda, k * TILE, TILE, k + 1, mt, k + 1, k + 2, true, s);
-            launch_potrf_tile(A, lda, (k + 1) * TILE, di1, f->dinfo, s);
-            launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, mt * TILE, di1, s);
-            if (k + 2 < nt) {
-                if (ev_upd) {
-                    hipEvent_t a, b;
-                    hipEventCreate(&a); hipEventCreate(&b);
-                    hipEventRecord(a, s);
-                    launch_update(A, lda, k * TILE, 2 * TILE, k + 2, mt, k + 2, nt, true, s);
-                    hipEventRecord(b, s);
-                    ev_upd->push_back(a); ev_upd->push_back(b);
-                } else {
-                    launch_update(A, lda, k * TILE, 2 * TILE, k + 2, mt, k + 2, nt, true, s);
-                }
-            }
+    double *q0 = f->dinv, *q1 = f->dinv + 8 * 256;
+    launch_potrf_tile(A, lda, k * TILE, q0, f->dinfo, s);
+    launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, mt * TILE, q0, s);
+    if (k + 1 < nt) {
+        launch_update(A, lda, k * TILE, TILE, k + 1, mt, k + 1, k + 2, true, s);
+        launch_potrf_tile(A, lda, (k + 1) * TILE, q1, f->dinfo, s);
+        launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, mt * TILE, q1, s);
+    }
+}
+
+static bool lookahead_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("COCONS_LOOKAHEAD");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
+static void timed_update(cocons_fit *f, int k, int kw, int t0, int t1, int mt, hipStream_t s,
+                         std::vector<hipEvent_t> *ev_upd)
+{
+    if (ev_upd) {
+        // algorithmic flops of this launch: lower triangle of the trailing block of order m
+        // (real columns only) times K, plus the rhs rows:  K m (m+1) + 2 K r m
+        double m = (double)f->n - (double)t0 * TILE;
+        if (m < 0) m = 0;
+        double K = (double)kw * TILE;
+        f->upd_flops += K * m * (m + 1.0) + 2.0 * K * (double)f->nrhs_cur * m;
+        hipEvent_t a, b;
+        hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a, s);
+        launch_update(f->dA, f->lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s);
+        hipEventRecord(b, s);
+        ev_upd->push_back(a); ev_upd->push_back(b);
+    } else {
+        launch_update(f->dA, f->lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s);
+    }
+}
+
+static void factorize(cocons_fit *f, int mt, std::vector<hipEvent_t> *ev_upd)
+{
+    const int nt = f->nt;
+    hipStream_t M = f->stream;
+    if (!lookahead_enabled() || nt <= 4) {
+        for (int k = 0; k < nt; k += 2) {
+            panel_ops(f, k, mt, M);
+            if (k + 2 < nt) timed_update(f, k, 2, k + 2, nt, mt, M, ev_upd);
         }
+        return;
+    }
+    hipStream_t P = f->stream2;
+    std::vector<hipEvent_t> &ev = *f->la_ev;
+    const size_t need = (size_t)nt + 4;
+    while (ev.size() < need) {
+        hipEvent_t e;
+        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        ev.push_back(e);
+    }
+    size_t ne = 0;
+    panel_ops(f, 0, mt, M);
+    for (int k = 0; k + 2 < nt; k += 2) {
+        const int u1_end = (k + 4 < nt) ? k + 4 : nt;
+        // U1: the next block's tile columns, then hand them to the panel stream
+        launch_update(f->dA, f->lda, k * TILE, 2 * TILE, k + 2, mt, k + 2, u1_end, true, M);
+        hipEvent_t e_u1 = ev[ne++];
+        hipEventRecord(e_u1, M);
+        hipStreamWaitEvent(P, e_u1, 0);
+        panel_ops(f, k + 2, mt, P);
+        hipEvent_t e_p = ev[ne++];
+        hipEventRecord(e_p, P);
+        // U2: the rest of the trailing matrix, concurrent with panel(k+2)
+        if (k + 4 < nt) timed_update(f, k, 2, k + 4, nt, mt, M, ev_upd);
+        hipStreamWaitEvent(M, e_p, 0);
     }
 }
 
@@ -358,6 +421,7 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
                         const double *xb, int nxb, std::vector<hipEvent_t> *ev_upd, bool stage_events)
 {
     const int nrhs = f->r + nxb;
+    f->nrhs_cur = nrhs;
     if (int rc = fit_alloc_matrix(f, nrhs)) return rc;
     const int mt = f->nt + f->rhs_cap / TILE;
     if (stage_events) hipEventRecord(f->ev[0], f->stream);
@@ -502,6 +566,7 @@ extern "C" int cocons_fit_profile(cocons_fit *f, const double *theta, const doub
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < reps; ++it) {
         std::vector<hipEvent_t> ev;
+        f->upd_flops = 0.0;
         if (int rc = enqueue_eval(f, theta, mean, true, nullptr, 0, &ev, true)) return rc;
         HIPCHK(hipStreamSynchronize(f->stream));
         float t01, t12, t23, t03;
@@ -524,6 +589,7 @@ extern "C" int cocons_fit_profile(cocons_fit *f, const double *theta, const doub
     ms[5] = acc[5];
     ms[6] = acc[6] / reps;
     ms[4] = acc[5] > 0 ? ms[6] / acc[5] : 0.0;
+    ms[7] = f->upd_flops;
     return info_status(f);
 }
 
@@ -868,5 +934,20 @@ extern "C" int cocons_shard_finish(cocons_fit *f, double *partial, int *info)
     for (int c = 0; c < cnt; ++c)
         for (int i = 0; i < len; ++i) partial[i] += f->hout[(size_t)c * len + i];
     if (info) *info = *f->hinfo;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops)
+{
+    if (!tflops || blocks_per_cu < 1 || blocks_per_cu > 8) return fail(-1, "cocons_mfma_f64_probe: bad argument");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, 0));
+    int blocks = prop.multiProcessorCount * blocks_per_cu;
+    double *d = nullptr;
+    HIPCHK(hipMalloc(&d, (size_t)blocks * 256 * sizeof(double)));
+    *tflops = run_mfma_f64_probe(nullptr, blocks, 20000, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipFree(d));
     return 0;
 }

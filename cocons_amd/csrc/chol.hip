@@ -19,6 +19,7 @@
 //      blk_mma(acc, P, Q):  acc(i,j) += sum_k P(i,k) Q(j,k).
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace cocons {
@@ -77,65 +78,125 @@ __device__ __forceinline__ void glb_blk_store(double *A, size_t lda, int row0, i
 }
 
 // ---------------------------------------------------------------------------
-// 16x16 Cholesky + inverse of the factor, executed by ONE wave (lanes 0..15 hold
-// row l of the block; lanes >= 16 mirror lane l&15 so that shuffles stay uniform).
-// blk / inv are block-packed LDS images.  Returns the 1-based failing column or 0.
-__device__ __forceinline__ int potrf16_wave(double *blk, double *inv, int lane)
+// 16x16 diagonal block on ONE wave, all in registers (blk layout), MFMA-based:
+//   for each 4-column group s: broadcast the 4x4 diagonal sub-block (v_readlane), factor
+//   and invert it redundantly on every lane (10 + 10 values), then
+//     one MFMA  : columns 4s..4s+3  <-  D(:, group s) * inv(L4)^T        (K = 4)
+//     one MFMA  : rank-4 update of the whole 16x16 block
+// Outputs: the factor L (blk layout) and Q[s] = per-lane MFMA A-operand of inv(L4_s)
+// (row m = lane&15, k = lane>>4; zero outside rows 4s..4s+3), which trsm16() reuses.
+__device__ __forceinline__ double rdlane(double v, int lane)
 {
-    const int l = lane & 15;
-    double a[16];
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// select among the lower-triangular 4x4 values by (c = row in group, k = column)
+__device__ __forceinline__ double sel_lower4(int c, int k, double v00, double v10, double v11, double v20,
+                                             double v21, double v22, double v30, double v31, double v32, double v33)
+{
+    double r0 = v00;                                   // c == 0 (k == 0)
+    double r1 = (k == 0) ? v10 : v11;                  // c == 1
+    double r2 = (k == 0) ? v20 : ((k == 1) ? v21 : v22);
+    double r3 = (k == 0) ? v30 : ((k == 1) ? v31 : ((k == 2) ? v32 : v33));
+    double r = (c == 0) ? r0 : ((c == 1) ? r1 : ((c == 2) ? r2 : r3));
+    return (k <= c) ? r : 0.0;
+}
+
+template <int S>
+__device__ __forceinline__ void potrf16_step(d4 &D, double (&Q)[4], int lane, int &fail)
+{
+    const int m = lane & 15, k = lane >> 4;
+    const double ds = D[S];
+    // element (4S+a, 4S+b) sits on lane (4S+a) + 16 b of register S
+    double a00 = rdlane(ds, 4 * S + 0), a10 = rdlane(ds, 4 * S + 1), a20 = rdlane(ds, 4 * S + 2),
+           a30 = rdlane(ds, 4 * S + 3);
+    double a11 = rdlane(ds, 4 * S + 1 + 16), a21 = rdlane(ds, 4 * S + 2 + 16), a31 = rdlane(ds, 4 * S + 3 + 16);
+    double a22 = rdlane(ds, 4 * S + 2 + 32), a32 = rdlane(ds, 4 * S + 3 + 32);
+    double a33 = rdlane(ds, 4 * S + 3 + 48);
+    // 4x4 Cholesky (dpotf2 order) -- identical on every lane
+    if (!(a00 > 0.0) && fail == 0) fail = 4 * S + 1;
+    double l00 = sqrt(a00), r0 = 1.0 / l00;
+    double l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
+    double t11 = fma(-l10, l10, a11);
+    if (!(t11 > 0.0) && fail == 0) fail = 4 * S + 2;
+    double l11 = sqrt(t11), r1 = 1.0 / l11;
+    double l21 = fma(-l20, l10, a21) * r1, l31 = fma(-l30, l10, a31) * r1;
+    double t22 = fma(-l21, l21, fma(-l20, l20, a22));
+    if (!(t22 > 0.0) && fail == 0) fail = 4 * S + 3;
+    double l22 = sqrt(t22), r2 = 1.0 / l22;
+    double l32 = fma(-l31, l21, fma(-l30, l20, a32)) * r2;
+    double t33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a33)));
+    if (!(t33 > 0.0) && fail == 0) fail = 4 * S + 4;
+    double l33 = sqrt(t33), r3 = 1.0 / l33;
+    // inverse of the 4x4 factor
+    double m00 = r0, m11 = r1, m22 = r2, m33 = r3;
+    double m10 = -(l10 * m00) * r1;
+    double m21 = -(l21 * m11) * r2;
+    double m32 = -(l32 * m22) * r3;
+    double m20 = -fma(l21, m10, l20 * m00) * r2;
+    double m31 = -fma(l32, m21, l31 * m11) * r3;
+    double m30 = -fma(l32, m20, fma(l31, m10, l30 * m00)) * r3;
+    const int c = m & 3;
+    const bool ingrp = (m >> 2) == S;
+    double q = sel_lower4(c, k, m00, m10, m11, m20, m21, m22, m30, m31, m32, m33);
+    q = ingrp ? q : 0.0;
+    Q[S] = q;
+    // columns of group S:  X = D(:, group S) * inv(L4)^T ; exact values inside the diagonal sub-block
+    d4 z = {0.0, 0.0, 0.0, 0.0};
+    d4 X = MFMA64(q, ds, z);
+    double lex = sel_lower4(c, k, l00, l10, l11, l20, l21, l22, l30, l31, l32, l33);
+    double xs = ingrp ? lex : ((m < 4 * S) ? 0.0 : X[S]);
+    // rank-4 update of the remaining columns (registers r > S)
+    if (S < 3) {
+        d4 U = MFMA64(xs, -xs, D);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = blk[k * 16 + l];
+        for (int r = S + 1; r < 4; ++r) D[r] = U[r];
+    }
+    D[S] = xs;
+}
+
+__device__ __forceinline__ int potrf16_regs(d4 &D, double (&Q)[4], int lane)
+{
     int fail = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        double ajj = __shfl(a[j], j, 64);
-        if (!(ajj > 0.0) && fail == 0) fail = j + 1;
-        double d = sqrt(ajj);
-        double lj = (l == j) ? d : a[j] / d;
-        a[j] = lj;
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) {
-            double lkj = __shfl(lj, k, 64);      // L(k,j)
-            a[k] = fma(-lj, lkj, a[k]);          // valid for rows l >= k
-        }
-    }
-    // inverse: lane c owns column c of X = L^-1;  X(i,c) = (delta_ic - sum_{k<i} L(i,k) X(k,c)) / L(i,i)
-    double x[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        double s = (i == l) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) {
-            double lik = __shfl(a[k], i, 64);    // L(i,k)
-            s = fma(-lik, x[k], s);
-        }
-        double lii = __shfl(a[i], i, 64);
-        x[i] = (i < l) ? 0.0 : s / lii;
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            blk[k * 16 + l] = (k <= l) ? a[k] : 0.0;   // lower factor, zero above the diagonal
-            inv[l * 16 + k] = x[k];                     // X(k, c=l) at c*16 + k ... stored as (row k, col l)
-        }
-    }
+    potrf16_step<0>(D, Q, lane, fail);
+    potrf16_step<1>(D, Q, lane, fail);
+    potrf16_step<2>(D, Q, lane, fail);
+    potrf16_step<3>(D, Q, lane, fail);
     return fail;
 }
 
+// X = B * L^-T for a 16x16 lower block L (blk layout) with the 4x4 inverse operands Q:
+// block forward substitution over the four column groups, 7 MFMAs.
+__device__ __forceinline__ void trsm16(d4 &B, const d4 &L, const double (&Q)[4])
+{
+    const d4 z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        d4 T = MFMA64(Q[s], B[s], z);
+        B[s] = T[s];
+        if (s < 3) {
+            d4 U = MFMA64(L[s], -B[s], B);
+#pragma unroll
+            for (int r = s + 1; r < 4; ++r) B[r] = U[r];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
-// Diagonal tile: 128x128 Cholesky in LDS (block-packed, 64 blocks of 16x16), one
-// workgroup of 4 waves.  Steps per 16-column block jb: potrf16 (wave 0) | solve the
-// blocks below against inv(L_jj)^T (MFMA) | symmetric update of the rest (MFMA).
+// Diagonal tile: 128x128 Cholesky in LDS (block-packed, 16x16 blocks), one workgroup of
+// 4 waves.  Per 16-column block jb: potrf16 in registers (wave 0) | blocks below solved
+// with trsm16 (MFMA) | symmetric update of the rest (MFMA).  Also exports, per diagonal
+// block, the Q operands (4 x 64 lanes) the panel solve needs.
 __global__ void __launch_bounds__(256)
-potrf_tile_kernel(double *A, size_t lda, int c0, double *dinv_out, int *info)
+potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
 {
     extern __shared__ double smem[];
     double *S = smem;                 // 64 blocks * 256: block (ib,kb) at (ib*8+kb)*256
-    double *DI = smem + 64 * 256;     // 8 inverse blocks
+    double *QS = smem + 64 * 256;     // 8 x (4 x 64) per-lane operands
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // load lower blocks (ib >= kb): thread t of each 256-group moves one element per block
     for (int b = 0; b < 64; ++b) {
         int ib = b >> 3, kb = b & 7;
         if (ib < kb) continue;
@@ -145,22 +206,32 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *dinv_out, int *info)
     __syncthreads();
 
     for (int jb = 0; jb < 8; ++jb) {
+        double *dblk = S + (jb * 8 + jb) * 256;
+        double *qs = QS + jb * 256;
         if (wave == 0) {
-            int f = potrf16_wave(S + (jb * 8 + jb) * 256, DI + jb * 256, lane);
+            d4 D = lds_blk(dblk, lane);
+            double Q[4];
+            int f = potrf16_regs(D, Q, lane);
             if (f && lane == 0) atomicMin(info, c0 + 16 * jb + f);
+            lds_blk_store(dblk, lane, D);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qs[s * 64 + lane] = Q[s];
         }
         __syncthreads();
-        // X(ib,jb) = A(ib,jb) * inv(L_jj)^T
-        d4 Q = lds_blk(DI + jb * 256, lane);
-        for (int ib = jb + 1 + wave; ib < 8; ib += 4) {
-            double *blk = S + (ib * 8 + jb) * 256;
-            d4 P = lds_blk(blk, lane);
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-            blk_mma(acc, P, Q);
-            lds_blk_store(blk, lane, acc);
+        if (jb == 7) break;
+        {
+            d4 L = lds_blk(dblk, lane);
+            double Q[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Q[s] = qs[s * 64 + lane];
+            for (int ib = jb + 1 + wave; ib < 8; ib += 4) {
+                double *blk = S + (ib * 8 + jb) * 256;
+                d4 B = lds_blk(blk, lane);
+                trsm16(B, L, Q);
+                lds_blk_store(blk, lane, B);
+            }
         }
         __syncthreads();
-        // A(ib,kb) -= X(ib,jb) X(kb,jb)^T for ib >= kb > jb
         int cnt = 0;
         for (int ib = jb + 1; ib < 8; ++ib) {
             for (int kb = jb + 1; kb <= ib; ++kb, ++cnt) {
@@ -182,25 +253,25 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *dinv_out, int *info)
         int i = tid & 15, k = tid >> 4;
         A[(size_t)(c0 + 16 * ib + i) + (size_t)(c0 + 16 * kb + k) * lda] = S[b * 256 + k * 16 + i];
     }
-    for (int e = tid; e < 8 * 256; e += 256) dinv_out[e] = DI[e];
+    for (int e = tid; e < 8 * 256; e += 256) q_out[e] = QS[e];
 }
 
 // ---------------------------------------------------------------------------
 // Panel solve: rows [r0, r1) of block column c0:  X <- X * L(c0)^-T.
 // One workgroup = 64 rows; each wave owns a 16 x 128 strip held in registers (8 blocks).
-// LDS holds the strictly-lower 16x16 blocks of L (28) and the 8 inverse diagonal blocks.
+// LDS holds the 36 lower 16x16 blocks of L and the 8 x 4 Q operands.
 __global__ void __launch_bounds__(256)
-trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *dinv)
+trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin)
 {
-    __shared__ double SL[28 * 256];
-    __shared__ double DI[8 * 256];
+    __shared__ double SL[36 * 256];
+    __shared__ double QS[8 * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         int i = tid & 15, k = tid >> 4, b = 0;
-        for (int ib = 1; ib < 8; ++ib)
-            for (int kb = 0; kb < ib; ++kb, ++b)
+        for (int ib = 0; ib < 8; ++ib)
+            for (int kb = 0; kb <= ib; ++kb, ++b)
                 SL[b * 256 + k * 16 + i] = A[(size_t)(c0 + 16 * ib + i) + (size_t)(c0 + 16 * kb + k) * lda];
-        for (int e = tid; e < 8 * 256; e += 256) DI[e] = dinv[e];
+        for (int e = tid; e < 8 * 256; e += 256) QS[e] = qin[e];
     }
     const int rs = r0 + 64 * blockIdx.x + 16 * wave;
     d4 B[8];
@@ -209,14 +280,15 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *dinv)
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        d4 X = {0.0, 0.0, 0.0, 0.0};
-        d4 Q = lds_blk(DI + j * 256, lane);
-        blk_mma(X, B[j], Q);
-        B[j] = X;
-        d4 NX = -X;
+        d4 L = lds_blk(SL + (j * (j + 1) / 2 + j) * 256, lane);
+        double Q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Q[s] = QS[j * 256 + s * 64 + lane];
+        trsm16(B[j], L, Q);
+        d4 NX = -B[j];
 #pragma unroll
         for (int jj = j + 1; jj < 8; ++jj) {
-            d4 Lb = lds_blk(SL + (jj * (jj - 1) / 2 + j) * 256, lane);
+            d4 Lb = lds_blk(SL + (jj * (jj + 1) / 2 + j) * 256, lane);
             blk_mma(B[jj], NX, Lb);
         }
     }
@@ -225,52 +297,58 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *dinv)
 }
 
 // ---------------------------------------------------------------------------
-// Trailing update: C(ti,tj) -= P(ti,:) P(tj,:)^T over K panel columns, 128x128 tiles,
-// 4 waves x (64x64 = 4x4 MFMA blocks).  Operand tiles stream through LDS in chunks of
-// KC=16 panel columns, register-staged double buffering, one barrier per chunk.
+// Trailing update: C(ti,tj) -= P(ti,:) P(tj,:)^T over K panel columns.  TM x TM tiles
+// (TM = 128: 4 waves x 64x64 = 4x4 MFMA blocks each, the throughput shape; TM = 64:
+// 4 waves x 32x32, four times as many workgroups -- used where the grid is too small to
+// fill 256 CUs: the narrow in-panel update, the look-ahead update and the late steps).
+// Operand tiles stream through LDS in chunks of KC=16 panel columns, register-staged
+// double buffering, one barrier per chunk.
 constexpr int KC = 16;
-constexpr int LDT = 144;    // 128 + 16: lanes l and l+16 land 128 B apart mod 256 -> conflict-free b64 reads
 
 struct UpdArgs {
     double *C; size_t ldc;
     const double *P; size_t ldp;   // panel: element (global row, k) at P[row + k*ldp]
     int K;
-    int ti0, tj0, lower_only;
-    int ptiles, world, rank;       // sharded path: only tile columns whose panel (tj / ptiles) is owned
+    int ti0, tj0, lower_only;      // tile indices in units of TM
+    int ptiles, world, rank;       // sharded path: only 128-tile columns whose panel (tj128 / ptiles) is owned
 };
 
-__global__ void __launch_bounds__(256, 2)
+template <int TM>
+__global__ void __launch_bounds__(256, (TM == 128 ? 2 : 4))
 update_kernel(UpdArgs a)
 {
+    constexpr int LDT = TM + 16;   // lanes l and l+16 land 128 B apart mod 256 -> conflict-free b64 reads
+    constexpr int NB = TM / 32;    // 16x16 blocks per wave and dimension
+    constexpr int RPT = TM / 16;   // rows staged per thread and side
     const int ti = a.ti0 + blockIdx.x, tj = a.tj0 + blockIdx.y;
     if (a.lower_only && tj > ti) return;
-    if (a.world > 1 && ((tj / a.ptiles) % a.world) != a.rank) return;
+    if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;
     __shared__ double sI[2][KC * LDT];
     __shared__ double sJ[2][KC * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
 
-    // staging map: thread -> (panel column kc, 8 consecutive rows)
-    const int kc = tid >> 4, rg = (tid & 15) * 8;
-    const double *gI = a.P + (size_t)(ti * TILE + rg) + (size_t)kc * a.ldp;
-    const double *gJ = a.P + (size_t)(tj * TILE + rg) + (size_t)kc * a.ldp;
+    // staging map: thread -> (panel column kc, RPT consecutive rows)
+    const int kc = tid >> 4, rg = (tid & 15) * RPT;
+    const double *gI = a.P + (size_t)(ti * TM + rg) + (size_t)kc * a.ldp;
+    const double *gJ = a.P + (size_t)(tj * TM + rg) + (size_t)kc * a.ldp;
     typedef double d2 __attribute__((ext_vector_type(2)));
-    d2 stI[4], stJ[4];
+    d2 stI[RPT / 2], stJ[RPT / 2];
 
-    d4 acc[4][4];
+    d4 acc[NB][NB];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < NB; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int y = 0; y < NB; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
 
     const int nch = a.K / KC;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < RPT / 2; ++v) {
         stI[v] = *(const d2 *)(gI + 2 * v);
         stJ[v] = *(const d2 *)(gJ + 2 * v);
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < RPT / 2; ++v) {
         *(d2 *)(&sI[0][kc * LDT + rg + 2 * v]) = stI[v];
         *(d2 *)(&sJ[0][kc * LDT + rg + 2 * v]) = stJ[v];
     }
@@ -283,29 +361,29 @@ update_kernel(UpdArgs a)
             const double *pI = gI + (size_t)(ch + 1) * KC * a.ldp;
             const double *pJ = gJ + (size_t)(ch + 1) * KC * a.ldp;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < RPT / 2; ++v) {
                 stI[v] = *(const d2 *)(pI + 2 * v);
                 stJ[v] = *(const d2 *)(pJ + 2 * v);
             }
         }
-        const double *bI = &sI[cur][ro + 64 * wi];
-        const double *bJ = &sJ[cur][ro + 64 * wj];
+        const double *bI = &sI[cur][ro + (TM / 2) * wi];
+        const double *bJ = &sJ[cur][ro + (TM / 2) * wj];
 #pragma unroll
         for (int s = 0; s < KC / 4; ++s) {
-            double pi_[4], pj_[4];
+            double pi_[NB], pj_[NB];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
+            for (int x = 0; x < NB; ++x) {
                 pi_[x] = bI[s * 4 * LDT + 16 * x];
                 pj_[x] = bJ[s * 4 * LDT + 16 * x];
             }
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+            for (int x = 0; x < NB; ++x)
 #pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] = MFMA64(pj_[y], pi_[x], acc[x][y]);
+                for (int y = 0; y < NB; ++y) acc[x][y] = MFMA64(pj_[y], pi_[x], acc[x][y]);
         }
         if (ch + 1 < nch) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < RPT / 2; ++v) {
                 *(d2 *)(&sI[cur ^ 1][kc * LDT + rg + 2 * v]) = stI[v];
                 *(d2 *)(&sJ[cur ^ 1][kc * LDT + rg + 2 * v]) = stJ[v];
             }
@@ -313,12 +391,12 @@ update_kernel(UpdArgs a)
         __syncthreads();
     }
     // C -= acc
-    double *Cb = a.C + (size_t)(ti * TILE + 64 * wi + (lane & 15)) +
-                 (size_t)(tj * TILE + 64 * wj + (lane >> 4)) * a.ldc;
+    double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi + (lane & 15)) +
+                 (size_t)(tj * TM + (TM / 2) * wj + (lane >> 4)) * a.ldc;
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < NB; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+        for (int y = 0; y < NB; ++y)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double *p = Cb + 16 * x + (size_t)(16 * y + 4 * r) * a.ldc;
@@ -399,6 +477,16 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
     hipLaunchKernelGGL(trsm_tile_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, dinv);
 }
 
+static int upd64_max_tiles()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("COCONS_UPD64_MAX_TILES");
+        v = e ? atoi(e) : 1000000;   // measured: the 64-tile shape wins at every step (45.7 vs 31 TF)
+    }
+    return v;
+}
+
 void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank)
@@ -406,9 +494,23 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     if (ti1 <= ti0 || tj1 <= tj0 || K <= 0) return;
     UpdArgs a;
     a.C = A; a.ldc = lda; a.P = P; a.ldp = ldp; a.K = K;
-    a.ti0 = ti0; a.tj0 = tj0; a.lower_only = lower_only ? 1 : 0;
+    a.lower_only = lower_only ? 1 : 0;
     a.ptiles = ptiles; a.world = world; a.rank = rank;
-    hipLaunchKernelGGL(update_kernel, dim3(ti1 - ti0, tj1 - tj0), dim3(256), 0, s, a);
+    // number of 128-tiles that do work
+    long nti = ti1 - ti0, ntj = tj1 - tj0;
+    long tiles = nti * ntj;
+    if (lower_only) {
+        tiles = 0;
+        for (int tj = tj0; tj < tj1; ++tj) tiles += (ti1 - (tj > ti0 ? tj : ti0));
+    }
+    if (world > 1) tiles = tiles / world + 1;
+    if (tiles <= upd64_max_tiles()) {
+        a.ti0 = 2 * ti0; a.tj0 = 2 * tj0;
+        hipLaunchKernelGGL(update_kernel<64>, dim3(2 * (ti1 - ti0), 2 * (tj1 - tj0)), dim3(256), 0, s, a);
+    } else {
+        a.ti0 = ti0; a.tj0 = tj0;
+        hipLaunchKernelGGL(update_kernel<128>, dim3(ti1 - ti0, tj1 - tj0), dim3(256), 0, s, a);
+    }
 }
 
 void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
@@ -439,4 +541,41 @@ void launch_row_reduce(const double *A, size_t lda, int n, int rowy, int row0, i
                        A, lda, n, rowy, row0, m, stoch, quad, cchunk);
 }
 
+}  // namespace cocons
+
+// ---------------------------------------------------------------------------
+// Measurement probe: back-to-back v_mfma_f64_16x16x4_f64 on every SIMD (one wave per
+// SIMD, 4 independent accumulators, operands in registers).  Gives the fp64 matrix rate
+// this chip actually sustains, the ceiling the update kernel is priced against.
+namespace cocons {
+__global__ void __launch_bounds__(256)
+mfma_f64_probe_kernel(double *out, int iters, double seed)
+{
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
+    double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
+    for (int i = 0; i < iters; ++i) {
+        acc0 = MFMA64(a, b, acc0);
+        acc1 = MFMA64(b, a, acc1);
+        acc2 = MFMA64(a, a, acc2);
+        acc3 = MFMA64(b, b, acc3);
+    }
+    d4 s = acc0 + acc1 + acc2 + acc3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+double run_mfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_f64_probe_kernel, dim3(blocks), dim3(256), 0, s, dbuf, iters / 10, 1.0);
+    hipEventRecord(e0, s);
+    hipLaunchKernelGGL(mfma_f64_probe_kernel, dim3(blocks), dim3(256), 0, s, dbuf, iters, 1.0);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    double flops = (double)blocks * 4 /*waves*/ * (double)iters * 4 /*mfma*/ * 2048.0;
+    return flops / (ms * 1e-3) / 1e12;
+}
 }  // namespace cocons

@@ -245,7 +245,8 @@ class CoconsFit:
         ms = np.zeros(8)
         _lib.check(self._L.cocons_fit_profile(self._h, _p(T), _p(mean), int(reps), _p(ms)), "cocons_fit_profile")
         return {"assembly_ms": ms[0], "cholesky_ms": ms[1], "reduce_ms": ms[2], "eval_ms": ms[3],
-                "update_avg_ms": ms[4], "update_launches": int(ms[5]), "update_sum_ms": ms[6]}
+                "update_avg_ms": ms[4], "update_launches": int(ms[5]), "update_sum_ms": ms[6],
+                "update_flops": ms[7]}
 
 
 def _with_fit(fit, locs, x_covariates, z, smooth_limits, x_betas=None):

@@ -115,9 +115,16 @@ int cocons_chol_solve(int n, const double *A, int nrhs, const double *rhs,
  * fit's stream with HIP events around each stage.  ms[0]=assembly, ms[1]=Cholesky
  * (+solve, fused), ms[2]=reductions, ms[3]=whole evaluation, ms[4]=average duration
  * of one trailing-update (MFMA) launch, ms[5]=number of such launches per
- * evaluation, ms[6]=sum of trailing-update launch durations per evaluation.      */
+ * evaluation, ms[6]=sum of trailing-update launch durations per evaluation,
+ * ms[7]=algorithmic flops of those launches (K m (m+1) + 2 K r m each; m = trailing order).
+ * `ms` must hold 8 doubles.                                                       */
 int cocons_fit_profile(cocons_fit *fit, const double *theta, const double *mean,
                        int reps, double *ms);
+
+/* fp64 MFMA issue-rate probe: back-to-back v_mfma_f64_16x16x4_f64 on every SIMD with
+ * `blocks_per_cu` 256-thread workgroups per CU; returns the sustained TFLOP/s.  Evidence
+ * for the roofline peak the update kernel is priced against. */
+int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops);
 
 /* ---- column-panel sharded evaluation across GPUs (one process per GPU) ---------
  * The reference's chol reads the UPPER triangle of Sigma row by row; its row
