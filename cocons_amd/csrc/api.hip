@@ -347,7 +347,8 @@ static bool lookahead_enabled()
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("COCONS_LOOKAHEAD");
-        v = e ? atoi(e) : 1;
+        v = e ? atoi(e) : 0;   // off by default: measured no gain yet (panel kernels need 90-147 KB of LDS
+                               // and cannot slot in beside resident update workgroups)
     }
     return v != 0;
 }

@@ -1,0 +1,206 @@
+"""GPU tests on the BASELINE configurations at (or near) full size.  Parity against the CPU
+oracle where the oracle finishes in seconds (C1 n=400, C2/C4 n=4096); size-independent
+properties at the sizes the oracle cannot reach quickly (C3 n=10 000, C5 n=m=8192)."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _grid_problem(g):
+    from cocons_amd import workloads as wl
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    return locs, X, wl.theta_full(), wl.synthetic_z(g * g)
+
+
+def test_c1_holes_plumbing(oracle, golden_dir):
+    """C1: 400 `holes` rows, stationary Matern nu=1.5 through cov_rns_classic and cov_rns,
+    one -2 loglik call; GPU vs CPU."""
+    import cocons_amd as ca
+    d = np.loadtxt(os.path.join(golden_dir, "holes_train400.csv"), delimiter=",", skiprows=1)
+    n = d.shape[0]
+    locs, z = d[:, :2], d[:, 4]
+    X = np.ones((n, 1))
+    sc = math.log(0.2)
+    th = {"mean": np.zeros(1), "std.dev": np.zeros(1), "scale": np.array([sc]), "aniso": np.zeros(1),
+          "tilt": np.zeros(1), "smooth": np.array([math.log(1.5)]), "nugget": np.array([math.log(0.01)])}
+    Sc = ca.cov_rns_classic(th, locs, X)
+    assert np.max(np.abs(Sc - oracle.cov_rns_classic(th, locs, X)) / np.abs(Sc)) < 2e-12
+    th["smooth"] = np.zeros(1)
+    S = ca.cov_rns(th, locs, X, (1.5, 1.5))
+    assert np.max(np.abs(S - Sc) / np.abs(S)) < 1e-12            # Bessel branch == closed form
+    pp = {"mean": 0.0, "std.dev": [True], "scale": [True], "aniso": 0.0, "tilt": 0.0, "smooth": 0.0,
+          "nugget": [True]}
+    tv = np.array([0.0 + sc, 0.0 - sc, math.log(0.01)])
+    got = ca.GetNeg2loglikelihood(tv, pp, locs, X, (1.5, 1.5), z, n, (0, 0, 0))
+    want = oracle.GetNeg2loglikelihood(tv, pp, locs, X, (1.5, 1.5), z, n, (0, 0, 0))
+    assert abs(got - want) <= 1e-8 * abs(want)
+
+
+def test_c2_grid4096_vs_cpu(oracle):
+    """C2: 64x64 grid, full nonstationary model, dense -2 loglik: entrywise Sigma and the value."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, z = _grid_problem(64)
+    n = 4096
+    S = ca.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    So = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    big = np.abs(So) > 1e-280
+    assert np.max(np.abs(S[big] - So[big]) / np.abs(So[big])) < 2e-12
+    pp = wl.par_pos_full()
+    tv = wl.theta_vector_from_lists(th, pp)
+    got = ca.GetNeg2loglikelihood(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, (0.1, 0.1, 0.1))
+    want = oracle.GetNeg2loglikelihood(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, (0.1, 0.1, 0.1))
+    assert abs(got - want) <= 1e-8 * abs(want)
+    # stress set: no nugget, shorter range (worse conditioning); tolerance still the north star's
+    th2 = wl.theta_full(nugget=False, scale0=np.log(0.02))
+    tv2 = wl.theta_vector_from_lists(th2, pp)
+    pp2 = wl.par_pos_full()
+    pp2["nugget"] = -np.inf
+    tv2 = tv2[:-1]
+    got2 = ca.GetNeg2loglikelihood(tv2, pp2, locs, X, wl.SMOOTH_LIMITS, z, n, (0, 0, 0))
+    want2 = oracle.GetNeg2loglikelihood(tv2, pp2, locs, X, wl.SMOOTH_LIMITS, z, n, (0, 0, 0))
+    assert abs(got2 - want2) <= 1e-8 * abs(want2)
+
+
+def test_c3_n10000_properties():
+    """C3 at full size, properties the domain offers (the CPU value at n=10 000 is checked by
+    bench.py's cpu_baseline leg, `parity_rel_err_vs_cpu`):
+      - permuting the locations leaves -2 loglik unchanged,
+      - scaling z by c scales every quadratic form by c^2 and leaves log det unchanged,
+      - shifting the std.dev and nugget intercepts by 2 log s scales Sigma by s^2:
+        sum(log diag chol) moves by n log s, the quadratic form by 1/s^2."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, z = _grid_problem(100)
+    n = 10000
+    fit = ca.CoconsFit(locs, X, np.column_stack([z, 3.0 * z]), wl.SMOOTH_LIMITS)
+    val, parts = fit.neg2loglik_core(th)
+    assert np.isfinite(val)
+    assert abs(parts[2] - 9.0 * parts[1]) < 1e-10 * parts[2]
+    perm = np.random.default_rng(1).permutation(n)
+    fitp = ca.CoconsFit(locs[perm], X[perm], np.column_stack([z, 3.0 * z])[perm], wl.SMOOTH_LIMITS)
+    valp, partsp = fitp.neg2loglik_core(th)
+    assert abs(partsp[0] - parts[0]) < 1e-10 * abs(parts[0])
+    assert abs(partsp[1] - parts[1]) < 1e-9 * abs(parts[1])
+    assert abs(valp - val) < 1e-9 * abs(val)
+    s = 1.7
+    th2 = {k: np.array(v, dtype=float) for k, v in th.items()}
+    th2["std.dev"][0] += 2 * math.log(s)
+    th2["nugget"][0] += 2 * math.log(s)
+    val2, parts2 = fit.neg2loglik_core(th2)
+    assert abs(parts2[0] - (parts[0] + n * math.log(s))) < 1e-10 * abs(parts2[0])
+    assert abs(parts2[1] - parts[1] / s ** 2) < 1e-9 * abs(parts2[1])
+
+
+def test_c4_optimizer_in_the_loop(oracle):
+    """C4 pattern at a size the oracle affords: L-BFGS-B with central differences
+    (ndeps = eps^(1/4), 1 + 2P evaluations per gradient) on the GPU objective; the GPU and the
+    CPU objective agree at the start and at the end point, and the optimiser decreased -2 loglik."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from optim_loop import lbfgsb_central
+    locs, X, th, _ = _grid_problem(24)
+    n = 576
+    rng = np.random.default_rng(3)
+    S = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    z = np.linalg.cholesky(S) @ rng.standard_normal(n)
+    pp = wl.par_pos_full()
+    t0 = wl.theta_vector_from_lists(th, pp) + 0.1
+    lam = (0.0, 0.0, 0.0)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+
+    def f_gpu(t):
+        return ca.GetNeg2loglikelihood(t, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+
+    res = lbfgsb_central(f_gpu, t0, lower=t0 - 3, upper=t0 + 3, max_evals=70)
+    assert res["nfev"] >= 34 and res["fun"] < f_gpu(t0)
+    for t in (t0, res["x"]):
+        a, b = f_gpu(t), oracle.GetNeg2loglikelihood(t, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+        assert abs(a - b) <= 1e-8 * abs(b)
+
+
+def test_c5_predict_8192_properties():
+    """C5 at full size (n = m = 8192).  Property: predicting AT the training locations, the
+    cross-covariance rows are rows of Sigma (coincident points take the diagonal value,
+    src/cocons_full.cpp:410-414), so  C Sigma^-1 r = r  and  diag(C Sigma^-1 C') = diag(Sigma)."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs = wl.grid_locs(128, 64)
+    sc = wl.design_from_locs(locs)
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.3, -0.1, 0.2])
+    z = wl.synthetic_z(8192)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    st, qf = fit.predict_core(th, locs, X)
+    resid = z - X @ th["mean"]
+    assert np.max(np.abs(st - resid)) < 1e-8 * np.max(np.abs(resid))
+    diag = 1 / np.exp(-(X @ th["std.dev"])) + np.exp(X @ th["nugget"])
+    assert np.max(np.abs(qf - diag)) < 1e-8 * np.max(diag)
+    # and the shifted prediction grid of the benchmark config runs to finite, sane values
+    lp = locs + np.array([0.5 / 127, 0.5 / 63])
+    Xp = wl.design_from_locs(lp, sc["mean.vector"], sc["sd.vector"])["std.covs"]
+    out = ca.cocoPredict_dense(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS, z, fit=fit)
+    assert np.all(np.isfinite(out["stochastic"])) and np.all(np.isfinite(out["sd.pred"]))
+    dvar = 1 / np.exp(-(Xp @ th["std.dev"])) + np.exp(Xp @ th["nugget"])
+    assert np.all(out["sd.pred"] ** 2 <= dvar * (1 + 1e-9))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_worker(rank, world, port, g, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch                      # noqa: F401  (before the HIP library, see cocons_amd/shard.py)
+    import torch.distributed as dist
+    from cocons_amd import workloads as wl
+    from cocons_amd.shard import ShardedFit, sharded_neg2loglik_core
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.1, -0.2, 0.05])
+    z = np.column_stack([wl.synthetic_z(g * g), wl.synthetic_z(g * g, seed=5)])
+    fit = ShardedFit(locs, X, z, wl.SMOOTH_LIMITS, device=0)     # every rank on the one GPU of the box
+    val, parts = sharded_neg2loglik_core(fit, th, dist, rank, world)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([[val], parts]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,g", [(2, 40), (3, 50)])
+def test_sharded_hip_engine_over_gloo(tmp_path, world, g):
+    """The production sharded path (HIP kernels + cocons_amd.shard schedule) with `world`
+    ranks sharing this box's single GPU and gloo carrying the panel broadcasts (RCCL refuses
+    several ranks on one device).  Must reproduce the single-GPU value."""
+    import torch.multiprocessing as mp
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    mp.spawn(_shard_worker, args=(world, _free_port(), g, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r)) for r in range(world)]
+    for r in res[1:]:
+        assert np.array_equal(r, res[0])
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.1, -0.2, 0.05])
+    z = np.column_stack([wl.synthetic_z(g * g), wl.synthetic_z(g * g, seed=5)])
+    val, parts = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS).neg2loglik_core(th)
+    assert abs(res[0][0] - val) < 1e-10 * abs(val)
+    assert np.allclose(res[0][1:], parts, rtol=1e-10, atol=0)
