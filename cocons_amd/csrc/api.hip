@@ -1,8 +1,10 @@
 // api.hip -- C ABI of the dense hot path (see include/cocons_hip.h for the contract and the
 // reference interface each entry point replaces).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <limits.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -116,6 +118,7 @@ static ModeSel select_mode(const double *theta, int p, const double *smooth_limi
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static bool lookahead_enabled();
 
 // ---------------------------------------------------------------------------
 struct cocons_fit {
@@ -219,7 +222,27 @@ extern "C" cocons_fit *cocons_fit_create(int n, int p, int r, int q, const doubl
         }                                                                         \
     } while (0)
     CK(hipSetDevice(f->device));
-    CK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    {
+        // Look-ahead needs the single-workgroup diagonal-tile kernel (147 KB of LDS) to find an
+        // empty CU while the trailing update saturates the chip: keep a few CUs out of the main
+        // stream's CU mask.  The panel stream sees every CU and has the higher priority.
+        int reserve = 0;
+        if (lookahead_enabled()) {
+            const char *e = getenv("COCONS_RESERVED_CUS");
+            reserve = e ? atoi(e) : 8;
+        }
+        hipDeviceProp_t prop;
+        CK(hipGetDeviceProperties(&prop, f->device));
+        const int ncu = prop.multiProcessorCount;
+        bool masked = false;
+        if (reserve > 0 && reserve < ncu) {
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            for (int c = reserve; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
+            masked = hipExtStreamCreateWithCUMask(&f->stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+            if (!masked) (void)hipGetLastError();
+        }
+        if (!masked) CK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    }
     f->own_stream = true;
     CK(hipMalloc(&f->dX, (size_t)n * p * sizeof(double)));
     CK(hipMalloc(&f->dlocs, (size_t)n * 2 * sizeof(double)));
@@ -242,7 +265,11 @@ extern "C" cocons_fit *cocons_fit_create(int n, int p, int r, int q, const doubl
     CK(hipHostMalloc(&f->hout, f->out_cap * sizeof(double)));
     CK(hipHostMalloc(&f->hinfo, sizeof(int)));
     for (auto &e : f->ev) CK(hipEventCreate(&e));
-    CK(hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;
+        CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        CK(hipStreamCreateWithPriority(&f->stream2, hipStreamNonBlocking, hi));
+    }
     f->la_ev = new std::vector<hipEvent_t>();
     if (fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
 #undef CK
@@ -327,18 +354,18 @@ static void assemble_rhs(cocons_fit *f, const double *mean, bool use_trend, cons
 // Look-ahead: panel(k+2) runs on a second stream as soon as U1(k) is done, concurrently
 // with U2(k) on the main stream; U1(k+2) waits for it.  mt = total tile rows (matrix + rhs
 // rows).  Optional per-launch timing of U2 via events (ev_upd): appended (start, stop).
-static void panel_ops(cocons_fit *f, int k, int mt, hipStream_t s)
+static void panel_ops(cocons_fit *f, int k, int mt, hipStream_t s, bool no_lds = false)
 {
     const int nt = f->nt;
     double *A = f->dA;
     const size_t lda = f->lda;
     double *q0 = f->dinv, *q1 = f->dinv + 8 * 256;
     launch_potrf_tile(A, lda, k * TILE, q0, f->dinfo, s);
-    launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, mt * TILE, q0, s);
+    launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, mt * TILE, q0, s, no_lds);
     if (k + 1 < nt) {
         launch_update(A, lda, k * TILE, TILE, k + 1, mt, k + 1, k + 2, true, s);
         launch_potrf_tile(A, lda, (k + 1) * TILE, q1, f->dinfo, s);
-        launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, mt * TILE, q1, s);
+        launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, mt * TILE, q1, s, no_lds);
     }
 }
 
@@ -347,8 +374,7 @@ static bool lookahead_enabled()
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("COCONS_LOOKAHEAD");
-        v = e ? atoi(e) : 0;   // off by default: measured no gain yet (panel kernels need 90-147 KB of LDS
-                               // and cannot slot in beside resident update workgroups)
+        v = e ? atoi(e) : 1;
     }
     return v != 0;
 }
@@ -393,21 +419,36 @@ static void factorize(cocons_fit *f, int mt, std::vector<hipEvent_t> *ev_upd)
         hipEventCreateWithFlags(&e, hipEventDisableTiming);
         ev.push_back(e);
     }
+    // Look-ahead pays while the trailing update is longer than the panel chain it hides; in
+    // the tail the chain is the critical path either way and the plain schedule has the
+    // shorter chain (LDS panel solve, no split update).  Switch when fewer than `tail`
+    // tile columns remain.
+    static int tail = -1;
+    if (tail < 0) {
+        const char *e = getenv("COCONS_LOOKAHEAD_TAIL");
+        tail = e ? atoi(e) : 20;
+    }
     size_t ne = 0;
     panel_ops(f, 0, mt, M);
-    for (int k = 0; k + 2 < nt; k += 2) {
+    int k = 0;
+    for (; k + 2 < nt && (nt - k) > tail; k += 2) {
         const int u1_end = (k + 4 < nt) ? k + 4 : nt;
         // U1: the next block's tile columns, then hand them to the panel stream
         launch_update(f->dA, f->lda, k * TILE, 2 * TILE, k + 2, mt, k + 2, u1_end, true, M);
         hipEvent_t e_u1 = ev[ne++];
         hipEventRecord(e_u1, M);
         hipStreamWaitEvent(P, e_u1, 0);
-        panel_ops(f, k + 2, mt, P);
+        panel_ops(f, k + 2, mt, P, true);
         hipEvent_t e_p = ev[ne++];
         hipEventRecord(e_p, P);
         // U2: the rest of the trailing matrix, concurrent with panel(k+2)
         if (k + 4 < nt) timed_update(f, k, 2, k + 4, nt, mt, M, ev_upd);
         hipStreamWaitEvent(M, e_p, 0);
+    }
+    // tail: panel(k) is factored; plain right-looking steps from here
+    for (; k < nt; k += 2) {
+        if (k + 2 < nt) timed_update(f, k, 2, k + 2, nt, mt, M, ev_upd);
+        if (k + 2 < nt) panel_ops(f, k + 2, mt, M);
     }
 }
 

@@ -197,11 +197,21 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
     double *QS = smem + 64 * 256;     // 8 x (4 x 64) per-lane operands
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int b = 0; b < 64; ++b) {
-        int ib = b >> 3, kb = b & 7;
-        if (ib < kb) continue;
-        int i = tid & 15, k = tid >> 4;
-        S[b * 256 + k * 16 + i] = A[(size_t)(c0 + 16 * ib + i) + (size_t)(c0 + 16 * kb + k) * lda];
+    {   // all 36 lower blocks: issue every global load before the first LDS store (one
+        // round trip instead of 36 -- matters most when the chip is busy with the update)
+        const int i = tid & 15, k = tid >> 4;
+        const double *src = A + (size_t)(c0 + i) + (size_t)(c0 + k) * lda;
+        double v[36];
+        int b = 0;
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib)
+#pragma unroll
+            for (int kb = 0; kb <= ib; ++kb, ++b) v[b] = src[(size_t)(16 * ib) + (size_t)(16 * kb) * lda];
+        b = 0;
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib)
+#pragma unroll
+            for (int kb = 0; kb <= ib; ++kb, ++b) S[(ib * 8 + kb) * 256 + k * 16 + i] = v[b];
     }
     __syncthreads();
 
@@ -289,6 +299,43 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin)
 #pragma unroll
         for (int jj = j + 1; jj < 8; ++jj) {
             d4 Lb = lds_blk(SL + (jj * (jj + 1) / 2 + j) * 256, lane);
+            blk_mma(B[jj], NX, Lb);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c0 + 16 * j, lane, B[j]);
+}
+
+// ---------------------------------------------------------------------------
+// Panel solve without LDS: the factor's 16x16 blocks and the Q operands are read straight
+// from global memory (L2-resident: every workgroup reads the same 72 KB) in blk layout.
+// Needs only registers, so its waves can slot in beside resident update workgroups -- this
+// is the variant the look-ahead schedule runs on the panel stream.
+__global__ void __launch_bounds__(256, 2)
+trsm_tile_l2_kernel(double *A, size_t lda, int c0, int r0, const double *qin)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rs = r0 + 64 * blockIdx.x + 16 * wave;
+    d4 B[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) B[j] = glb_blk(A, lda, rs, c0 + 16 * j, lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        d4 L = glb_blk(A, lda, c0 + 16 * j, c0 + 16 * j, lane);
+        // the strictly-upper part of a diagonal block is not stored as zero in global memory
+        // only the lower part is meaningful: trsm16 reads L[s] rows >= columns via MFMA, and
+        // rows above the diagonal must contribute nothing -> mask them
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((lane & 15) < 4 * r + (lane >> 4)) L[r] = 0.0;
+        double Q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Q[s] = qin[j * 256 + s * 64 + lane];
+        trsm16(B[j], L, Q);
+        d4 NX = -B[j];
+#pragma unroll
+        for (int jj = j + 1; jj < 8; ++jj) {
+            d4 Lb = glb_blk(A, lda, c0 + 16 * jj, c0 + 16 * j, lane);
             blk_mma(B[jj], NX, Lb);
         }
     }
@@ -470,11 +517,13 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
     hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), shm, s, A, lda, c0, dinv, info);
 }
 
-void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s)
+void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
+                      bool no_lds)
 {
     int nb = (r1 - r0) / 64;
     if (nb <= 0) return;
-    hipLaunchKernelGGL(trsm_tile_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, dinv);
+    if (no_lds) hipLaunchKernelGGL(trsm_tile_l2_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, dinv);
+    else hipLaunchKernelGGL(trsm_tile_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, dinv);
 }
 
 static int upd64_max_tiles()

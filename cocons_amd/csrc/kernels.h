@@ -75,7 +75,9 @@ constexpr int TILE = 128;          // tile edge of the blocked factorisation
 // 1-based failing column (initialise to INT_MAX).
 void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, hipStream_t s);
 // rows [r0, r1) x cols [c0, c0+128):  X <- X * L(c0)^{-T}, L read from A(c0,c0)
-void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s);
+// no_lds: operands straight from L2 (slots in beside resident update workgroups; look-ahead)
+void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
+                      bool no_lds = false);
 // C(i,j) -= sum_{k in [k0,k0+K)} A(i,k) A(j,k) for tiles with tile-row in [ti0,ti1),
 // tile-col in [tj0,tj1); lower_only keeps ti >= tj.  All tile indices in units of TILE.
 void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,

@@ -52,6 +52,24 @@ __device__ __forceinline__ double kahan(double a, double b, double c, double d)
     return res - err;
 }
 
+// 1/x for moderate x: v_rcp_f64 seed + two Newton steps (|rel err| ~ 1e-16; no scaling,
+// the operands below are O(1)..O(1e3))
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+__constant__ double c_inv_k[64] = {
+    0.0, 1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10, 1.0 / 11, 1.0 / 12,
+    1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16, 1.0 / 17, 1.0 / 18, 1.0 / 19, 1.0 / 20, 1.0 / 21, 1.0 / 22, 1.0 / 23,
+    1.0 / 24, 1.0 / 25, 1.0 / 26, 1.0 / 27, 1.0 / 28, 1.0 / 29, 1.0 / 30, 1.0 / 31, 1.0 / 32, 1.0 / 33, 1.0 / 34,
+    1.0 / 35, 1.0 / 36, 1.0 / 37, 1.0 / 38, 1.0 / 39, 1.0 / 40, 1.0 / 41, 1.0 / 42, 1.0 / 43, 1.0 / 44, 1.0 / 45,
+    1.0 / 46, 1.0 / 47, 1.0 / 48, 1.0 / 49, 1.0 / 50, 1.0 / 51, 1.0 / 52, 1.0 / 53, 1.0 / 54, 1.0 / 55, 1.0 / 56,
+    1.0 / 57, 1.0 / 58, 1.0 / 59, 1.0 / 60, 1.0 / 61, 1.0 / 62, 1.0 / 63};
+
 // 2^(1-nu)/Gamma(nu) * u^nu * K_nu(u), 0 < u < 706
 __device__ __noinline__ double matern_bessel(double nu, double u)
 {
@@ -68,7 +86,8 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
     }
     double gampl = gam2 - mu * gam1;   // 1/Gamma(1+mu)
     double gammi = gam2 + mu * gam1;   // 1/Gamma(1-mu)
-    double kmu, kmu1;
+    double kmu, kmu1;                  // K_mu, K_{mu+1}, both WITHOUT the factor exp(-u) when u > 2
+    double escale;                     // the factor still to be applied: exp(-u) (CF2) or 1 (Temme)
     if (u <= 2.0) {
         double x2 = 0.5 * u, pimu = pi * mu;
         double fact = fabs(pimu) < tol ? 1.0 : pimu / sin(pimu);
@@ -82,9 +101,9 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         double sum1 = pp;
         for (int i = 1; i < 500; ++i) {
             double di = (double)i;
-            double inv = 1.0 / ((di - mu) * (di + mu));
+            double inv = fast_rcp((di - mu) * (di + mu));
             ff = (di * ff + pp + q) * inv;
-            c *= d / di;
+            c *= d * ((i < 64) ? c_inv_k[i] : 1.0 / di);
             pp *= inv * (di + mu);
             q *= inv * (di - mu);
             double del = c * ff;
@@ -94,27 +113,35 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         }
         kmu = sum;
         kmu1 = sum1 * (2.0 / u);
+        escale = 1.0;
     } else {
+        // Steed's CF2.  With A_k = C_k q_k and B_k = C_k q_{k-1} the recurrences
+        //   q_k = (q_{k-2} - (b_k - 2) q_{k-1}) / a_k ,  C_k = -C_{k-1} a_k / k
+        // become  A_k = -(B_{k-1} - (b_k - 2) A_{k-1}) / k ,  B_k = -(a_k / k) A_{k-1}
+        // (a_k cancels), leaving one reciprocal per step.
         double a = mu2 - 0.25;
-        double b = 2.0 * (u + 1.0), D = 1.0 / b, f = D, delta = D;
-        double prev = 0.0, cur = 1.0, C = -a, Q = C, S = 1.0 + Q * delta;
+        double b = 2.0 * (u + 1.0), D = fast_rcp(b), f = D, delta = D;
+        double Ak = -a;          // C_1 q_1 = -a * 1
+        double Bk = 0.0;         // C_1 q_0 = 0
+        double Q = Ak, S = 1.0 + Q * delta;
         for (int k = 2; k < 500; ++k) {
             a -= 2 * (k - 1);
             b += 2.0;
-            D = 1.0 / (b + a * D);
-            delta *= b * D - 1.0;
+            D = fast_rcp(fma(a, D, b));
+            delta *= fma(b, D, -1.0);
             f += delta;
-            double ra = 1.0 / a;
-            double qn = (prev - (b - 2.0) * cur) * ra;
-            prev = cur;
-            cur = qn;
-            C *= -a / k;
-            Q += C * qn;
-            S += Q * delta;
-            if (fabs(Q * delta) < fabs(S) * tol) break;
+            double ik = (k < 64) ? c_inv_k[k] : 1.0 / (double)k;
+            double An = -(Bk - (b - 2.0) * Ak) * ik;
+            Bk = -(a * ik) * Ak;
+            Ak = An;
+            Q += Ak;
+            double qd = Q * delta;
+            S += qd;
+            if (fabs(qd) < fabs(S) * tol) break;
         }
-        kmu = sqrt(pi / (2.0 * u)) * exp(-u) / S;
+        kmu = sqrt(pi / (2.0 * u)) / S;
         kmu1 = kmu * (0.5 + mu + u + (mu2 - 0.25) * f) / u;
+        escale = exp(-u);
     }
     // forward recurrence to order nu, and 1/Gamma(nu) = gampl / prod_{k=1}^{n-1} (mu+k)
     double rg = (n == 0) ? mu * gampl : gampl;
@@ -128,7 +155,8 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         if (k < n) prod *= (mu + k);
     }
     rg = rg / prod;
-    return exp2(-(nu - 1.0)) * rg * pow(u, nu) * pk;
+    // 2^(1-nu) u^nu = 2^(nu log2 u + 1 - nu): the exponent stays O(25), so its rounding is harmless
+    return exp2(fma(nu, log2(u), 1.0 - nu)) * escale * rg * pk;
 }
 
 // value of one covariance entry; A = first ("ii") side, B = second ("jj") side.
