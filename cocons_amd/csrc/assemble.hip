@@ -89,6 +89,9 @@ __device__ __forceinline__ LocP load_locp(const double *base, size_t stride, int
 }
 
 constexpr int TS = 64;   // pair tile edge
+#ifndef PAIR_MIN_WAVES
+#define PAIR_MIN_WAVES 4   // measured on MI355X: 2 -> 3.69 ms, 3 -> 2.93, 4 -> 2.60, 5 -> 2.71, 8 -> 3.65 (n = 10^4 assembly)
+#endif
 
 // Symmetric assembly.  One workgroup (256 threads) per 64x64 tile (bi >= bj) of the
 // lower triangle, tile columns from a.bj0 up to ncols_out; lane = row, each wave sweeps 16 columns whose parameters are
@@ -96,7 +99,7 @@ constexpr int TS = 64;   // pair tile edge
 // the reference's (ii<jj) orientation.  npad rows/cols beyond n are written as the
 // identity (unit diagonal, zero elsewhere) for the padded factorisation buffer.
 template <int MODE, bool MIRROR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, PAIR_MIN_WAVES)
 pair_sym_kernel(PairArgs a)
 {
     __shared__ double tile[MIRROR ? TS * (TS + 1) : 1];
@@ -143,7 +146,7 @@ pair_sym_kernel(PairArgs a)
 // columns = observation locations.  Exact coordinate match -> prediction-side
 // diagonal value (cocons_full.cpp:410-414).
 template <int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, PAIR_MIN_WAVES)
 pair_rect_kernel(PairArgs a)
 {
     const int lane = threadIdx.x & 63;
