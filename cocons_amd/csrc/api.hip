@@ -228,8 +228,10 @@ extern "C" cocons_fit *cocons_fit_create(int n, int p, int r, int q, const doubl
         // stream's CU mask.  The panel stream sees every CU and has the higher priority.
         int reserve = 0;
         if (lookahead_enabled()) {
+            // off by default: with CU-masked queues created and destroyed repeatedly in one
+            // process, later launches were observed to hang on ROCm 7.2 (round-1 test runs)
             const char *e = getenv("COCONS_RESERVED_CUS");
-            reserve = e ? atoi(e) : 8;
+            reserve = e ? atoi(e) : 0;
         }
         hipDeviceProp_t prop;
         CK(hipGetDeviceProperties(&prop, f->device));
@@ -374,7 +376,7 @@ static bool lookahead_enabled()
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("COCONS_LOOKAHEAD");
-        v = e ? atoi(e) : 1;
+        v = e ? atoi(e) : 0;   // experimental, off by default
     }
     return v != 0;
 }

@@ -110,8 +110,7 @@ pair_sym_kernel(PairArgs a)
     const int wave = threadIdx.x >> 6;
     const int r = bi * TS + lane;
     const int n = a.n;
-    LocP R;
-    if (r < n) R = load_locp(a.rows, a.stride, r);
+    const bool offdiag = (bi != bj);           // wave-uniform: then r > c for every entry
     for (int cc = 0; cc < TS / 4; ++cc) {
         int cl = wave * (TS / 4) + cc;
         int c = bj * TS + cl;
@@ -120,11 +119,14 @@ pair_sym_kernel(PairArgs a)
         if (r >= n || c >= n) {
             v = (r == c) ? 1.0 : 0.0;
         } else if (r == c) {
-            v = R.diag;
+            v = a.rows[r + 11 * a.stride];
         } else {
-            LocP C = load_locp(a.rows, a.stride, c);     // wave-uniform -> scalar loads
-            v = (r > c) ? pair_value<MODE>(C, R, a.gr, a.nu_fixed)
-                        : pair_value<MODE>(R, C, a.gr, a.nu_fixed);
+            int rr = r;
+            asm volatile("" : "+v"(rr));         // keep the row-side loads inside the loop
+            if (offdiag || r > c)                // ii = c (wave-uniform -> scalar loads), jj = r
+                v = pair_value_idx<MODE>(a.rows, a.stride, c, a.rows, a.stride, rr, a.gr, a.nu_fixed, false);
+            else
+                v = pair_value_idx<MODE>(a.rows, a.stride, rr, a.rows, a.stride, c, a.gr, a.nu_fixed, false);
         }
         if (r < a.nrows_out) a.out[(size_t)r + (size_t)c * a.ld] = v;
         if (MIRROR) tile[cl * (TS + 1) + lane] = v;
@@ -153,16 +155,14 @@ pair_rect_kernel(PairArgs a)
     const int wave = threadIdx.x >> 6;
     const int r = blockIdx.x * TS + lane;          // prediction location
     const int m = a.m;
-    LocP R;
-    if (r < m) R = load_locp(a.rows, a.stride_rows, r);
     for (int cc = 0; cc < TS / 4; ++cc) {
         int c = blockIdx.y * TS + wave * (TS / 4) + cc;
         if (c >= a.ncols_out) break;
         double v = 0.0;
         if (r < m && c < a.n) {
-            LocP C = load_locp(a.cols, a.stride, c);
-            if (R.x == C.x && R.y == C.y) v = R.diag;
-            else v = pair_value<MODE>(R, C, a.gr, a.nu_fixed);
+            int rr = r;
+            asm volatile("" : "+v"(rr));
+            v = pair_value_idx<MODE>(a.rows, a.stride_rows, rr, a.cols, a.stride, c, a.gr, a.nu_fixed, true);
         }
         if (r < a.nrows_out) a.out[(size_t)r + (size_t)c * a.ld] = v;
     }

@@ -92,6 +92,21 @@ __device__ __forceinline__ double rdlane(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+// l = sqrt(a), r = 1/sqrt(a) for a normal positive a (pivots of an SPD matrix); both to
+// about 1 ulp: v_rsq_f64 seed, two Newton steps on r, one correction of l.
+__device__ __forceinline__ void rsqrt_pivot(double a, double &l, double &r)
+{
+    double y = __builtin_amdgcn_rsq(a);
+    double h = 0.5 * a;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    double s = a * y;
+    s = fma(fma(-s, s, a), 0.5 * y, s);      // s + (a - s^2) / (2 s)
+    y = fma(fma(-s, y, 1.0), y, y);          // y + y (1 - s y)
+    l = (a > 0.0) ? s : __builtin_nan("");   // non-positive pivot: propagate NaN like sqrt would
+    r = (a > 0.0) ? y : __builtin_nan("");
+}
+
 // select among the lower-triangular 4x4 values by (c = row in group, k = column)
 __device__ __forceinline__ double sel_lower4(int c, int k, double v00, double v10, double v11, double v20,
                                              double v21, double v22, double v30, double v31, double v32, double v33)
@@ -115,21 +130,27 @@ __device__ __forceinline__ void potrf16_step(d4 &D, double (&Q)[4], int lane, in
     double a11 = rdlane(ds, 4 * S + 1 + 16), a21 = rdlane(ds, 4 * S + 2 + 16), a31 = rdlane(ds, 4 * S + 3 + 16);
     double a22 = rdlane(ds, 4 * S + 2 + 32), a32 = rdlane(ds, 4 * S + 3 + 32);
     double a33 = rdlane(ds, 4 * S + 3 + 48);
-    // 4x4 Cholesky (dpotf2 order) -- identical on every lane
+    // 4x4 Cholesky (dpotf2 order) -- identical on every lane.  Pivots through
+    // rsqrt_pivot(): l = sqrt(a) and r = 1/l from one v_rsq_f64 seed (short dependent chain;
+    // this loop is pure latency).
     if (!(a00 > 0.0) && fail == 0) fail = 4 * S + 1;
-    double l00 = sqrt(a00), r0 = 1.0 / l00;
+    double l00, r0;
+    rsqrt_pivot(a00, l00, r0);
     double l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
     double t11 = fma(-l10, l10, a11);
     if (!(t11 > 0.0) && fail == 0) fail = 4 * S + 2;
-    double l11 = sqrt(t11), r1 = 1.0 / l11;
+    double l11, r1;
+    rsqrt_pivot(t11, l11, r1);
     double l21 = fma(-l20, l10, a21) * r1, l31 = fma(-l30, l10, a31) * r1;
     double t22 = fma(-l21, l21, fma(-l20, l20, a22));
     if (!(t22 > 0.0) && fail == 0) fail = 4 * S + 3;
-    double l22 = sqrt(t22), r2 = 1.0 / l22;
+    double l22, r2;
+    rsqrt_pivot(t22, l22, r2);
     double l32 = fma(-l31, l21, fma(-l30, l20, a32)) * r2;
     double t33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a33)));
     if (!(t33 > 0.0) && fail == 0) fail = 4 * S + 4;
-    double l33 = sqrt(t33), r3 = 1.0 / l33;
+    double l33, r3;
+    rsqrt_pivot(t33, l33, r3);
     // inverse of the 4x4 factor
     double m00 = r0, m11 = r1, m22 = r2, m33 = r3;
     double m10 = -(l10 * m00) * r1;
@@ -184,12 +205,19 @@ __device__ __forceinline__ void trsm16(d4 &B, const d4 &L, const double (&Q)[4])
     }
 }
 
+// row index of the b-th block of the packed lower triangle (b = ib (ib+1)/2 + kb)
+__constant__ int c_tri_ib[36] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5,
+                                 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 7};
+
 // ---------------------------------------------------------------------------
-// Diagonal tile: 128x128 Cholesky in LDS (block-packed, 16x16 blocks), one workgroup of
-// 4 waves.  Per 16-column block jb: potrf16 in registers (wave 0) | blocks below solved
-// with trsm16 (MFMA) | symmetric update of the rest (MFMA).  Also exports, per diagonal
-// block, the Q operands (4 x 64 lanes) the panel solve needs.
-__global__ void __launch_bounds__(256)
+// Diagonal tile: 128x128 Cholesky in LDS (block-packed 16x16 blocks), ONE workgroup of
+// 8 waves -- a pure latency kernel on the critical path of the factorisation.
+// Per 16-column block jb, two barriers:
+//   T: the (7-jb) blocks below the diagonal block are solved with trsm16, one per wave
+//   S: symmetric update of the remaining blocks; wave 0 takes block (jb+1,jb+1) first and
+//      factors it in registers (potrf16_regs) while waves 1..7 finish the other updates.
+// Also exports, per diagonal block, the Q operands (4 x 64 lanes) the panel solve needs.
+__global__ void __launch_bounds__(512)
 potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
 {
     extern __shared__ double smem[];
@@ -197,73 +225,95 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
     double *QS = smem + 64 * 256;     // 8 x (4 x 64) per-lane operands
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    {   // all 36 lower blocks: issue every global load before the first LDS store (one
-        // round trip instead of 36 -- matters most when the chip is busy with the update)
-        const int i = tid & 15, k = tid >> 4;
+    {   // 36 lower blocks, 18 per half-workgroup: every global load is issued before the
+        // first LDS store (one round trip instead of 36; matters when the chip is busy)
+        const int i = tid & 15, k = (tid >> 4) & 15;
+        const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
         const double *src = A + (size_t)(c0 + i) + (size_t)(c0 + k) * lda;
-        double v[36];
-        int b = 0;
+        double v[18];
 #pragma unroll
-        for (int ib = 0; ib < 8; ++ib)
+        for (int t = 0; t < 18; ++t) {
+            const int bb = 2 * t + half;
+            const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+            v[t] = src[(size_t)(16 * ib) + (size_t)(16 * kb) * lda];
+        }
 #pragma unroll
-            for (int kb = 0; kb <= ib; ++kb, ++b) v[b] = src[(size_t)(16 * ib) + (size_t)(16 * kb) * lda];
-        b = 0;
+        for (int t = 0; t < 18; ++t) {
+            const int bb = 2 * t + half;
+            const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+            S[(ib * 8 + kb) * 256 + k * 16 + i] = v[t];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        d4 D = lds_blk(S, lane);
+        double Q[4];
+        int f = potrf16_regs(D, Q, lane);
+        if (f && lane == 0) atomicMin(info, c0 + f);
+        lds_blk_store(S, lane, D);
 #pragma unroll
-        for (int ib = 0; ib < 8; ++ib)
-#pragma unroll
-            for (int kb = 0; kb <= ib; ++kb, ++b) S[(ib * 8 + kb) * 256 + k * 16 + i] = v[b];
+        for (int s = 0; s < 4; ++s) QS[s * 64 + lane] = Q[s];
     }
     __syncthreads();
 
-    for (int jb = 0; jb < 8; ++jb) {
+    for (int jb = 0; jb < 7; ++jb) {
         double *dblk = S + (jb * 8 + jb) * 256;
         double *qs = QS + jb * 256;
-        if (wave == 0) {
-            d4 D = lds_blk(dblk, lane);
-            double Q[4];
-            int f = potrf16_regs(D, Q, lane);
-            if (f && lane == 0) atomicMin(info, c0 + 16 * jb + f);
-            lds_blk_store(dblk, lane, D);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) qs[s * 64 + lane] = Q[s];
-        }
-        __syncthreads();
-        if (jb == 7) break;
-        {
+        // T: one block per wave
+        if (jb + 1 + wave < 8) {
+            const int ib = jb + 1 + wave;
             d4 L = lds_blk(dblk, lane);
             double Q[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) Q[s] = qs[s * 64 + lane];
-            for (int ib = jb + 1 + wave; ib < 8; ib += 4) {
-                double *blk = S + (ib * 8 + jb) * 256;
-                d4 B = lds_blk(blk, lane);
-                trsm16(B, L, Q);
-                lds_blk_store(blk, lane, B);
-            }
+            double *blk = S + (ib * 8 + jb) * 256;
+            d4 B = lds_blk(blk, lane);
+            trsm16(B, L, Q);
+            lds_blk_store(blk, lane, B);
         }
         __syncthreads();
-        int cnt = 0;
-        for (int ib = jb + 1; ib < 8; ++ib) {
-            for (int kb = jb + 1; kb <= ib; ++kb, ++cnt) {
-                if ((cnt & 3) != wave) continue;
-                d4 P = lds_blk(S + (ib * 8 + jb) * 256, lane);
-                d4 Qk = lds_blk(S + (kb * 8 + jb) * 256, lane);
-                double *blk = S + (ib * 8 + kb) * 256;
-                d4 acc = lds_blk(blk, lane);
-                P = -P;
-                blk_mma(acc, P, Qk);
-                lds_blk_store(blk, lane, acc);
+        // S: wave 0 -> next diagonal block, then its factorisation; others share the rest
+        if (wave == 0) {
+            const int nb = jb + 1;
+            d4 P = lds_blk(S + (nb * 8 + jb) * 256, lane);
+            double *blk = S + (nb * 8 + nb) * 256;
+            d4 acc = lds_blk(blk, lane);
+            d4 NP = -P;
+            blk_mma(acc, NP, P);
+            double Q[4];
+            int f = potrf16_regs(acc, Q, lane);
+            if (f && lane == 0) atomicMin(info, c0 + 16 * nb + f);
+            lds_blk_store(blk, lane, acc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) QS[nb * 256 + s * 64 + lane] = Q[s];
+        } else {
+            int cnt = 0;
+            for (int ib = jb + 1; ib < 8; ++ib) {
+                for (int kb = jb + 1; kb <= ib; ++kb) {
+                    if (ib == jb + 1) continue;            // (jb+1,jb+1) belongs to wave 0
+                    if ((cnt++ % 7) + 1 != wave) continue;
+                    d4 P = lds_blk(S + (ib * 8 + jb) * 256, lane);
+                    d4 Qk = lds_blk(S + (kb * 8 + jb) * 256, lane);
+                    double *blk = S + (ib * 8 + kb) * 256;
+                    d4 acc = lds_blk(blk, lane);
+                    P = -P;
+                    blk_mma(acc, P, Qk);
+                    lds_blk_store(blk, lane, acc);
+                }
             }
         }
         __syncthreads();
     }
-    for (int b = 0; b < 64; ++b) {
-        int ib = b >> 3, kb = b & 7;
-        if (ib < kb) continue;
-        int i = tid & 15, k = tid >> 4;
-        A[(size_t)(c0 + 16 * ib + i) + (size_t)(c0 + 16 * kb + k) * lda] = S[b * 256 + k * 16 + i];
+    {
+        const int i = tid & 15, k = (tid >> 4) & 15, half = tid >> 8;
+        double *dst = A + (size_t)(c0 + i) + (size_t)(c0 + k) * lda;
+        int b = 0;
+        for (int ib = 0; ib < 8; ++ib)
+            for (int kb = 0; kb <= ib; ++kb, ++b)
+                if ((b & 1) == half)
+                    dst[(size_t)(16 * ib) + (size_t)(16 * kb) * lda] = S[(ib * 8 + kb) * 256 + k * 16 + i];
     }
-    for (int e = tid; e < 8 * 256; e += 256) q_out[e] = QS[e];
+    for (int e = tid; e < 8 * 256; e += 512) q_out[e] = QS[e];
 }
 
 // ---------------------------------------------------------------------------
@@ -514,7 +564,7 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
         hipFuncSetAttribute((const void *)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set = true;
     }
-    hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), shm, s, A, lda, c0, dinv, info);
+    hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), shm, s, A, lda, c0, dinv, info);
 }
 
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,

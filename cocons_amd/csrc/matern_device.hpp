@@ -159,40 +159,54 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
     return exp2(fma(nu, log2(u), 1.0 - nu)) * escale * rg * pk;
 }
 
-// value of one covariance entry; A = first ("ii") side, B = second ("jj") side.
-// gr = global_range = 1/exp(-2*scale[0]); nu_fixed used by the closed-form modes.
+// asymptotic branch of the reference for u >= 706 (src/cocons_full.cpp:301-305)
+__device__ __noinline__ double matern_asymptotic(double smtns, double u)
+{
+    return pow(2.0, -(smtns - 1)) / tgamma(smtns) * pow(u, smtns) *
+           sqrt(3.14159265358979323846 / (2.0 * u)) * exp(-u);
+}
+
+// Value of one covariance entry from the per-location SoA; ia = first ("ii") location,
+// ib = second ("jj").  `base_a`/`base_b` are the SoAs of the two sides.  The fields are
+// loaded in two stages -- geometry before the Bessel call, amplitude after it -- and the
+// lane-varying index is laundered through an empty asm so that the loads are NOT hoisted
+// out of the caller's column loop: nothing but (det, m) stays live across the call, which
+// is what lets the kernel run at 4 waves/SIMD without scratch.
+// gr = global_range = 1/exp(-2*scale[0]); nu_fixed is used by the closed-form modes.
 template <int MODE>
-__device__ __forceinline__ double pair_value(const LocP &A, const LocP &B, double gr, double nu_fixed)
+__device__ __forceinline__ double pair_value_idx(const double *base_a, size_t sa, int ia,
+                                                 const double *base_b, size_t sb, int ib,
+                                                 double gr, double nu_fixed, bool coincident_check)
 {
     const double epsilon = 2.220446049250313e-16;
-    double s11 = (A.rd + B.rd) * 0.5;
-    double s22 = kahan(A.rd, A.an2, -B.rd, B.an2) * 0.5;
-    double s12 = kahan(A.ra, A.ct, -B.ra, B.ct) * 0.5;
+    const double *pa = base_a + ia, *pb = base_b + ib;
+    double ax = pa[0], ay = pa[sa], bx = pb[0], by = pb[sb];
+    if (coincident_check && ax == bx && ay == by) return pa[11 * sa];    // cocons_full.cpp:410-414
+    double ard = pa[2 * sa], aan2 = pa[3 * sa], ara = pa[4 * sa], act = pa[5 * sa];
+    double brd = pb[2 * sb], ban2 = pb[3 * sb], bra = pb[4 * sb], bct = pb[5 * sb];
+    double s11 = (ard + brd) * 0.5;
+    double s22 = kahan(ard, aan2, -brd, ban2) * 0.5;
+    double s12 = kahan(ara, act, -bra, bct) * 0.5;
     double det = kahan(s11, s22, s12, s12);
-    double dx = A.x - B.x, dy = A.y - B.y;
+    double dx = ax - bx, dy = ay - by;
     double smtns;
-    if (MODE == MODE_GEOM) smtns = A.snu * B.snu;
-    else if (MODE == MODE_MEAN) smtns = (A.snu + B.snu) / 2;
+    if (MODE == MODE_GEOM) smtns = pa[10 * sa] * pb[10 * sb];
+    else if (MODE == MODE_MEAN) smtns = (pa[10 * sa] + pb[10 * sb]) / 2;
     else smtns = nu_fixed;
     double u = sqrt(8 * smtns / (gr * det)) *
                sqrt(fma(kahan(s22, dx * dx, -s11, dy * dy), 1.0, -2 * s12 * dx * dy));
-    if (u <= epsilon) return A.diag;
-    double amp = sqrt(A.ds * B.dets * B.st);
-    double sdet = sqrt(det);
-    if (MODE == MODE_HALF)
-        return exp(-u) * A.sigma * B.sigma * amp / sdet;
-    if (MODE == MODE_THREEHALF)
-        return (1 + u) * exp(-u) * A.sigma * B.sigma * amp / sdet;
-    if (MODE == MODE_FIVEHALF)
-        return (1 + u + u * u / 3) * exp(-u) * A.sigma * B.sigma * amp / sdet;
+    if (u <= epsilon) return pa[11 * sa];
     double m;
-    if (u < 706.0) {
-        m = matern_bessel(smtns, u);
-    } else {   // :301-305
-        m = pow(2.0, -(smtns - 1)) / tgamma(smtns) * pow(u, smtns) *
-            sqrt(3.14159265358979323846 / (2.0 * u)) * exp(-u);
-    }
-    return m * A.sigma * B.sigma * amp / sdet;
+    if (MODE == MODE_HALF) m = exp(-u);
+    else if (MODE == MODE_THREEHALF) m = (1 + u) * exp(-u);
+    else if (MODE == MODE_FIVEHALF) m = (1 + u + u * u / 3) * exp(-u);
+    else m = (u < 706.0) ? matern_bessel(smtns, u) : matern_asymptotic(smtns, u);
+    // stage 2: amplitude (fields reloaded, see above)
+    asm volatile("" : "+v"(ia), "+v"(ib));
+    pa = base_a + ia;
+    pb = base_b + ib;
+    double amp = sqrt(pa[8 * sa] * pb[7 * sb] * pb[6 * sb]);
+    return m * pa[9 * sa] * pb[9 * sb] * amp / sqrt(det);
 }
 
 }  // namespace cocons
