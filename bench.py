@@ -36,25 +36,12 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (= fp64 vector peak): 256 CU x 4 SIMD
 #                                  x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 issues every 64 cycles
+MEASURED_MFMA_F64_TFLOPS = 47.1  # tools/probe_mfma.py on the GPU box: back-to-back v_mfma_f64_16x16x4_f64 on
+#                                  every SIMD, 4 waves/SIMD, operands in registers (the clock the chip holds)
 
 
 def chol_flops(n):
     return n ** 3 / 3.0
-
-
-def update_algorithmic_flops(n, r, tile=128, nb=256):
-    """Algorithmic flops of the trailing-update launches of one evaluation: for the outer
-    step at column c0 the update touches the lower triangle of the trailing block of order
-    m = n - c0 - nb with K = nb: m (m + 1) K flop, plus 2 r m K for the r rhs rows."""
-    total, launches = 0.0, 0
-    npad = (n + tile - 1) // tile * tile
-    for c0 in range(0, npad, nb):
-        if c0 + nb >= npad:
-            break
-        m = max(n - c0 - nb, 0)
-        total += m * (m + 1) * nb + 2.0 * r * m * nb
-        launches += 1
-    return total, launches
 
 
 def cpu_baseline(n, locs, X, th, z, want_value=True):
@@ -98,6 +85,9 @@ def main():
     ap.add_argument("--n", type=int, default=10000, help="number of locations (square grid edge^2)")
     ap.add_argument("--mode", choices=["shard", "replica"], default="shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="extra measurement at N=1: this many independent evaluations in flight on the GPU "
+                         "(separate fit handles / streams, as optimParallel's workers issue them); 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -165,6 +155,36 @@ def main():
     evals_per_s = evals / dt
     ms_per_step = 1e3 * dt / args.steps
 
+    # extra (N=1 only): throughput with several independent evaluations in flight -- the call
+    # pattern of optimParallel's forked workers sharing one GPU (R/optim.R:117-121).  Reported
+    # beside `value`, never as `value`.
+    inflight = None
+    if world == 1 and args.inflight > 1:
+        import threading
+        fits = [fit] + [ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
+                        for _ in range(args.inflight - 1)]
+        per = max(args.steps // args.inflight, 1)
+
+        def worker(f):
+            for _ in range(per):
+                f.neg2loglik_core(th)
+
+        for f in fits:
+            f.neg2loglik_core(th)
+        torch.cuda.synchronize()
+        ts = [threading.Thread(target=worker, args=(f,)) for f in fits]
+        t1 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        inflight = {"evaluations_in_flight": args.inflight, "evals_per_s": round(per * args.inflight / dt2, 4),
+                    "evals": per * args.inflight}
+        for f in fits[1:]:
+            f.close()
+
     out = None
     if rank == 0:
         stages = None
@@ -180,7 +200,13 @@ def main():
                             "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
                             "flops_per_launch": flops / max(launches, 1),
                             "launch_ms": round(st["update_avg_ms"], 4), "launches_per_eval": st["update_launches"],
+                            "measured_mfma_f64_peak": MEASURED_MFMA_F64_TFLOPS,
                             "traffic": None}
+                tr = os.path.join(ROOT, "profiles", "r01_update_kernel_hbm_traffic.json")
+                if n == 10000 and os.path.exists(tr):      # PMC pass of the same command (see file)
+                    with open(tr) as fh:
+                        roofline["traffic"] = json.load(fh)["hbm_bytes_per_launch_corrected"]
+                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
         cpu = None
         parity = None
         if world == 1 and not args.no_cpu_baseline:
@@ -204,6 +230,7 @@ def main():
             "cholesky_frac_of_peak": None if chol_tf is None else round(chol_tf / (FP64_MFMA_PEAK_TFLOPS * world), 4),
             "stages_ms": stages,
             "neg2loglik": val,
+            "throughput_inflight": inflight,
             "parity_rel_err_vs_cpu": parity,
             "roofline": roofline,
             "cpu_baseline": cpu,
