@@ -185,6 +185,24 @@ def main():
         for f in fits[1:]:
             f.close()
 
+    # extra (N=1 only): the library's own batch entry (cocons_neg2loglik_batch): the same
+    # independent evaluations pipelined over internal slots, no host threads.
+    batch = None
+    if world == 1 and args.inflight > 1:
+        nbatch = max(args.steps, 6)
+        ths = []
+        for i in range(nbatch):
+            t = {k: np.array(v, dtype=np.float64) for k, v in th.items()}
+            t["std.dev"][0] += 1.22e-4 * (i + 1)        # distinct finite-difference points
+            ths.append(t)
+        fit.neg2loglik_batch_core(ths[:3])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        bv, bs = fit.neg2loglik_batch_core(ths)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t1
+        batch = {"evals": nbatch, "evals_per_s": round(nbatch / dtb, 4), "all_ok": bool((bs == 0).all())}
+
     out = None
     if rank == 0:
         stages = None
@@ -231,6 +249,7 @@ def main():
             "stages_ms": stages,
             "neg2loglik": val,
             "throughput_inflight": inflight,
+            "throughput_batch_api": batch,
             "parity_rel_err_vs_cpu": parity,
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -10,6 +10,7 @@ from .host import (  # noqa: F401
     GetNeg2loglikelihood,
     GetNeg2loglikelihoodProfile,
     GetNeg2loglikelihoodREML,
+    GetNeg2loglikelihood_batch,
     cocoPredict_dense,
     cov_rns,
     cov_rns_classic,

@@ -44,6 +44,7 @@ SIGNATURES = {
     "cocons_fit_create": (c_vp, [c_int, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_int]),
     "cocons_fit_destroy": (None, [c_vp]),
     "cocons_neg2loglik_dense": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
+    "cocons_neg2loglik_batch": (c_int, [c_vp, c_int, c_dp, c_dp, c_dp, ctypes.POINTER(c_int)]),
     "cocons_neg2loglik_profile": (c_int, [c_vp, c_dp, c_dp, c_dp]),
     "cocons_neg2loglik_reml": (c_int, [c_vp, c_dp, c_int, c_dp, c_dp]),
     "cocons_predict_dense": (c_int, [c_vp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_dp, c_dp]),

@@ -151,6 +151,9 @@ struct cocons_fit {
     hipStream_t stream2;          // panel stream of the look-ahead schedule
     std::vector<hipEvent_t> *la_ev;
     double upd_flops;             // algorithmic flops of the event-timed trailing updates (profile runs)
+    // host copies of the inputs + lazily created clones: the slots of cocons_neg2loglik_batch
+    std::vector<double> *h_locs, *h_X, *h_z;
+    std::vector<cocons_fit *> *slots;
 };
 
 static int fit_check(cocons_fit *f)
@@ -187,9 +190,11 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         hipHostFree(f->hout); hipHostFree(f->hinfo);
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
         if (f->la_ev) { for (auto e : *f->la_ev) hipEventDestroy(e); delete f->la_ev; }
+        if (f->slots) { for (auto c : *f->slots) cocons_fit_destroy(c); delete f->slots; f->slots = nullptr; }
         if (f->stream2) hipStreamDestroy(f->stream2);
         if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     }
+    delete f->h_locs; delete f->h_X; delete f->h_z;
     delete f;
 }
 
@@ -273,6 +278,10 @@ extern "C" cocons_fit *cocons_fit_create(int n, int p, int r, int q, const doubl
         CK(hipStreamCreateWithPriority(&f->stream2, hipStreamNonBlocking, hi));
     }
     f->la_ev = new std::vector<hipEvent_t>();
+    f->h_locs = new std::vector<double>(locs, locs + (size_t)2 * n);
+    f->h_X = new std::vector<double>(X, X + (size_t)n * p);
+    f->h_z = new std::vector<double>();
+    if (r > 0) f->h_z->assign(z, z + (size_t)n * r);
     if (fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
 #undef CK
     return f;
@@ -496,6 +505,7 @@ static int info_status(cocons_fit *f)
 }
 
 static const double LOG_2PI = 1.8378770664093454835606594728112;
+static void dense_collect(cocons_fit *f, double *sum_logliks, double *parts);
 
 extern "C" int cocons_neg2loglik_dense(cocons_fit *f, const double *theta, const double *mean,
                                        double *sum_logliks, double *parts)
@@ -506,6 +516,12 @@ extern "C" int cocons_neg2loglik_dense(cocons_fit *f, const double *theta, const
     if (int rc = enqueue_eval(f, theta, mean, true, nullptr, 0, nullptr, false)) return rc;
     HIPCHK(hipStreamSynchronize(f->stream));
     if (int st = info_status(f)) return st;
+    dense_collect(f, sum_logliks, parts);
+    return 0;
+}
+
+static void dense_collect(cocons_fit *f, double *sum_logliks, double *parts)
+{
     const int nr = f->r;
     double logdet = f->hout[0], total = 0.0;
     for (int k = 0; k < nr; ++k) {                                   // R/neg2loglikelihood.R:212-218
@@ -515,7 +531,66 @@ extern "C" int cocons_neg2loglik_dense(cocons_fit *f, const double *theta, const
     }
     if (parts) parts[0] = logdet;
     *sum_logliks = total;
-    return 0;
+}
+
+// Batch of independent evaluations (the 2P finite-difference points of one L-BFGS-B gradient,
+// R/optim.R:237-259 + R/profile.R:11-12, or getHessian's 3 P (P+1)/2 points,
+// R/getFunctions.R:979-1016): evaluation i runs on slot i mod S, each slot a clone of the fit
+// with its own factorisation buffer and stream, so the latency-bound panel chain of one
+// evaluation overlaps the MFMA-bound updates and the VALU-bound assembly of the others.
+// thetas: nb x (6 p) row-major tables; means: nb x p; values[nb]; status[nb] (0 / k>0 like the
+// single call).  Returns 0 unless a HIP / argument error occurred.
+extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thetas, const double *means,
+                                       double *values, int *status)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (nb < 0 || (nb > 0 && (!thetas || !means || !values || !status)))
+        return fail(-1, "cocons_neg2loglik_batch: bad argument");
+    if (f->r < 1) return fail(-1, "cocons_neg2loglik_batch: fit has no z");
+    static int nslots_env = -1;
+    if (nslots_env < 0) {
+        const char *e = getenv("COCONS_BATCH_SLOTS");
+        nslots_env = e ? atoi(e) : 3;
+        if (nslots_env < 1) nslots_env = 1;
+        if (nslots_env > 8) nslots_env = 8;
+    }
+    const int S = nb < nslots_env ? (nb > 0 ? nb : 1) : nslots_env;
+    if (!f->slots) f->slots = new std::vector<cocons_fit *>();
+    while ((int)f->slots->size() < S - 1) {          // slot 0 is the fit itself
+        cocons_fit *c = cocons_fit_create(f->n, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(),
+                                          f->h_z->data(), nullptr, f->smooth_limits, f->device);
+        if (!c) return -1;
+        f->slots->push_back(c);
+    }
+    std::vector<int> pending(S, -1);
+    const int tp = 6 * f->p;
+    int rc_all = 0;
+    auto slot_of = [&](int s) { return s == 0 ? f : (*f->slots)[s - 1]; };
+    auto collect = [&](int s) -> int {
+        cocons_fit *c = slot_of(s);
+        int i = pending[s];
+        if (i < 0) return 0;
+        pending[s] = -1;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        int st = info_status(c);
+        status[i] = st;
+        if (st == 0) dense_collect(c, &values[i], nullptr);
+        else values[i] = NAN;
+        return 0;
+    };
+    for (int i = 0; i < nb; ++i) {
+        int s = i % S;
+        if (int rc = collect(s)) { rc_all = rc; break; }
+        cocons_fit *c = slot_of(s);
+        if (int rc = enqueue_eval(c, thetas + (size_t)i * tp, means + (size_t)i * f->p, true, nullptr, 0, nullptr, false)) {
+            rc_all = rc;
+            break;
+        }
+        pending[s] = i;
+    }
+    for (int s = 0; s < S; ++s)
+        if (int rc = collect(s)) rc_all = rc_all ? rc_all : rc;
+    return rc_all;
 }
 
 // small dense SPD solve on the host (q x q, q <= COCONS_P_MAX): W = C C^T, returns

@@ -212,6 +212,20 @@ class CoconsFit:
                    "cocons_neg2loglik_dense")
         return val.value, parts
 
+    def neg2loglik_batch_core(self, theta_lists):
+        """Independent evaluations pipelined on the GPU (cocons_neg2loglik_batch).  Returns
+        (values, status) arrays; status k > 0 marks a Cholesky failure at minor k."""
+        nb = len(theta_lists)
+        T = np.ascontiguousarray(np.stack([theta_table(t) for t in theta_lists], axis=0)) if nb else np.zeros((0, 6, self.p))
+        M = np.ascontiguousarray(np.stack([np.asarray(t["mean"], dtype=np.float64) for t in theta_lists], axis=0)) \
+            if nb else np.zeros((0, self.p))
+        vals = np.zeros(nb)
+        st = np.zeros(nb, dtype=np.int32)
+        _lib.check(self._L.cocons_neg2loglik_batch(self._h, nb, _p(T), _p(M), _p(vals),
+                                                   st.ctypes.data_as(ctypes.POINTER(ctypes.c_int))),
+                   "cocons_neg2loglik_batch")
+        return vals, st
+
     def neg2loglik_profile_core(self, theta_list):
         T = theta_table(theta_list)
         val = ctypes.c_double(0.0)
@@ -268,6 +282,27 @@ def GetNeg2loglikelihood(theta, par_pos, locs, x_covariates, smooth_limits, z, n
                 return 1e6                                  # :202-206
             raise RuntimeError("Cholesky error")
         return val + getPen(n * f.r, lam, tl, smooth_limits)
+    finally:
+        if own:
+            f.close()
+
+
+def GetNeg2loglikelihood_batch(thetas, par_pos, locs, x_covariates, smooth_limits, z, n, lam, safe=True, fit=None):
+    """`GetNeg2loglikelihood` at several theta vectors at once -- what optimParallel's workers
+    compute in parallel for one gradient (R/optim.R:237-259).  Same values, same `safe` rule."""
+    tls = [getModelLists(t, par_pos, "diff") for t in thetas]
+    f, own = _with_fit(fit, locs, x_covariates, z, smooth_limits)
+    try:
+        vals, st = f.neg2loglik_batch_core(tls)
+        out = np.empty(len(tls))
+        for i, tl in enumerate(tls):
+            if st[i] > 0:
+                if not safe:
+                    raise RuntimeError("Cholesky error")
+                out[i] = 1e6
+            else:
+                out[i] = vals[i] + getPen(n * f.r, lam, tl, smooth_limits)
+        return out
     finally:
         if own:
             f.close()

@@ -79,6 +79,15 @@ void cocons_fit_destroy(cocons_fit *fit);
 int cocons_neg2loglik_dense(cocons_fit *fit, const double *theta, const double *mean,
                             double *sum_logliks, double *parts);
 
+/* Batch of nb independent evaluations of the same fit (the 1 + 2P points of one
+ * finite-difference gradient, R/optim.R:237-259 with R/profile.R:11-12; getHessian's
+ * 3 P (P+1)/2 points, R/getFunctions.R:979-1016).  thetas: nb x (6 p) row-major tables,
+ * means: nb x p, values[nb] = sum_logliks of each, status[nb] = 0 or the failing minor k > 0.
+ * Evaluations are pipelined over a few internal slots (COCONS_BATCH_SLOTS, default 3) so the
+ * latency-bound panel chain of one overlaps the updates and the assembly of the others.    */
+int cocons_neg2loglik_batch(cocons_fit *fit, int nb, const double *thetas, const double *means,
+                            double *values, int *status);
+
 /* Profile / REML cores: replace R/neg2loglikelihood.R:132-160 and :254-287.
  * Both avoid chol2inv and the n x n P_mat through
  *   z' P z = ||L^-1 z||^2 - (Y'y)' (Y'Y)^-1 (Y'y),  Y = L^-1 Xb, y = L^-1 z.

@@ -237,3 +237,30 @@ def test_predict_vs_cpu(oracle):
     vg, vw = got["sd.pred"] ** 2, want["sd.pred"] ** 2
     assert np.max(np.abs(vg - vw)) < 1e-11 * np.max(vw)
     assert got["sd.pred"][7] < 1e-6 and want["sd.pred"][7] < 1e-6
+
+
+def test_batch_matches_single_calls(oracle):
+    """cocons_neg2loglik_batch: pipelined independent evaluations give the values of the
+    single calls; a theta whose Sigma is not positive definite yields 1e6 (safe) in place."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n = 520
+    locs, X, th, rng = _problem(n, seed=21)
+    z = rng.standard_normal(n)
+    pp = wl.par_pos_full()
+    t0 = wl.theta_vector_from_lists(th, pp)
+    thetas = [t0 + 0.05 * rng.standard_normal(t0.size) for _ in range(7)]
+    bad = t0.copy()
+    bad[-1] = -800.0                      # nugget -> 0 ...
+    bad[0], bad[3] = 30.0, -30.0          # ... std.dev' = 0, scale' = 30: range e^30, Sigma = all-ones (rank 1)
+    thetas.insert(3, bad)
+    lam = (0.1, 0.1, 0.1)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    got = ca.GetNeg2loglikelihood_batch(thetas, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    one = np.array([ca.GetNeg2loglikelihood(t, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit) for t in thetas])
+    assert np.array_equal(got, one)
+    assert got[3] == 1e6
+    want0 = oracle.GetNeg2loglikelihood(thetas[0], pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+    assert abs(got[0] - want0) <= N2LL_RTOL * abs(want0)
+    with pytest.raises(RuntimeError, match="Cholesky error"):
+        ca.GetNeg2loglikelihood_batch(thetas, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, safe=False, fit=fit)

@@ -16,7 +16,9 @@ import numpy as np
 NDEPS = np.finfo(float).eps ** 0.25
 
 
-def lbfgsb_central(fn, x0, lower, upper, max_evals=50, log=None):
+def lbfgsb_central(fn, x0, lower, upper, max_evals=50, log=None, fn_batch=None):
+    """fn_batch (optional): evaluates a list of points at once (the 2P gradient points, which
+    optimParallel hands to its workers in parallel)."""
     from scipy.optimize import minimize
     count = {"n": 0}
 
@@ -37,8 +39,23 @@ def lbfgsb_central(fn, x0, lower, upper, max_evals=50, log=None):
         return v
 
     def fg(x):
-        f0 = f(x)
         g = np.zeros_like(x)
+        if fn_batch is not None:                      # 1 + 2P points in one pipelined batch
+            if count["n"] + 1 + 2 * x.size > max_evals + 2 * x.size:
+                raise Stop()
+            pts = [x]
+            for i in range(x.size):
+                e = np.zeros_like(x)
+                e[i] = NDEPS
+                pts += [x + e, x - e]
+            vals = fn_batch(pts)
+            count["n"] += len(pts)
+            if vals[0] < best["f"]:
+                best["f"], best["x"] = vals[0], np.array(x, float)
+            for i in range(x.size):
+                g[i] = (vals[1 + 2 * i] - vals[2 + 2 * i]) / (2 * NDEPS)
+            return vals[0], g
+        f0 = f(x)
         for i in range(x.size):                       # the 2P points optimParallel farms out
             e = np.zeros_like(x)
             e[i] = NDEPS
@@ -73,12 +90,21 @@ def main():
     def fn(t):
         return ca.GetNeg2loglikelihood(t, pp, locs, X, wl.SMOOTH_LIMITS, z, n, (0, 0, 0), fit=fit)
 
+    def fnb(ts):
+        return ca.GetNeg2loglikelihood_batch(ts, pp, locs, X, wl.SMOOTH_LIMITS, z, n, (0, 0, 0), fit=fit)
+
     fn(t0)
     t = time.perf_counter()
     res = lbfgsb_central(fn, t0, t0 - 3, t0 + 3, max_evals=a.evals)
     dt = time.perf_counter() - t
-    print("C4: n=%d P=%d evals=%d  %.2f evals/s (%.2f ms/eval)  f: %.6f -> %.6f" %
+    print("C4 sequential: n=%d P=%d evals=%d  %.2f evals/s (%.2f ms/eval)  f: %.6f -> %.6f" %
           (n, t0.size, res["nfev"], res["nfev"] / dt, 1e3 * dt / res["nfev"], fn(t0), res["fun"]))
+    fnb([t0, t0])
+    t = time.perf_counter()
+    res = lbfgsb_central(fn, t0, t0 - 3, t0 + 3, max_evals=a.evals, fn_batch=fnb)
+    dt = time.perf_counter() - t
+    print("C4 batched gradient points: evals=%d  %.2f evals/s (%.2f ms/eval)  f -> %.6f" %
+          (res["nfev"], res["nfev"] / dt, 1e3 * dt / res["nfev"], res["fun"]))
 
 
 if __name__ == "__main__":
