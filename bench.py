@@ -102,12 +102,20 @@ def main():
             sys.exit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
+    # rehearsal knob for boxes with a single GPU: every rank on device 0, gloo instead of RCCL
+    # (RCCL refuses several ranks on one device).  Never set by the driver.
+    rehearsal = os.environ.get("COCONS_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     g = int(round(math.sqrt(args.n)))
     n = g * g
@@ -154,6 +162,27 @@ def main():
     evals = args.steps * (world if (world > 1 and not shard_mode) else 1)
     evals_per_s = evals / dt
     ms_per_step = 1e3 * dt / args.steps
+
+    # extra (N>1, sharded mode): the replica mode on the same ranks -- every rank evaluates its
+    # own theta with its own fit, no collective in the data path ("weak" scaling).
+    replica = None
+    if shard_mode:
+        rfit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
+        rth = {k: np.array(v, dtype=np.float64) for k, v in th.items()}
+        rth["std.dev"][0] += 1.22e-4 * rank
+        for _ in range(2):
+            rfit.neg2loglik_core(rth)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            rfit.neg2loglik_core(rth)
+        barrier()
+        dtr = time.perf_counter() - t1
+        tr = torch.tensor([dtr], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        replica = {"evals_per_s": round(args.steps * world / float(tr.item()), 4), "scaling": "weak",
+                   "note": "every rank evaluates its own theta (no data-path collective)"}
+        rfit.close()
 
     # extra (N=1 only): throughput with several independent evaluations in flight -- the call
     # pattern of optimParallel's forked workers sharing one GPU (R/optim.R:117-121).  Reported
@@ -250,6 +279,7 @@ def main():
             "neg2loglik": val,
             "throughput_inflight": inflight,
             "throughput_batch_api": batch,
+            "replica_mode": replica,
             "parity_rel_err_vs_cpu": parity,
             "roofline": roofline,
             "cpu_baseline": cpu,
