@@ -30,6 +30,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -109,13 +111,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    ctl = None          # gloo control group: barriers / flags / timing, independent of the RCCL data path
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=300))
+        ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
 
     g = int(round(math.sqrt(args.n)))
     n = g * g
@@ -126,15 +132,38 @@ def main():
     r = 1
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctl)
         torch.cuda.synchronize()
 
-    shard_mode = world > 1 and args.mode == "shard"
-    if shard_mode:
-        from cocons_amd.shard import ShardedFit, sharded_neg2loglik_core
-        fit = ShardedFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+        return float(t.item())
 
+    shard_mode = world > 1 and args.mode == "shard"
+    shard_error = None
+    if shard_mode:
+        # one sharded evaluation as a rehearsal: if the RCCL path fails on any rank, every rank
+        # falls back to replica mode (reported as such) instead of losing the whole run
+        from cocons_amd.shard import ShardedFit, sharded_neg2loglik_core
+        fit = None
+        try:
+            fit = ShardedFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
+            sharded_neg2loglik_core(fit, th, dist, rank, world)
+            torch.cuda.synchronize()
+        except Exception as e:                                  # noqa: BLE001
+            shard_error = "%s: %s" % (type(e).__name__, str(e)[:300])
+        if max_over_ranks(0.0 if shard_error is None else 1.0) > 0:
+            shard_mode = False
+            if shard_error is None:
+                shard_error = "sharded path failed on another rank"
+            if fit is not None:
+                fit.close()
+    if shard_mode:
         def step():
             return sharded_neg2loglik_core(fit, th, dist, rank, world)[0]
     else:
@@ -154,11 +183,7 @@ def main():
     for _ in range(args.steps):
         val = step()
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     evals = args.steps * (world if (world > 1 and not shard_mode) else 1)
     evals_per_s = evals / dt
     ms_per_step = 1e3 * dt / args.steps
@@ -177,10 +202,8 @@ def main():
         for _ in range(args.steps):
             rfit.neg2loglik_core(rth)
         barrier()
-        dtr = time.perf_counter() - t1
-        tr = torch.tensor([dtr], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
-        replica = {"evals_per_s": round(args.steps * world / float(tr.item()), 4), "scaling": "weak",
+        dtr = max_over_ranks(time.perf_counter() - t1)
+        replica = {"evals_per_s": round(args.steps * world / dtr, 4), "scaling": "weak",
                    "note": "every rank evaluates its own theta (no data-path collective)"}
         rfit.close()
 
@@ -280,6 +303,7 @@ def main():
             "throughput_inflight": inflight,
             "throughput_batch_api": batch,
             "replica_mode": replica,
+            "shard_error": shard_error,
             "parity_rel_err_vs_cpu": parity,
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -287,8 +311,11 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier(group=ctl)
+            dist.destroy_process_group()
+        except Exception:                                       # noqa: BLE001
+            pass
 
 
 if __name__ == "__main__":

@@ -221,8 +221,12 @@ __global__ void __launch_bounds__(512)
 potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
 {
     extern __shared__ double smem[];
-    double *S = smem;                 // 64 blocks * 256: block (ib,kb) at (ib*8+kb)*256
-    double *QS = smem + 64 * 256;     // 8 x (4 x 64) per-lane operands
+    // lower-packed image: block (ib,kb), ib >= kb, at (ib (ib+1)/2 + kb) * 256  (72 KB), plus the
+    // Q operands of the CURRENT diagonal block (2 KB): 74 KB in all, so the kernel fits on a CU
+    // beside four resident update workgroups (look-ahead without reserving CUs)
+    double *S = smem;
+    double *QS = smem + 36 * 256;
+#define SB(ib, kb) (S + ((ib) * ((ib) + 1) / 2 + (kb)) * 256)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     {   // 36 lower blocks, 18 per half-workgroup: every global load is issued before the
@@ -241,7 +245,7 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
         for (int t = 0; t < 18; ++t) {
             const int bb = 2 * t + half;
             const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
-            S[(ib * 8 + kb) * 256 + k * 16 + i] = v[t];
+            SB(ib, kb)[k * 16 + i] = v[t];
         }
     }
     __syncthreads();
@@ -252,13 +256,13 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
         if (f && lane == 0) atomicMin(info, c0 + f);
         lds_blk_store(S, lane, D);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) QS[s * 64 + lane] = Q[s];
+        for (int s = 0; s < 4; ++s) { QS[s * 64 + lane] = Q[s]; q_out[s * 64 + lane] = Q[s]; }
     }
     __syncthreads();
 
     for (int jb = 0; jb < 7; ++jb) {
-        double *dblk = S + (jb * 8 + jb) * 256;
-        double *qs = QS + jb * 256;
+        double *dblk = SB(jb, jb);
+        double *qs = QS;
         // T: one block per wave
         if (jb + 1 + wave < 8) {
             const int ib = jb + 1 + wave;
@@ -266,7 +270,7 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
             double Q[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) Q[s] = qs[s * 64 + lane];
-            double *blk = S + (ib * 8 + jb) * 256;
+            double *blk = SB(ib, jb);
             d4 B = lds_blk(blk, lane);
             trsm16(B, L, Q);
             lds_blk_store(blk, lane, B);
@@ -275,8 +279,8 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
         // S: wave 0 -> next diagonal block, then its factorisation; others share the rest
         if (wave == 0) {
             const int nb = jb + 1;
-            d4 P = lds_blk(S + (nb * 8 + jb) * 256, lane);
-            double *blk = S + (nb * 8 + nb) * 256;
+            d4 P = lds_blk(SB(nb, jb), lane);
+            double *blk = SB(nb, nb);
             d4 acc = lds_blk(blk, lane);
             d4 NP = -P;
             blk_mma(acc, NP, P);
@@ -284,17 +288,19 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
             int f = potrf16_regs(acc, Q, lane);
             if (f && lane == 0) atomicMin(info, c0 + 16 * nb + f);
             lds_blk_store(blk, lane, acc);
+            // the single Q buffer is still being read by the T phase of this jb?  No: T ended at
+            // the barrier above; the next reader is the T phase after the barrier below.
 #pragma unroll
-            for (int s = 0; s < 4; ++s) QS[nb * 256 + s * 64 + lane] = Q[s];
+            for (int s = 0; s < 4; ++s) { QS[s * 64 + lane] = Q[s]; q_out[nb * 256 + s * 64 + lane] = Q[s]; }
         } else {
             int cnt = 0;
             for (int ib = jb + 1; ib < 8; ++ib) {
                 for (int kb = jb + 1; kb <= ib; ++kb) {
                     if (ib == jb + 1) continue;            // (jb+1,jb+1) belongs to wave 0
                     if ((cnt++ % 7) + 1 != wave) continue;
-                    d4 P = lds_blk(S + (ib * 8 + jb) * 256, lane);
-                    d4 Qk = lds_blk(S + (kb * 8 + jb) * 256, lane);
-                    double *blk = S + (ib * 8 + kb) * 256;
+                    d4 P = lds_blk(SB(ib, jb), lane);
+                    d4 Qk = lds_blk(SB(kb, jb), lane);
+                    double *blk = SB(ib, kb);
                     d4 acc = lds_blk(blk, lane);
                     P = -P;
                     blk_mma(acc, P, Qk);
@@ -311,9 +317,9 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
         for (int ib = 0; ib < 8; ++ib)
             for (int kb = 0; kb <= ib; ++kb, ++b)
                 if ((b & 1) == half)
-                    dst[(size_t)(16 * ib) + (size_t)(16 * kb) * lda] = S[(ib * 8 + kb) * 256 + k * 16 + i];
+                    dst[(size_t)(16 * ib) + (size_t)(16 * kb) * lda] = SB(ib, kb)[k * 16 + i];
     }
-    for (int e = tid; e < 8 * 256; e += 512) q_out[e] = QS[e];
+#undef SB
 }
 
 // ---------------------------------------------------------------------------
@@ -400,7 +406,6 @@ trsm_tile_l2_kernel(double *A, size_t lda, int c0, int r0, const double *qin)
 // fill 256 CUs: the narrow in-panel update, the look-ahead update and the late steps).
 // Operand tiles stream through LDS in chunks of KC=16 panel columns, register-staged
 // double buffering, one barrier per chunk.
-constexpr int KC = 16;
 
 struct UpdArgs {
     double *C; size_t ldc;
@@ -410,13 +415,14 @@ struct UpdArgs {
     int ptiles, world, rank;       // sharded path: only 128-tile columns whose panel (tj128 / ptiles) is owned
 };
 
-template <int TM>
+template <int TM, int KC>
 __global__ void __launch_bounds__(256, (TM == 128 ? 2 : 4))
 update_kernel(UpdArgs a)
 {
     constexpr int LDT = TM + 16;   // lanes l and l+16 land 128 B apart mod 256 -> conflict-free b64 reads
     constexpr int NB = TM / 32;    // 16x16 blocks per wave and dimension
-    constexpr int RPT = TM / 16;   // rows staged per thread and side
+    constexpr int TPC = 256 / KC;  // threads per panel column
+    constexpr int RPT = TM / TPC;  // rows staged per thread and side
     const int ti = a.ti0 + blockIdx.x, tj = a.tj0 + blockIdx.y;
     if (a.lower_only && tj > ti) return;
     if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;
@@ -426,7 +432,7 @@ update_kernel(UpdArgs a)
     const int wi = wave & 1, wj = wave >> 1;
 
     // staging map: thread -> (panel column kc, RPT consecutive rows)
-    const int kc = tid >> 4, rg = (tid & 15) * RPT;
+    const int kc = tid / TPC, rg = (tid % TPC) * RPT;
     const double *gI = a.P + (size_t)(ti * TM + rg) + (size_t)kc * a.ldp;
     const double *gJ = a.P + (size_t)(tj * TM + rg) + (size_t)kc * a.ldp;
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -559,7 +565,7 @@ row_reduce_kernel(const double *A, size_t lda, int n, int rowy, int row0, int m,
 void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, hipStream_t s)
 {
     static bool attr_set = false;
-    const size_t shm = (64 + 8) * 256 * sizeof(double);   // 147,456 B
+    const size_t shm = (36 + 1) * 256 * sizeof(double);   // 75,776 B
     if (!attr_set) {
         hipFuncSetAttribute((const void *)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set = true;
@@ -586,6 +592,18 @@ static int upd64_max_tiles()
     return v;
 }
 
+// K-chunks of 8 (20 KB of LDS, up to 8 workgroups = 8 waves/SIMD per CU) measured 48.1 TFLOP/s
+// against 46.8 for chunks of 16 (40 KB, 4 workgroups/CU): default on; COCONS_UPD_KC8=0 to compare
+static bool upd_small_lds()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("COCONS_UPD_KC8");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
 void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank)
@@ -605,10 +623,13 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     if (world > 1) tiles = tiles / world + 1;
     if (tiles <= upd64_max_tiles()) {
         a.ti0 = 2 * ti0; a.tj0 = 2 * tj0;
-        hipLaunchKernelGGL(update_kernel<64>, dim3(2 * (ti1 - ti0), 2 * (tj1 - tj0)), dim3(256), 0, s, a);
+        if (upd_small_lds())
+            hipLaunchKernelGGL((update_kernel<64, 8>), dim3(2 * (ti1 - ti0), 2 * (tj1 - tj0)), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((update_kernel<64, 16>), dim3(2 * (ti1 - ti0), 2 * (tj1 - tj0)), dim3(256), 0, s, a);
     } else {
         a.ti0 = ti0; a.tj0 = tj0;
-        hipLaunchKernelGGL(update_kernel<128>, dim3(ti1 - ti0, tj1 - tj0), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((update_kernel<128, 16>), dim3(ti1 - ti0, tj1 - tj0), dim3(256), 0, s, a);
     }
 }
 

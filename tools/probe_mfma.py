@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cocons_amd import _lib
 
 L = _lib.load()
-for bpc in (1, 2, 4):
+for bpc in (1, 2, 4, 8):
     t = ctypes.c_double()
     _lib.check(L.cocons_mfma_f64_probe(bpc, ctypes.byref(t)), "probe")
     print("v_mfma_f64_16x16x4_f64 back-to-back, %d block(s) of 4 waves per CU: %.2f TFLOP/s" % (bpc, t.value))
