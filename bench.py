@@ -38,8 +38,8 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (= fp64 vector peak): 256 CU x 4 SIMD
 #                                  x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 issues every 64 cycles
-MEASURED_MFMA_F64_TFLOPS = 47.1  # tools/probe_mfma.py on the GPU box: back-to-back v_mfma_f64_16x16x4_f64 on
-#                                  every SIMD, 4 waves/SIMD, operands in registers (the clock the chip holds)
+MEASURED_MFMA_F64_TFLOPS = 49.0  # tools/probe_mfma.py on the GPU box: back-to-back v_mfma_f64_16x16x4_f64 on
+#                                  every SIMD, 8 waves/SIMD, operands in registers (32.6 / 43.9 / 47.4 / 49.0 at 1 / 2 / 4 / 8 waves per SIMD)
 
 
 def chol_flops(n):

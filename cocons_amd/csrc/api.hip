@@ -1065,7 +1065,22 @@ extern "C" int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops)
     int blocks = prop.multiProcessorCount * blocks_per_cu;
     double *d = nullptr;
     HIPCHK(hipMalloc(&d, (size_t)blocks * 256 * sizeof(double)));
+    // blocks_per_cu > 0: MFMA probe; the vector-FMA companion is reported through cocons_vfma_f64_probe
     *tflops = run_mfma_f64_probe(nullptr, blocks, 20000, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipFree(d));
+    return 0;
+}
+
+extern "C" int cocons_vfma_f64_probe(int blocks_per_cu, double *tflops)
+{
+    if (!tflops || blocks_per_cu < 1 || blocks_per_cu > 8) return fail(-1, "cocons_vfma_f64_probe: bad argument");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, 0));
+    int blocks = prop.multiProcessorCount * blocks_per_cu;
+    double *d = nullptr;
+    HIPCHK(hipMalloc(&d, (size_t)blocks * 256 * sizeof(double)));
+    *tflops = run_vfma_f64_probe(nullptr, blocks, 20000, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipFree(d));
     return 0;

@@ -683,6 +683,40 @@ mfma_f64_probe_kernel(double *out, int iters, double seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
+// companion probe: independent v_fma_f64 chains (16 accumulators per lane), the fp64 VECTOR rate
+__global__ void __launch_bounds__(256)
+vfma_f64_probe_kernel(double *out, int iters, double seed)
+{
+    double a = seed + threadIdx.x * 1e-9, b = 1.0 - 1e-9;
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = a + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = fma(x[i], b, a);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += x[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+double run_vfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(vfma_f64_probe_kernel, dim3(blocks), dim3(256), 0, s, dbuf, iters / 10, 1.0);
+    hipEventRecord(e0, s);
+    hipLaunchKernelGGL(vfma_f64_probe_kernel, dim3(blocks), dim3(256), 0, s, dbuf, iters, 1.0);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    double flops = (double)blocks * 256.0 * (double)iters * 16.0 * 2.0;
+    return flops / (ms * 1e-3) / 1e12;
+}
+
 double run_mfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf)
 {
     hipEvent_t e0, e1;

@@ -101,5 +101,6 @@ void launch_row_reduce(const double *A, size_t lda, int n, int rowy, int row0, i
 
 // fp64 MFMA issue-rate probe (TFLOP/s); dbuf must hold blocks*256 doubles
 double run_mfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf);
+double run_vfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf);
 
 }  // namespace cocons

@@ -134,6 +134,8 @@ int cocons_fit_profile(cocons_fit *fit, const double *theta, const double *mean,
  * `blocks_per_cu` 256-thread workgroups per CU; returns the sustained TFLOP/s.  Evidence
  * for the roofline peak the update kernel is priced against. */
 int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops);
+/* companion: independent v_fma_f64 chains -- the fp64 vector rate the chip sustains */
+int cocons_vfma_f64_probe(int blocks_per_cu, double *tflops);
 
 /* ---- column-panel sharded evaluation across GPUs (one process per GPU) ---------
  * The reference's chol reads the UPPER triangle of Sigma row by row; its row

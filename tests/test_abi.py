@@ -44,3 +44,22 @@ def test_host_penalty_runs_without_gpu():
     """cocons_sumsmoothlone is pure host arithmetic (src/cocons_full.cpp:12-30)."""
     import cocons_amd as ca
     assert ca.sumsmoothlone([0.5, -2.0], 2.0) == 5.0
+
+
+def test_bad_arguments_return_error_codes_without_touching_the_gpu():
+    """argument validation happens before any HIP call: status < 0 and a message, no abort."""
+    import ctypes
+    import numpy as np
+    from cocons_amd import _lib
+    lib = _lib.load()
+    dp = ctypes.POINTER(ctypes.c_double)
+    a = np.zeros(8)
+    p = a.ctypes.data_as(dp)
+    assert lib.cocons_cov_rns(0, 1, p, p, p, p, p) < 0
+    assert "bad argument" in _lib.last_error()
+    assert lib.cocons_cov_rns(4, 33, p, p, p, p, p) < 0            # p > COCONS_P_MAX
+    assert lib.cocons_cov_rns_pred(4, 0, 1, p, p, p, p, p, p, p) < 0
+    assert lib.cocons_chol_solve(0, p, 0, None, None, None, None) < 0
+    assert not lib.cocons_fit_create(0, 1, 1, 0, p, p, p, None, p, 0)
+    assert lib.cocons_neg2loglik_dense(None, p, p, p, None) < 0
+    assert "null fit handle" in _lib.last_error()

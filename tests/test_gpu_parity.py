@@ -264,3 +264,70 @@ def test_batch_matches_single_calls(oracle):
     assert abs(got[0] - want0) <= N2LL_RTOL * abs(want0)
     with pytest.raises(RuntimeError, match="Cholesky error"):
         ca.GetNeg2loglikelihood_batch(thetas, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, safe=False, fit=fit)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129, 200])
+def test_ragged_sizes_all_entry_points(oracle, n):
+    """sizes around the 64-wide pair tiles and the 128-wide factorisation tiles, p = 1 and p = 5,
+    several realizations."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    rng = np.random.default_rng(1000 + n)
+    locs = rng.uniform(0, 1, size=(n, 2))
+    for p in (1, 5):
+        X = np.column_stack([np.ones(n)] + [rng.standard_normal(n) * 0.5 for _ in range(p - 1)])
+        th = {"mean": rng.standard_normal(p) * 0.1,
+              "std.dev": np.r_[0.1, rng.standard_normal(p - 1) * 0.1],
+              "scale": np.r_[np.log(0.3), rng.standard_normal(p - 1) * 0.1],
+              "aniso": np.r_[0.0, rng.standard_normal(p - 1) * 0.1],
+              "tilt": np.r_[0.1, rng.standard_normal(p - 1) * 0.1],
+              "smooth": np.r_[0.2, rng.standard_normal(p - 1) * 0.2],
+              "nugget": np.r_[np.log(0.05), np.zeros(p - 1)]}
+        got = ca.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+        want = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+        assert got.shape == (n, n) and _relerr(got, want) < ENTRY_RTOL
+        assert _relerr(ca.cov_rns_classic(th, locs, X), oracle.cov_rns_classic(th, locs, X)) < ENTRY_RTOL
+        m = max(1, n // 3)
+        lp = rng.uniform(0, 1, size=(m, 2))
+        Xp = np.column_stack([np.ones(m)] + [rng.standard_normal(m) * 0.5 for _ in range(p - 1)])
+        assert _relerr(ca.cov_rns_pred(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS),
+                       oracle.cov_rns_pred(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS)) < ENTRY_RTOL
+        z = rng.standard_normal((n, 3))
+        fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+        val, parts = fit.neg2loglik_core(th)
+        info, ld, quad, _ = oracle.chol_ld(want, z - (X @ th["mean"])[:, None])
+        assert info == 0
+        truth = sum(n * np.log(2 * np.pi) + 2 * ld + q for q in quad)
+        assert abs(val - truth) <= 1e-9 * abs(truth)
+        assert np.allclose(parts[1:], quad, rtol=1e-9)
+        st, qf = fit.predict_core(th, lp, Xp, z_col=1)
+        Cw = oracle.cov_rns_pred(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS)
+        sol = np.linalg.solve(want, Cw.T)
+        assert np.allclose(st, (z[:, 1] - X @ th["mean"]) @ sol, rtol=1e-8, atol=1e-10)
+        assert np.allclose(qf, np.sum(Cw * sol.T, axis=1), rtol=1e-8, atol=1e-12)
+
+
+def test_handle_refuses_use_after_fork():
+    """cocoOptim forks its workers (R/optim.R:117-121); a HIP context does not survive fork, so a
+    handle created in the parent must be refused in the child (before any HIP call)."""
+    import multiprocessing as mp
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, rng = _problem(50, seed=3)
+    fit = ca.CoconsFit(locs, X, rng.standard_normal(50), wl.SMOOTH_LIMITS)
+    fit.neg2loglik_core(th)
+
+    def child(q):
+        try:
+            fit.neg2loglik_core(th)
+            q.put("ran")
+        except Exception as e:            # noqa: BLE001
+            q.put(str(e))
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    pr = ctx.Process(target=child, args=(q,))
+    pr.start()
+    msg = q.get(timeout=60)
+    pr.join(timeout=60)
+    assert "another process" in msg

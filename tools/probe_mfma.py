@@ -12,3 +12,7 @@ for bpc in (1, 2, 4, 8):
     t = ctypes.c_double()
     _lib.check(L.cocons_mfma_f64_probe(bpc, ctypes.byref(t)), "probe")
     print("v_mfma_f64_16x16x4_f64 back-to-back, %d block(s) of 4 waves per CU: %.2f TFLOP/s" % (bpc, t.value))
+for bpc in (1, 2, 4, 8):
+    t = ctypes.c_double()
+    _lib.check(L.cocons_vfma_f64_probe(bpc, ctypes.byref(t)), "probe")
+    print("v_fma_f64 independent chains (16 per lane), %d block(s) of 4 waves per CU: %.2f TFLOP/s" % (bpc, t.value))
