@@ -15,6 +15,7 @@ from .host import (  # noqa: F401
     cov_rns,
     cov_rns_classic,
     cov_rns_pred,
+    getHessian_dense,
     getModelLists,
     getPen,
     getScale,

@@ -308,6 +308,42 @@ def GetNeg2loglikelihood_batch(thetas, par_pos, locs, x_covariates, smooth_limit
             f.close()
 
 
+def getHessian_dense(par, par_pos, locs, x_covariates, smooth_limits, z, n, lam, f00=None,
+                      eps=np.finfo(float).eps ** 0.25, fit=None):
+    """Dense branch of getHessian, R/getFunctions.R:925-1034, from the point where the scaled
+    design matrix exists: for every index pair (jj <= ii) three objective values at par shifted by
+    eps, H[jj,ii] = 0.5 (f11 - f01 - f10 + f00) / eps^2, then H + t(H) with the diagonal halved.
+    The reference farms the 3 P (P+1)/2 evaluations out with parApply (:979); here they form one
+    pipelined batch on the GPU."""
+    par = np.asarray(par, dtype=np.float64).ravel()
+    P = par.size
+    f, own = _with_fit(fit, locs, x_covariates, z, smooth_limits)
+    try:
+        if f00 is None:
+            f00 = GetNeg2loglikelihood(par, par_pos, locs, x_covariates, smooth_limits, z, n, lam, fit=f)
+        pts, idx = [], []
+        for jj in range(P):
+            for ii in range(jj, P):
+                t01, t10, t11 = par.copy(), par.copy(), par.copy()
+                t01[jj] += eps
+                t10[ii] += eps
+                t11[jj] += eps
+                t11[ii] += eps
+                pts += [t01, t10, t11]
+                idx.append((jj, ii))
+        vals = GetNeg2loglikelihood_batch(pts, par_pos, locs, x_covariates, smooth_limits, z, n, lam, fit=f)
+        H = np.zeros((P, P))
+        for k, (jj, ii) in enumerate(idx):
+            f01, f10, f11 = vals[3 * k], vals[3 * k + 1], vals[3 * k + 2]
+            H[jj, ii] = 0.5 * ((f11 - f01 - f10 + f00) / (eps * eps))
+        H = H + H.T
+        H[np.diag_indices(P)] /= 2
+        return H
+    finally:
+        if own:
+            f.close()
+
+
 def GetNeg2loglikelihoodProfile(theta, par_pos, locs, x_covariates, smooth_limits, z, n, x_betas, lam,
                                 safe=True, fit=None):
     """R/neg2loglikelihood.R:127-165."""

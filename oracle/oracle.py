@@ -271,6 +271,31 @@ def GetNeg2loglikelihoodREML(theta, par_pos, locs, x_covariates, x_betas, smooth
     return total + getPen((n - p) * z.shape[1], lam, tl, smooth_limits)
 
 
+def getHessian_dense(par, par_pos, locs, x_covariates, smooth_limits, z, n, lam, f00=None,
+                      eps=np.finfo(float).eps ** 0.25):
+    """R/getFunctions.R:925-1034 (dense branch), serial."""
+    par = np.asarray(par, dtype=np.float64).ravel()
+    P = par.size
+
+    def fn(t):
+        return GetNeg2loglikelihood(t, par_pos, locs, x_covariates, smooth_limits, z, n, lam)
+
+    if f00 is None:
+        f00 = fn(par)
+    H = np.zeros((P, P))
+    for jj in range(P):
+        for ii in range(jj, P):
+            t01, t10, t11 = par.copy(), par.copy(), par.copy()
+            t01[jj] += eps
+            t10[ii] += eps
+            t11[jj] += eps
+            t11[ii] += eps
+            H[jj, ii] = 0.5 * ((fn(t11) - fn(t01) - fn(t10) + f00) / (eps * eps))
+    H = H + H.T
+    H[np.diag_indices(P)] /= 2
+    return H
+
+
 def cocoPredict_dense(theta_list, locs, newlocs, X_std, X_pred_std, smooth_limits, z, type="pred"):
     """Dense branch of cocoPredict, R/predict.R:136-187, from the point where the
     scaled design matrices and the adjusted theta list exist."""
