@@ -103,9 +103,19 @@ __global__ void __launch_bounds__(256, PAIR_MIN_WAVES)
 pair_sym_kernel(PairArgs a)
 {
     __shared__ double tile[MIRROR ? TS * (TS + 1) : 1];
-    // 2-D grid over 64x64 tiles; only the lower triangle (bi >= bj) does work
-    const int bi = blockIdx.x, bj = a.bj0 + blockIdx.y;
-    if (bj > bi) return;
+    // 1-D grid over the 64x64 tiles (bi >= bj) of the trapezoid rows bj0.., columns bj0..:
+    // column j (from bj0) holds H - j tiles and starts at j H - j (j-1)/2 -- no empty workgroups
+    int bi, bj;
+    {
+        const long long L = blockIdx.x;
+        const double hh = 2.0 * a.H + 1.0;
+        int j = (int)((hh - sqrt(hh * hh - 8.0 * (double)L)) * 0.5);
+        while (j > 0 && (long long)j * a.H - (long long)j * (j - 1) / 2 > L) --j;
+        while ((long long)(j + 1) * a.H - (long long)(j + 1) * j / 2 <= L) ++j;
+        const long long c0 = (long long)j * a.H - (long long)j * (j - 1) / 2;
+        bj = a.bj0 + j;
+        bi = a.bj0 + j + (int)(L - c0);
+    }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = bi * TS + lane;
@@ -216,9 +226,12 @@ void launch_pair_sym(int mode, bool mirror, const PairArgs &a, hipStream_t s)
     int T = (ext + TS - 1) / TS;
     int tj1 = (a.ncols_out + TS - 1) / TS;
     if (tj1 <= a.bj0) return;
-    dim3 g(T, tj1 - a.bj0);
-    if (mirror) launch_sym_mode<true>(mode, a, g, s);
-    else launch_sym_mode<false>(mode, a, g, s);
+    PairArgs b = a;
+    const long long H = T - a.bj0, W = tj1 - a.bj0;
+    b.H = (int)H;
+    dim3 g((unsigned)(W * H - W * (W - 1) / 2));
+    if (mirror) launch_sym_mode<true>(mode, b, g, s);
+    else launch_sym_mode<false>(mode, b, g, s);
 }
 
 void launch_pair_rect(int mode, const PairArgs &a, hipStream_t s)

@@ -412,6 +412,7 @@ struct UpdArgs {
     const double *P; size_t ldp;   // panel: element (global row, k) at P[row + k*ldp]
     int K;
     int ti0, tj0, lower_only;      // tile indices in units of TM
+    int H;                         // lower_only: rows of the trapezoid (ti1 - tj0), 1-D grid over its tiles
     int ptiles, world, rank;       // sharded path: only 128-tile columns whose panel (tj128 / ptiles) is owned
 };
 
@@ -423,8 +424,22 @@ update_kernel(UpdArgs a)
     constexpr int NB = TM / 32;    // 16x16 blocks per wave and dimension
     constexpr int TPC = 256 / KC;  // threads per panel column
     constexpr int RPT = TM / TPC;  // rows staged per thread and side
-    const int ti = a.ti0 + blockIdx.x, tj = a.tj0 + blockIdx.y;
-    if (a.lower_only && tj > ti) return;
+    int ti, tj;
+    if (a.lower_only) {
+        // 1-D grid over the tiles (ti >= tj) of the trapezoid, column by column: column j (0-based
+        // from tj0) holds H - j tiles and starts at j H - j (j-1)/2.  No empty workgroups.
+        const long long L = blockIdx.x;
+        const double hh = 2.0 * a.H + 1.0;
+        int j = (int)((hh - sqrt(hh * hh - 8.0 * (double)L)) * 0.5);
+        while (j > 0 && (long long)j * a.H - (long long)j * (j - 1) / 2 > L) --j;
+        while ((long long)(j + 1) * a.H - (long long)(j + 1) * j / 2 <= L) ++j;
+        const long long c0 = (long long)j * a.H - (long long)j * (j - 1) / 2;
+        tj = a.tj0 + j;
+        ti = a.tj0 + j + (int)(L - c0);
+    } else {
+        ti = a.ti0 + blockIdx.x;
+        tj = a.tj0 + blockIdx.y;
+    }
     if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;
     __shared__ double sI[2][KC * LDT];
     __shared__ double sJ[2][KC * LDT];
@@ -621,15 +636,24 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
         for (int tj = tj0; tj < tj1; ++tj) tiles += (ti1 - (tj > ti0 ? tj : ti0));
     }
     if (world > 1) tiles = tiles / world + 1;
-    if (tiles <= upd64_max_tiles()) {
-        a.ti0 = 2 * ti0; a.tj0 = 2 * tj0;
-        if (upd_small_lds())
-            hipLaunchKernelGGL((update_kernel<64, 8>), dim3(2 * (ti1 - ti0), 2 * (tj1 - tj0)), dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL((update_kernel<64, 16>), dim3(2 * (ti1 - ti0), 2 * (tj1 - tj0)), dim3(256), 0, s, a);
+    const bool small = tiles <= upd64_max_tiles();
+    const int f = small ? 2 : 1;                 // tile indices in units of TM
+    a.ti0 = f * ti0; a.tj0 = f * tj0;
+    dim3 grid(f * (ti1 - ti0), f * (tj1 - tj0));
+    if (lower_only) {
+        // requires ti0 >= tj0 == first column: the trapezoid rows tj0..ti1, columns tj0..tj1
+        if (ti0 != tj0) { a.lower_only = 0; }    // strictly-below rectangle: every tile does work
+        else {
+            const long long H = (long long)f * (ti1 - tj0), W = (long long)f * (tj1 - tj0);
+            a.H = (int)H;
+            grid = dim3((unsigned)(W * H - W * (W - 1) / 2), 1);
+        }
+    }
+    if (small) {
+        if (upd_small_lds()) hipLaunchKernelGGL((update_kernel<64, 8>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((update_kernel<64, 16>), grid, dim3(256), 0, s, a);
     } else {
-        a.ti0 = ti0; a.tj0 = tj0;
-        hipLaunchKernelGGL((update_kernel<128, 16>), dim3(ti1 - ti0, tj1 - tj0), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((update_kernel<128, 16>), grid, dim3(256), 0, s, a);
     }
 }
 

@@ -46,6 +46,7 @@ struct PairArgs {
     double *out; size_t ld;
     int nrows_out, ncols_out;   // extent to write (>= n pads with identity / zeros)
     int bj0;               // sym: first 64-wide tile column to assemble (sharded path), else 0
+    int H;                 // sym: tile rows of the trapezoid (set by the launcher)
     double gr;             // global_range
     double nu_fixed;       // closed-form modes
 };
