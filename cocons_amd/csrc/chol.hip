@@ -413,6 +413,7 @@ struct UpdArgs {
     int K;
     int ti0, tj0, lower_only;      // tile indices in units of TM
     int H;                         // lower_only: rows of the trapezoid (ti1 - tj0), 1-D grid over its tiles
+    int xcd_swizzle;
     int ptiles, world, rank;       // sharded path: only 128-tile columns whose panel (tj128 / ptiles) is owned
 };
 
@@ -428,7 +429,15 @@ update_kernel(UpdArgs a)
     if (a.lower_only) {
         // 1-D grid over the tiles (ti >= tj) of the trapezoid, column by column: column j (0-based
         // from tj0) holds H - j tiles and starts at j H - j (j-1)/2.  No empty workgroups.
-        const long long L = blockIdx.x;
+        long long L = blockIdx.x;
+        if (a.xcd_swizzle) {
+            // workgroups b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous
+            // run of the tile order so that neighbouring tiles (same operand panels) share an L2
+            const long long G = gridDim.x, per = G / 8, rem = G % 8;
+            const long long x = L % 8, q = L / 8;
+            // XCD x owns [start_x, start_x + per + (x < rem)) of the tile order
+            L = x * per + (x < rem ? x : rem) + q;
+        }
         const double hh = 2.0 * a.H + 1.0;
         int j = (int)((hh - sqrt(hh * hh - 8.0 * (double)L)) * 0.5);
         while (j > 0 && (long long)j * a.H - (long long)j * (j - 1) / 2 > L) --j;
@@ -636,6 +645,10 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
         for (int tj = tj0; tj < tj1; ++tj) tiles += (ti1 - (tj > ti0 ? tj : ti0));
     }
     if (world > 1) tiles = tiles / world + 1;
+    static int swz = -1;
+    if (swz < 0) { const char *e = getenv("COCONS_XCD_SWIZZLE"); swz = e ? atoi(e) : 0; }
+    a.xcd_swizzle = swz;
+    a.H = 0;
     const bool small = tiles <= upd64_max_tiles();
     const int f = small ? 2 : 1;                 // tile indices in units of TM
     a.ti0 = f * ti0; a.tj0 = f * tj0;
