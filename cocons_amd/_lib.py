@@ -56,6 +56,7 @@ SIGNATURES = {
     "cocons_shard_panel_factor": (c_int, [c_vp, c_int]),
     "cocons_shard_panel_buffer": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(ctypes.c_longlong)]),
     "cocons_shard_panel_apply": (c_int, [c_vp, c_int]),
+    "cocons_shard_panel_apply_range": (c_int, [c_vp, c_int, c_int, c_int]),
     "cocons_shard_finish": (c_int, [c_vp, c_dp, ctypes.POINTER(c_int)]),
     "cocons_shard_num_panels": (c_int, [c_vp]),
     "cocons_shard_exchange_bytes": (ctypes.c_longlong, [c_vp]),

@@ -1013,22 +1013,35 @@ extern "C" int cocons_shard_panel_factor(cocons_fit *f, int k)
     return 0;
 }
 
-extern "C" int cocons_shard_panel_apply(cocons_fit *f, int k)
+// update the rank's OWN panels j in [j0, j1) (j > k) with the received panel k; j1 < 0 = all
+static int shard_apply_range(cocons_fit *f, int k, int j0, int j1)
 {
     if (int rc = fit_check(f)) return rc;
     const int np = cocons_shard_num_panels(f);
     if (k < 0 || k >= np) return fail(-1, "cocons_shard_panel_apply: bad panel");
+    if (j1 < 0 || j1 > np) j1 = np;
+    if (j0 < k + 1) j0 = k + 1;
+    if (j0 >= j1) return 0;
     const int mt = f->nt + f->rhs_cap / TILE;
     const int t0 = k * PT;
     const int w = (f->nt - t0) < PT ? (f->nt - t0) : PT;
-    if (t0 + w >= f->nt) return 0;      // nothing to the right
+    int c0 = j0 * PT, c1 = j1 * PT;               // tile-column range
+    if (c1 > f->nt) c1 = f->nt;
+    if (c0 >= c1) return 0;
     size_t rows = panel_rows(f, k);
     // operand pointer such that P[row + kk*rows] addresses GLOBAL row `row`
     const double *P = f->xbuf[k & 1] - (size_t)t0 * TILE;
-    launch_update_from(f->dA, f->lda, P, rows, w * TILE, t0 + w, mt, t0 + w, f->nt, true, f->stream,
+    launch_update_from(f->dA, f->lda, P, rows, w * TILE, c0, mt, c0, c1, true, f->stream,
                        PT, f->world, f->rank);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+extern "C" int cocons_shard_panel_apply(cocons_fit *f, int k) { return shard_apply_range(f, k, k + 1, -1); }
+
+extern "C" int cocons_shard_panel_apply_range(cocons_fit *f, int k, int j0, int j1)
+{
+    return shard_apply_range(f, k, j0, j1);
 }
 
 // partial[0] = sum over OWN columns of log(diag); partial[1 + a*r + b] = own-column part of the

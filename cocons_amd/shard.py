@@ -74,8 +74,11 @@ class ShardedFit(CoconsFit):
         assert ptr.value == buf.data_ptr()
         return buf[: nbytes.value // 8]
 
-    def panel_apply(self, k):
-        _lib.check(self._L.cocons_shard_panel_apply(self._h, k), "cocons_shard_panel_apply")
+    def panel_apply(self, k, j0=None, j1=None):
+        """update own panels j in [j0, j1) (default: all right of k) with the received panel k"""
+        j0 = k + 1 if j0 is None else j0
+        j1 = -1 if j1 is None else j1
+        _lib.check(self._L.cocons_shard_panel_apply_range(self._h, k, j0, j1), "cocons_shard_panel_apply_range")
 
     def finish(self):
         part = np.zeros(1 + self.r * self.r)
@@ -87,18 +90,44 @@ class ShardedFit(CoconsFit):
         return self.torch.as_tensor(arr, device=self.device)
 
 
-def sharded_neg2loglik_core(engine, theta_list, dist, rank, world, group=None):
+def sharded_neg2loglik_core(engine, theta_list, dist, rank, world, group=None, lookahead=True):
     """One sharded evaluation.  Returns (sum_logliks, parts) like CoconsFit.neg2loglik_core,
-    identical on every rank; raises CholeskyError on every rank if any panel failed."""
+    identical on every rank; raises CholeskyError on every rank if any panel failed.
+
+    Look-ahead: the owner of panel k+1 updates and factors that panel FIRST and starts its
+    broadcast asynchronously; every rank then applies panel k to the rest of its panels while
+    the broadcast of k+1 is in flight (the exchange buffers alternate, so the receive of k+1
+    never touches the buffer panel k is being read from)."""
     engine.begin(theta_list, rank, world)
     npan = engine.num_panels()
-    for k in range(npan):
-        owner = k % world
-        if rank == owner:
+    if world == 1:
+        for k in range(npan):
             engine.panel_factor(k)
-        if world > 1:
+            engine.panel_apply(k)
+    elif not lookahead:
+        for k in range(npan):
+            owner = k % world
+            if rank == owner:
+                engine.panel_factor(k)
             dist.broadcast(engine.panel_tensor(k), src=owner, group=group)
-        engine.panel_apply(k)
+            engine.panel_apply(k)
+    else:
+        if rank == 0:
+            engine.panel_factor(0)
+        work = dist.broadcast(engine.panel_tensor(0), src=0, group=group, async_op=True)
+        for k in range(npan):
+            work.wait()                                   # panel k is in its exchange buffer
+            nxt = k + 1
+            if nxt < npan:
+                if rank == nxt % world:
+                    engine.panel_apply(k, nxt, nxt + 1)   # only the columns of panel k+1 ...
+                    engine.panel_factor(nxt)              # ... factor it ...
+                # ... and put it on the wire while everybody applies panel k to the rest
+                work = dist.broadcast(engine.panel_tensor(nxt), src=nxt % world, group=group, async_op=True)
+                if rank == nxt % world:
+                    engine.panel_apply(k, nxt + 1, None)
+                else:
+                    engine.panel_apply(k)
     part, info = engine.finish()
     if world > 1:
         t = engine.make_tensor(np.concatenate([part, [-float(info)]]))

@@ -153,6 +153,9 @@ int cocons_shard_begin(cocons_fit *fit, const double *theta, const double *mean,
 int cocons_shard_panel_factor(cocons_fit *fit, int k);
 int cocons_shard_panel_buffer(cocons_fit *fit, int k, void **dev_ptr, long long *bytes);
 int cocons_shard_panel_apply(cocons_fit *fit, int k);
+/* same, restricted to the rank's own panels j in [j0, j1) (j1 < 0: to the end) -- lets the
+ * owner of panel k+1 update and factor it first (look-ahead) and apply the rest afterwards */
+int cocons_shard_panel_apply_range(cocons_fit *fit, int k, int j0, int j1);
 int cocons_shard_finish(cocons_fit *fit, double *partial /* 1 + (r)(r) */, int *info);
 int cocons_shard_num_panels(cocons_fit *fit);
 /* bytes one exchange buffer must hold; optionally hand in two caller-owned device

@@ -67,11 +67,13 @@ class NumpyShardEngine:
         c0, c1 = self._cols(k)
         return self.xbuf[k & 1][: (self.lda - c0) * (c1 - c0)]
 
-    def panel_apply(self, k):
+    def panel_apply(self, k, j0=None, j1=None):
         c0, c1 = self._cols(k)
         rows = self.lda - c0
         P = self.panel_tensor(k).numpy().reshape((rows, c1 - c0), order="F")
-        for j in range(k + 1, self.num_panels()):
+        j0 = k + 1 if j0 is None else max(j0, k + 1)
+        j1 = self.num_panels() if (j1 is None or j1 < 0) else min(j1, self.num_panels())
+        for j in range(j0, j1):
             if j % self.world != self.rank:
                 continue
             d0, d1 = self._cols(j)

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, seed, out_dir):
+def _worker(rank, world, port, n, seed, out_dir, lookahead=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -38,18 +38,19 @@ def _worker(rank, world, port, n, seed, out_dir):
     th["mean"] = np.array([0.1, -0.2, 0.05])
     z = rng.standard_normal((n, 2))
     eng = NumpyShardEngine(O, locs, X, z, wl.SMOOTH_LIMITS)
-    val, parts = sharded_neg2loglik_core(eng, th, dist, rank, world)
+    val, parts = sharded_neg2loglik_core(eng, th, dist, rank, world, lookahead=lookahead)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([[val], parts]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 700), (3, 900), (2, 200)])
-def test_sharded_schedule_over_gloo(oracle, tmp_path, world, n):
+@pytest.mark.parametrize("world,n,lookahead", [(2, 700, True), (3, 900, True), (2, 200, True), (2, 700, False),
+                                                  (4, 1300, True)])
+def test_sharded_schedule_over_gloo(oracle, tmp_path, world, n, lookahead):
     import torch.multiprocessing as mp
     from cocons_amd import workloads as wl
     seed = 100 + n
-    mp.spawn(_worker, args=(world, _free_port(), n, seed, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, seed, str(tmp_path), lookahead), nprocs=world, join=True)
     res = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r)) for r in range(world)]
     for r in res[1:]:
         assert np.array_equal(r, res[0])              # identical on every rank
