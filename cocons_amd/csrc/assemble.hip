@@ -70,24 +70,6 @@ loc_params_kernel(LocArgs a)
     o[w + 11 * s] = (1 / exp(-1 * t_sd)) + ng;          // :111
 }
 
-__device__ __forceinline__ LocP load_locp(const double *base, size_t stride, int w)
-{
-    LocP r;
-    r.x = base[w + 0 * stride];
-    r.y = base[w + 1 * stride];
-    r.rd = base[w + 2 * stride];
-    r.an2 = base[w + 3 * stride];
-    r.ra = base[w + 4 * stride];
-    r.ct = base[w + 5 * stride];
-    r.st = base[w + 6 * stride];
-    r.dets = base[w + 7 * stride];
-    r.ds = base[w + 8 * stride];
-    r.sigma = base[w + 9 * stride];
-    r.snu = base[w + 10 * stride];
-    r.diag = base[w + 11 * stride];
-    return r;
-}
-
 constexpr int TS = 64;   // pair tile edge
 #ifndef PAIR_MIN_WAVES
 #define PAIR_MIN_WAVES 4   // measured on MI355X: 2 -> 3.69 ms, 3 -> 2.93, 4 -> 2.60, 5 -> 2.71, 8 -> 3.65 (n = 10^4 assembly)

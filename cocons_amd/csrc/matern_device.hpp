@@ -28,19 +28,17 @@ enum PairMode : int {
     MODE_MEAN = 4        // classic, nu_ij = (nu_i + nu_j)/2 (:529-591)
 };
 
-// per-location quantities, one struct per side of a pair
-struct LocP {
-    double x, y;     // coordinates
-    double rd;       // Pexp(2*scale_je)           range_det_vector
-    double an2;      // an*an                       aniso_det_vector squared
-    double ra;       // rd*an
-    double ct, st;   // cos(tilt), sin(tilt)
-    double dets;     // Pexp(2*scale_je + aniso)
-    double ds;       // dets * st
-    double sigma;    // Pexp(0.5*std.dev)
-    double snu;      // sqrt(nu_w) (GEOM) or nu_w (MEAN)
-    double diag;     // Pexp(std.dev) + nugget
-};
+// per-location SoA written by loc_params_kernel: field f of location w at base[w + f*stride]
+//   0 x, 1 y            coordinates
+//   2 rd                Pexp(2*scale_je)                 range_det_vector
+//   3 an2               an*an                            aniso_det_vector squared
+//   4 ra                rd*an
+//   5 ct, 6 st          cos(tilt), sin(tilt)
+//   7 dets              Pexp(2*scale_je + aniso)
+//   8 ds                dets * st
+//   9 sigma             Pexp(0.5*std.dev)
+//  10 snu               sqrt(nu_w) (GEOM) or nu_w (MEAN)
+//  11 diag              Pexp(std.dev) + nugget
 constexpr int LOCP_FIELDS = 12;
 
 // src/cocons_types.h:49-54
