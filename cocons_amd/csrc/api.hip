@@ -867,6 +867,57 @@ extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const do
 }
 
 // ---------------------------------------------------------------------------
+// marginal simulation core: replaces R/sim.R:147-172
+//   covmat <- cov_rns[_classic](...); cholS <- chol(covmat); t(sweep(t(iiderrors) %*% cholS, 2, X %*% mean, "+"))
+extern "C" int cocons_sim_dense(cocons_fit *f, const double *theta, const double *mean, int classic,
+                                int nsim, const double *iiderrors, double *out)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!theta || !mean || nsim <= 0 || !iiderrors || !out) return fail(-1, "cocons_sim_dense: bad argument");
+    const int n = f->n, p = f->p;
+    double *dE = nullptr, *dY = nullptr, *dtr = nullptr;
+    int rc = 0;
+    hipStream_t s = f->stream;
+    do {
+        if ((rc = fit_alloc_matrix(f, 1))) break;
+        const int mt = f->nt + f->rhs_cap / TILE;
+        hipError_t e;
+#define CKS(expr) if ((e = (expr)) != hipSuccess) { rc = fail(-100 - (int)e, "cocons_sim_dense: %s", hipGetErrorString(e)); break; }
+        CKS(hipMalloc(&dE, (size_t)n * nsim * sizeof(double)));
+        CKS(hipMalloc(&dY, (size_t)n * nsim * sizeof(double)));
+        CKS(hipMalloc(&dtr, (size_t)n * sizeof(double)));
+        CKS(hipMemcpyAsync(dE, iiderrors, (size_t)n * nsim * sizeof(double), hipMemcpyHostToDevice, s));
+        {   // trend = X %*% mean on the host (O(n p)), as the reference does (:170)
+            std::vector<double> tr(n, 0.0);
+            for (int j = 0; j < p; ++j)
+                for (int i = 0; i < n; ++i) tr[i] += (*f->h_X)[(size_t)i + (size_t)j * n] * mean[j];
+            CKS(hipMemcpy(dtr, tr.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if ((rc = reset_info(f))) break;
+        f->nrhs_cur = 0;
+        assemble_sigma(f, theta, classic ? 1 : 0, 0, f->npad);
+        {   // no right-hand sides: clear the rows under the matrix
+            RhsArgs ra;
+            memset(&ra, 0, sizeof ra);
+            ra.n = n; ra.p = p; ra.X = f->dX; ra.ldx = n; ra.src = f->dX; ra.lds = n;
+            ra.out = f->dA; ra.ld = f->lda; ra.row0 = f->npad; ra.nrows = 0; ra.nrows_zero = f->rhs_cap;
+            ra.col0 = 0; ra.ncols_out = f->npad;
+            launch_rhs_rows(ra, s);
+        }
+        factorize(f, mt, nullptr);
+        launch_trmm_lower(f->dA, f->lda, n, dE, n, nsim, dtr, dY, n, s);
+        CKS(hipMemcpyAsync(out, dY, (size_t)n * nsim * sizeof(double), hipMemcpyDeviceToHost, s));
+        CKS(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+        CKS(hipGetLastError());
+        CKS(hipStreamSynchronize(s));
+#undef CKS
+        rc = info_status(f);
+    } while (0);
+    hipFree(dE); hipFree(dY); hipFree(dtr);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
 extern "C" int cocons_chol_solve(int n, const double *Ain, int nrhs, const double *rhs,
                                  double *L, double *Y, double *logdet_half)
 {

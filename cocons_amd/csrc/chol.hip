@@ -586,6 +586,49 @@ row_reduce_kernel(const double *A, size_t lda, int n, int rowy, int row0, int m,
 }
 
 // ---------------------------------------------------------------------------
+// Y = L E + trend for the lower factor L (marginal simulation: cocoSim's t(iiderrors) %*% cholS,
+// R/sim.R:172, is (L E)^T).  One workgroup per 64-row block, lanes along rows (coalesced reads of
+// L's columns), the four waves split the k-range and are summed through LDS; E(k, s) is
+// wave-uniform.  HBM-bound: the lower triangle of L is read once per group of 8 columns of E.
+__global__ void __launch_bounds__(256)
+trmm_lower_kernel(const double *A, size_t lda, int n, const double *E, int lde, int nsim,
+                  const double *trend, double *Y, int ldy)
+{
+    __shared__ double red[4][8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rb = gridDim.x - 1 - blockIdx.x;          // longest rows first
+    const int i = rb * 64 + lane;
+    const int kend = (rb + 1) * 64 < n ? (rb + 1) * 64 : n;
+    for (int s0 = 0; s0 < nsim; s0 += 8) {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = wave; k < kend; k += 4) {
+            double l = (i < n && k <= i) ? A[(size_t)i + (size_t)k * lda] : 0.0;
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s0 + s < nsim) acc[s] = fma(l, E[(size_t)k + (size_t)(s0 + s) * lde], acc[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) red[wave][s][lane] = acc[s];
+        __syncthreads();
+        if (wave == 0 && i < n) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s0 + s < nsim)
+                    Y[(size_t)i + (size_t)(s0 + s) * ldy] =
+                        ((red[0][s][lane] + red[1][s][lane]) + (red[2][s][lane] + red[3][s][lane])) + trend[i];
+        }
+        __syncthreads();
+    }
+}
+
+void launch_trmm_lower(const double *A, size_t lda, int n, const double *E, int lde, int nsim,
+                       const double *trend, double *Y, int ldy, hipStream_t s)
+{
+    if (n <= 0 || nsim <= 0) return;
+    hipLaunchKernelGGL(trmm_lower_kernel, dim3((n + 63) / 64), dim3(256), 0, s, A, lda, n, E, lde, nsim, trend, Y, ldy);
+}
+
+// ---------------------------------------------------------------------------
 void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, hipStream_t s)
 {
     static bool attr_set = false;

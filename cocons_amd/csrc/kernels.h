@@ -100,6 +100,10 @@ void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, in
 void launch_row_reduce(const double *A, size_t lda, int n, int rowy, int row0, int m,
                        double *stoch, double *quad, hipStream_t s);
 
+// Y = L E + trend (lower factor L in A), E n x nsim, Y n x nsim
+void launch_trmm_lower(const double *A, size_t lda, int n, const double *E, int lde, int nsim,
+                       const double *trend, double *Y, int ldy, hipStream_t s);
+
 // fp64 MFMA issue-rate probe (TFLOP/s); dbuf must hold blocks*256 doubles
 double run_mfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf);
 double run_vfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf);

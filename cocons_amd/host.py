@@ -252,6 +252,15 @@ class CoconsFit:
                                                 _p(st), _p(qf)), "cocons_predict_dense")
         return st, qf
 
+    def sim_core(self, theta_list, iiderrors, classic=False):
+        E = _f(np.asarray(iiderrors, dtype=np.float64).reshape(self.n, -1))
+        T = theta_table(theta_list)
+        mean = np.ascontiguousarray(np.asarray(theta_list["mean"], dtype=np.float64))
+        out = np.empty(E.shape, order="F")
+        _lib.check(self._L.cocons_sim_dense(self._h, _p(T), _p(mean), 1 if classic else 0, E.shape[1], _p(E), _p(out)),
+                   "cocons_sim_dense")
+        return out
+
     def profile_stages(self, theta_list, reps=3):
         """Stage timings (ms) from HIP events on the fit's stream; see cocons_fit_profile."""
         T = theta_table(theta_list)
@@ -376,6 +385,26 @@ def GetNeg2loglikelihoodREML(theta, par_pos, locs, x_covariates, x_betas, smooth
                 return 1e6
             raise RuntimeError("Cholesky error")
         return val + getPen((n - rank) * f.r, lam, tl, smooth_limits)
+    finally:
+        if own:
+            f.close()
+
+
+def cocoSim_dense(theta_list, locs, X_std, smooth_limits, iiderrors, type="classic", fit=None):
+    """Marginal branch of cocoSim for a dense object, R/sim.R:147-172, from the point where the
+    scaled design matrix and the theta list exist.  `iiderrors` is the n x nsim matrix of N(0,1)
+    draws (the reference draws it with rnorm after set.seed; pass the same numbers for identical
+    output).  type = "classic" -> cov_rns_classic, "diff" -> cov_rns.  Returns n x nsim."""
+    if type not in ("classic", "diff"):
+        raise ValueError("type must be 'classic' or 'diff'")
+    E = np.asarray(iiderrors, dtype=np.float64)
+    n = np.asarray(X_std).shape[0]
+    f, own = _with_fit(fit, locs, X_std, np.zeros(n), smooth_limits)
+    try:
+        try:
+            return f.sim_core(theta_list, E.reshape(n, -1), classic=(type == "classic"))
+        except CholeskyError:
+            raise RuntimeError("Cholesky error")          # base::chol's error propagates in the reference
     finally:
         if own:
             f.close()

@@ -111,6 +111,14 @@ int cocons_predict_dense(cocons_fit *fit, const double *theta, const double *mea
                          int z_col, int m, const double *locs_pred, const double *X_pred,
                          double *stochastic, double *quadform);
 
+/* Marginal simulation core: replaces R/sim.R:147-172
+ *   covmat <- cov_rns(...) | cov_rns_classic(...); cholS <- chol(covmat);
+ *   t(sweep(t(iiderrors) %*% cholS, 2, x %*% mean, "+"))
+ * iiderrors and out are n x nsim column-major (the caller draws the N(0,1) numbers, as the
+ * reference does with rnorm); classic != 0 selects cov_rns_classic.                        */
+int cocons_sim_dense(cocons_fit *fit, const double *theta, const double *mean, int classic,
+                     int nsim, const double *iiderrors, double *out);
+
 /* Dense Cholesky of a caller-supplied SPD matrix (host, n x n column-major, lower
  * triangle read) with nrhs right-hand sides: replaces base::chol + forwardsolve
  * (R/neg2loglikelihood.R:200,214) for callers that already hold Sigma.

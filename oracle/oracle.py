@@ -315,6 +315,20 @@ def cocoPredict_dense(theta_list, locs, newlocs, X_std, X_pred_std, smooth_limit
     return {"systematic": systematic_pred, "stochastic": stochastic, "sd.pred": np.sqrt(unc)}
 
 
+def cocoSim_dense(theta_list, locs, X_std, smooth_limits, iiderrors, type="classic"):
+    """Marginal branch of cocoSim (dense), R/sim.R:147-172."""
+    if type == "classic":
+        covmat = cov_rns_classic(theta_list, locs, X_std)
+    else:
+        covmat = cov_rns(theta_list, locs, X_std, smooth_limits)
+    R, info = _chol_upper(covmat)
+    if R is None:
+        raise RuntimeError("Cholesky error")
+    E = np.asarray(iiderrors, dtype=np.float64).reshape(covmat.shape[0], -1)
+    mu = np.asarray(X_std, float) @ np.asarray(theta_list["mean"], float)
+    return (E.T @ R + mu[None, :]).T
+
+
 def chol_ld(A, rhs):
     """long-double Cholesky truth: returns (info, sum(log(diag)), quad[nrhs], Y)."""
     A = _f(A)

@@ -331,3 +331,20 @@ def test_handle_refuses_use_after_fork():
     msg = q.get(timeout=60)
     pr.join(timeout=60)
     assert "another process" in msg
+
+
+@pytest.mark.parametrize("type_", ["classic", "diff"])
+def test_cocoSim_marginal_vs_cpu(oracle, type_):
+    """cocoSim, marginal branch: same N(0,1) draws -> same fields."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n = 333
+    locs, X, th, rng = _problem(n, seed=31)
+    th["mean"] = np.array([0.3, -0.2, 0.1])
+    if type_ == "classic":
+        th["smooth"] = np.array([np.log(1.2), 0.2, -0.1])
+    E = rng.standard_normal((n, 11))
+    got = ca.cocoSim_dense(th, locs, X, wl.SMOOTH_LIMITS, E, type=type_)
+    want = oracle.cocoSim_dense(th, locs, X, wl.SMOOTH_LIMITS, E, type=type_)
+    assert got.shape == (n, 11)
+    assert np.max(np.abs(got - want)) < 1e-10 * np.max(np.abs(want))
