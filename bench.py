@@ -205,6 +205,20 @@ def main():
         dtr = max_over_ranks(time.perf_counter() - t1)
         replica = {"evals_per_s": round(args.steps * world / dtr, 4), "scaling": "weak",
                    "note": "every rank evaluates its own theta (no data-path collective)"}
+        # the same with each rank's points pipelined through the batch entry
+        nbatch = max(args.steps, 6)
+        rths = []
+        for i in range(nbatch):
+            t = {k: np.array(v, dtype=np.float64) for k, v in rth.items()}
+            t["std.dev"][0] += 1.22e-4 * (i + 1)
+            rths.append(t)
+        rfit.neg2loglik_batch_core(rths[:3])
+        barrier()
+        t1 = time.perf_counter()
+        rfit.neg2loglik_batch_core(rths)
+        barrier()
+        dtb = max_over_ranks(time.perf_counter() - t1)
+        replica["batched_evals_per_s"] = round(nbatch * world / dtb, 4)
         rfit.close()
 
     # extra (N=1 only): throughput with several independent evaluations in flight -- the call
