@@ -16,6 +16,7 @@ from .host import (  # noqa: F401
     cov_rns,
     cov_rns_classic,
     cov_rns_pred,
+    getBetas_profile,
     getHessian_dense,
     getModelLists,
     getPen,

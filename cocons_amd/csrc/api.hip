@@ -650,7 +650,16 @@ static int profile_tail(cocons_fit *f, int nxb, double n_eff, bool reml, double 
         total += n_eff * LOG_2PI + 2 * logdet + (reml ? 2 * ldW : 0.0) + quad;
         if (parts) parts[2 + k] = quad;
     }
-    if (parts) { parts[0] = logdet; parts[1] = ldW; }
+    if (parts) {
+        parts[0] = logdet; parts[1] = ldW;
+        // generalised-least-squares coefficients W^-1 Xb' Sigma^-1 zbar, zbar = rowSums(z)/r -- the
+        // "Compute Betas" block of cocoOptim's pml/reml branch (R/optim.R:329-341)
+        for (int a = 0; a < nxb; ++a) {
+            double s = 0;
+            for (int k = 0; k < r; ++k) s += Bv[(size_t)k * nxb + a];
+            parts[2 + r + a] = s / r;
+        }
+    }
     *sum_logliks = total;
     return 0;
 }

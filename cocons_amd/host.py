@@ -229,7 +229,7 @@ class CoconsFit:
     def neg2loglik_profile_core(self, theta_list):
         T = theta_table(theta_list)
         val = ctypes.c_double(0.0)
-        parts = np.zeros(2 + self.r)
+        parts = np.zeros(2 + self.r + self.q)
         _lib.check(self._L.cocons_neg2loglik_profile(self._h, _p(T), ctypes.byref(val), _p(parts)),
                    "cocons_neg2loglik_profile")
         return val.value, parts
@@ -237,7 +237,7 @@ class CoconsFit:
     def neg2loglik_reml_core(self, theta_list, rank):
         T = theta_table(theta_list)
         val = ctypes.c_double(0.0)
-        parts = np.zeros(2 + self.r)
+        parts = np.zeros(2 + self.r + self.p)
         _lib.check(self._L.cocons_neg2loglik_reml(self._h, _p(T), int(rank), ctypes.byref(val), _p(parts)),
                    "cocons_neg2loglik_reml")
         return val.value, parts
@@ -385,6 +385,22 @@ def GetNeg2loglikelihoodREML(theta, par_pos, locs, x_covariates, x_betas, smooth
                 return 1e6
             raise RuntimeError("Cholesky error")
         return val + getPen((n - rank) * f.r, lam, tl, smooth_limits)
+    finally:
+        if own:
+            f.close()
+
+
+def getBetas_profile(theta_list, locs, x_covariates, smooth_limits, z, x_betas, fit=None):
+    """The "Compute Betas" block of cocoOptim's pml/reml branch, R/optim.R:329-341:
+    solve(W, t(V)) %*% rowSums(z) / ncol(z) with V = Sigma^-1 x_betas, W = x_betas' V -- here read
+    off the Gram matrix of the bordered factorisation (no second Cholesky, no V)."""
+    f, own = _with_fit(fit, locs, x_covariates, z, smooth_limits, x_betas=x_betas)
+    try:
+        try:
+            _, parts = f.neg2loglik_profile_core(theta_list)
+        except CholeskyError:
+            raise RuntimeError("Cholesky error")
+        return parts[2 + f.r: 2 + f.r + f.q].copy()
     finally:
         if own:
             f.close()

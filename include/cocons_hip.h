@@ -94,7 +94,10 @@ int cocons_neg2loglik_batch(cocons_fit *fit, int nb, const double *thetas, const
  * profile: Xb = x_betas given at fit creation (q columns);
  * reml:    Xb = x_covariates (as the reference does, :273-276); `rank` = qr(X)$rank,
  *          computed by the caller.  parts[0] = sum(log(diag(chol))),
- * parts[1] = sum(log(diag(chol(W)))) (reml only), parts[2..] = quadratic forms. */
+ * parts[1] = sum(log(diag(chol(W)))), parts[2 .. 2+r) = quadratic forms,
+ * parts[2+r .. 2+r+nxb) = the GLS coefficients W^-1 Xb' Sigma^-1 rowSums(z)/r that cocoOptim
+ * recovers after a pml/reml fit (R/optim.R:329-341); nxb = q (profile) or p (reml).
+ * `parts` may be NULL, else must hold 2 + r + nxb doubles.                        */
 int cocons_neg2loglik_profile(cocons_fit *fit, const double *theta,
                               double *sum_logliks, double *parts);
 int cocons_neg2loglik_reml(cocons_fit *fit, const double *theta, int rank,

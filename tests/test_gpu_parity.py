@@ -217,6 +217,21 @@ def test_profile_and_reml_vs_cpu(oracle):
     assert abs(got - want) <= N2LL_RTOL * abs(want)
 
 
+def test_profile_betas_vs_numpy(oracle):
+    """beta recovery after a pml fit (R/optim.R:329-341) against the literal formula."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n = 310
+    locs, X, th, rng = _problem(n, seed=13)
+    z = rng.standard_normal((n, 3)) + (X @ np.array([0.5, -0.3, 0.2]))[:, None]
+    got = ca.getBetas_profile(th, locs, X, wl.SMOOTH_LIMITS, z, X)
+    S = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    V = np.linalg.solve(S, X)
+    W = X.T @ V
+    want = np.linalg.solve(W, V.T) @ z.sum(axis=1) / z.shape[1]
+    assert np.max(np.abs(got - want)) < 1e-9 * np.max(np.abs(want))
+
+
 def test_predict_vs_cpu(oracle):
     import cocons_amd as ca
     from cocons_amd import workloads as wl
