@@ -149,3 +149,27 @@ def sharded_neg2loglik_core(engine, theta_list, dist, rank, world, group=None, l
         total += engine.n * LOG_2PI + 2 * logdet + quad
         parts[1 + c] = quad
     return total, parts
+
+
+def sharded_predict_core(fit, theta_list, locs_pred, x_covariates_pred, dist, rank, world, group=None, z_col=0):
+    """Dense kriging (R/predict.R:136-183) with the m prediction locations split over the ranks
+    (BASELINE config C5: the right-hand sides shard): every rank factors Sigma with
+    its own m/world cross-covariance rows as border -- no exchange during the solve -- and the
+    (stochastic, quadratic-form) vectors are all-gathered.  `fit` is a plain CoconsFit per rank."""
+    lp = np.asarray(locs_pred, dtype=np.float64)
+    Xp = np.asarray(x_covariates_pred, dtype=np.float64)
+    m = lp.shape[0]
+    lo, hi = (m * rank) // world, (m * (rank + 1)) // world
+    st = np.zeros(m)
+    qf = np.zeros(m)
+    if hi > lo:
+        s, q = fit.predict_core(theta_list, lp[lo:hi], Xp[lo:hi], z_col=z_col)
+        st[lo:hi], qf[lo:hi] = s, q
+    if world > 1:
+        import torch
+        t = torch.from_numpy(np.stack([st, qf]))
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)     # disjoint supports: sum = concatenation
+        st, qf = t[0].cpu().numpy(), t[1].cpu().numpy()
+    return st, qf

@@ -86,3 +86,45 @@ def test_sharded_schedule_world1_matches(oracle):
     info, ld, quad, _ = oracle.chol_ld(S, z)
     truth = n * math.log(2 * math.pi) + 2 * ld + quad[0]
     assert abs(val - truth) < 1e-11 * abs(truth)
+
+
+def _predict_worker(rank, world, port, out_dir):
+    """sharded_predict_core over gloo with a fake fit whose predict_core is the oracle (CPU)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from cocons_amd import workloads as wl
+    from cocons_amd.shard import sharded_predict_core
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(4)
+    n, m = 120, 37
+    locs = rng.uniform(0, 1, size=(n, 2))
+    X = wl.design_from_locs(locs)["std.covs"]
+    lp = rng.uniform(0, 1, size=(m, 2))
+    Xp = wl.design_from_locs(lp)["std.covs"]
+    th = wl.theta_full(scale0=np.log(0.2))
+    z = rng.standard_normal(n)
+
+    class OracleFit:
+        def predict_core(self, tl, lpp, Xpp, z_col=0):
+            S = O.cov_rns(tl, locs, X, wl.SMOOTH_LIMITS)
+            C = O.cov_rns_pred(tl, locs, lpp, X, Xpp, wl.SMOOTH_LIMITS)
+            sol = np.linalg.solve(S, C.T)
+            return (z - X @ tl["mean"]) @ sol, np.sum(C * sol.T, axis=1)
+
+    st, qf = sharded_predict_core(OracleFit(), th, lp, Xp, dist, rank, world)
+    full = OracleFit().predict_core(th, lp, Xp)
+    assert np.allclose(st, full[0], rtol=1e-12) and np.allclose(qf, full[1], rtol=1e-12)
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), st)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_predict_over_gloo(oracle, tmp_path):
+    """C5's multi-GPU shape: prediction locations split over ranks, results all-gathered."""
+    import torch.multiprocessing as mp
+    mp.spawn(_predict_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    a = [np.load(os.path.join(str(tmp_path), "p%d.npy" % r)) for r in range(3)]
+    assert np.array_equal(a[0], a[1]) and np.array_equal(a[0], a[2])
