@@ -62,6 +62,7 @@ def cpu_baseline(n, locs, X, th, z, want_value=True):
     t1 = time.perf_counter()
     # for context: the same dpotrf with every host core LAPACK will use
     S2 = S.copy(order="F")
+    lapack.dpotrf(np.eye(256) * 2.0, lower=0)             # spin the BLAS thread pool up first
     t4 = time.perf_counter()
     lapack.dpotrf(S2, lower=0, clean=0, overwrite_a=1)
     t_all = time.perf_counter() - t4
