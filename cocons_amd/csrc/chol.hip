@@ -631,12 +631,9 @@ void launch_trmm_lower(const double *A, size_t lda, int n, const double *E, int 
 // ---------------------------------------------------------------------------
 void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, hipStream_t s)
 {
-    static bool attr_set = false;
-    const size_t shm = (36 + 1) * 256 * sizeof(double);   // 75,776 B
-    if (!attr_set) {
-        hipFuncSetAttribute((const void *)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set = true;
-    }
+    const size_t shm = (36 + 1) * 256 * sizeof(double);   // 75,776 B of dynamic LDS (> the 64 KB default)
+    // per device and cheap: set on every launch rather than caching a process-wide flag
+    (void)hipFuncSetAttribute((const void *)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), shm, s, A, lda, c0, dinv, info);
 }
 
