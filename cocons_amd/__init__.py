@@ -12,6 +12,7 @@ from .host import (  # noqa: F401
     GetNeg2loglikelihoodREML,
     GetNeg2loglikelihood_batch,
     cocoPredict_dense,
+    cocoSim_cond_dense,
     cocoSim_dense,
     cov_rns,
     cov_rns_classic,

@@ -49,6 +49,7 @@ SIGNATURES = {
     "cocons_neg2loglik_reml": (c_int, [c_vp, c_dp, c_int, c_dp, c_dp]),
     "cocons_predict_dense": (c_int, [c_vp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_dp, c_dp]),
     "cocons_sim_dense": (c_int, [c_vp, c_dp, c_dp, c_int, c_int, c_dp, c_dp]),
+    "cocons_sim_cond_dense": (c_int, [c_vp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_dp, c_int, c_dp, c_dp]),
     "cocons_chol_solve": (c_int, [c_int, c_dp, c_int, c_dp, c_dp, c_dp, c_dp]),
     "cocons_fit_profile": (c_int, [c_vp, c_dp, c_dp, c_int, c_dp]),
     "cocons_mfma_f64_probe": (c_int, [c_int, c_dp]),

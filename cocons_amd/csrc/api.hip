@@ -365,11 +365,25 @@ static void assemble_rhs(cocons_fit *f, const double *mean, bool use_trend, cons
 // Look-ahead: panel(k+2) runs on a second stream as soon as U1(k) is done, concurrently
 // with U2(k) on the main stream; U1(k+2) waits for it.  mt = total tile rows (matrix + rhs
 // rows).  Optional per-launch timing of U2 via events (ev_upd): appended (start, stop).
-static void panel_ops(cocons_fit *f, int k, int mt, hipStream_t s, bool no_lds = false)
+// the matrix a factorisation runs on: column tiles nt, row tiles mt (>= nt: rows under the square)
+struct FactorView {
+    double *A;
+    size_t lda;
+    int nt, mt;
+};
+
+static FactorView main_view(cocons_fit *f)
 {
-    const int nt = f->nt;
-    double *A = f->dA;
-    const size_t lda = f->lda;
+    FactorView v;
+    v.A = f->dA; v.lda = f->lda; v.nt = f->nt; v.mt = f->nt + f->rhs_cap / TILE;
+    return v;
+}
+
+static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s, bool no_lds = false)
+{
+    const int nt = v.nt, mt = v.mt;
+    double *A = v.A;
+    const size_t lda = v.lda;
     double *q0 = f->dinv, *q1 = f->dinv + 8 * 256;
     launch_potrf_tile(A, lda, k * TILE, q0, f->dinfo, s);
     launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, mt * TILE, q0, s, no_lds);
@@ -390,9 +404,10 @@ static bool lookahead_enabled()
     return v != 0;
 }
 
-static void timed_update(cocons_fit *f, int k, int kw, int t0, int t1, int mt, hipStream_t s,
+static void timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int t0, int t1, hipStream_t s,
                          std::vector<hipEvent_t> *ev_upd)
 {
+    const int mt = v.mt;
     if (ev_upd) {
         // algorithmic flops of this launch: lower triangle of the trailing block of order m
         // (real columns only) times K, plus the rhs rows:  K m (m+1) + 2 K r m
@@ -403,22 +418,22 @@ static void timed_update(cocons_fit *f, int k, int kw, int t0, int t1, int mt, h
         hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a, s);
-        launch_update(f->dA, f->lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s);
+        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s);
         hipEventRecord(b, s);
         ev_upd->push_back(a); ev_upd->push_back(b);
     } else {
-        launch_update(f->dA, f->lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s);
+        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s);
     }
 }
 
-static void factorize(cocons_fit *f, int mt, std::vector<hipEvent_t> *ev_upd)
+static void factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t> *ev_upd)
 {
-    const int nt = f->nt;
+    const int nt = v.nt, mt = v.mt;
     hipStream_t M = f->stream;
     if (!lookahead_enabled() || nt <= 4) {
         for (int k = 0; k < nt; k += 2) {
-            panel_ops(f, k, mt, M);
-            if (k + 2 < nt) timed_update(f, k, 2, k + 2, nt, mt, M, ev_upd);
+            panel_ops(f, v, k, M);
+            if (k + 2 < nt) timed_update(f, v, k, 2, k + 2, nt, M, ev_upd);
         }
         return;
     }
@@ -440,26 +455,26 @@ static void factorize(cocons_fit *f, int mt, std::vector<hipEvent_t> *ev_upd)
         tail = e ? atoi(e) : 20;
     }
     size_t ne = 0;
-    panel_ops(f, 0, mt, M);
+    panel_ops(f, v, 0, M);
     int k = 0;
     for (; k + 2 < nt && (nt - k) > tail; k += 2) {
         const int u1_end = (k + 4 < nt) ? k + 4 : nt;
         // U1: the next block's tile columns, then hand them to the panel stream
-        launch_update(f->dA, f->lda, k * TILE, 2 * TILE, k + 2, mt, k + 2, u1_end, true, M);
+        launch_update(v.A, v.lda, k * TILE, 2 * TILE, k + 2, mt, k + 2, u1_end, true, M);
         hipEvent_t e_u1 = ev[ne++];
         hipEventRecord(e_u1, M);
         hipStreamWaitEvent(P, e_u1, 0);
-        panel_ops(f, k + 2, mt, P, true);
+        panel_ops(f, v, k + 2, P, true);
         hipEvent_t e_p = ev[ne++];
         hipEventRecord(e_p, P);
         // U2: the rest of the trailing matrix, concurrent with panel(k+2)
-        if (k + 4 < nt) timed_update(f, k, 2, k + 4, nt, mt, M, ev_upd);
+        if (k + 4 < nt) timed_update(f, v, k, 2, k + 4, nt, M, ev_upd);
         hipStreamWaitEvent(M, e_p, 0);
     }
     // tail: panel(k) is factored; plain right-looking steps from here
     for (; k < nt; k += 2) {
-        if (k + 2 < nt) timed_update(f, k, 2, k + 2, nt, mt, M, ev_upd);
-        if (k + 2 < nt) panel_ops(f, k + 2, mt, M);
+        if (k + 2 < nt) timed_update(f, v, k, 2, k + 2, nt, M, ev_upd);
+        if (k + 2 < nt) panel_ops(f, v, k + 2, M);
     }
 }
 
@@ -476,13 +491,12 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
     const int nrhs = f->r + nxb;
     f->nrhs_cur = nrhs;
     if (int rc = fit_alloc_matrix(f, nrhs)) return rc;
-    const int mt = f->nt + f->rhs_cap / TILE;
     if (stage_events) hipEventRecord(f->ev[0], f->stream);
     if (int rc = reset_info(f)) return rc;
     assemble_sigma(f, theta, 0, 0, f->npad);
     assemble_rhs(f, mean, use_trend, xb, nxb, 0, f->npad);
     if (stage_events) hipEventRecord(f->ev[1], f->stream);
-    factorize(f, mt, ev_upd);
+    factorize(f, main_view(f), ev_upd);
     if (stage_events) hipEventRecord(f->ev[2], f->stream);
     launch_finalize(f->dA, f->lda, f->n, f->npad, nrhs, f->dout, f->stream);
     HIPCHK(hipMemcpyAsync(f->hout, f->dout, (size_t)(1 + nrhs * nrhs) * sizeof(double),
@@ -826,7 +840,6 @@ extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const do
         f->pred_cap = m;
     }
     if (int rc = fit_alloc_matrix(f, m + 1)) return rc;
-    const int mt = f->nt + f->rhs_cap / TILE;
     hipStream_t s = f->stream;
     HIPCHK(hipMemcpyAsync(f->dXp, X_pred, (size_t)m * p * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(f->dlocsp, locs_pred, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
@@ -865,7 +878,7 @@ extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const do
         if (ms0.smooth_kind != ms.smooth_kind) launch_loc_params(lo, s);
         launch_pair_rect(MODE_GEOM, pa, s);
     }
-    factorize(f, mt, nullptr);
+    factorize(f, main_view(f), nullptr);
     launch_row_reduce(f->dA, f->lda, n, f->npad, f->npad + 1, m, f->dstoch, f->dquad, s);
     HIPCHK(hipMemcpyAsync(stochastic, f->dstoch, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(quadform, f->dquad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -889,7 +902,6 @@ extern "C" int cocons_sim_dense(cocons_fit *f, const double *theta, const double
     hipStream_t s = f->stream;
     do {
         if ((rc = fit_alloc_matrix(f, 1))) break;
-        const int mt = f->nt + f->rhs_cap / TILE;
         hipError_t e;
 #define CKS(expr) if ((e = (expr)) != hipSuccess) { rc = fail(-100 - (int)e, "cocons_sim_dense: %s", hipGetErrorString(e)); break; }
         CKS(hipMalloc(&dE, (size_t)n * nsim * sizeof(double)));
@@ -913,7 +925,7 @@ extern "C" int cocons_sim_dense(cocons_fit *f, const double *theta, const double
             ra.col0 = 0; ra.ncols_out = f->npad;
             launch_rhs_rows(ra, s);
         }
-        factorize(f, mt, nullptr);
+        factorize(f, main_view(f), nullptr);
         launch_trmm_lower(f->dA, f->lda, n, dE, n, nsim, dtr, dY, n, s);
         CKS(hipMemcpyAsync(out, dY, (size_t)n * nsim * sizeof(double), hipMemcpyDeviceToHost, s));
         CKS(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -923,6 +935,120 @@ extern "C" int cocons_sim_dense(cocons_fit *f, const double *theta, const double
         rc = info_status(f);
     } while (0);
     hipFree(dE); hipFree(dY); hipFree(dtr);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// conditional simulation core: replaces R/sim.R:84-127
+//   covmat, covmat_pred, covmat_unobs; L <- chol(covmat_unobs - covmat_pred solve(covmat) t(covmat_pred));
+//   t(sweep(t(iiderrors) %*% L, 2, systematic + stochastic, "+"))
+// One Cholesky of the JOINT covariance of (observed, new) locations: its lower-right block is
+// the factor of the Schur complement, and the kriging mean falls out of the border row, so the
+// LU solve, the m x n x m product and the second chol of the reference are all this one pass.
+extern "C" int cocons_sim_cond_dense(cocons_fit *f, const double *theta, const double *mean, int z_col,
+                                     int m, const double *locs_pred, const double *X_pred,
+                                     const double *locs_unobs, int nsim, const double *iiderrors, double *out)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!theta || !mean || m <= 0 || !locs_pred || !X_pred || !locs_unobs || nsim <= 0 || !iiderrors || !out ||
+        z_col < 0 || z_col >= f->r)
+        return fail(-1, "cocons_sim_cond_dense: bad argument");
+    const int n = f->n, p = f->p, npad = f->npad;
+    const int mpad = round_up(m, TILE), N = npad + mpad;
+    const size_t ldj = (size_t)N + TILE;
+    double *dJ = nullptr, *dXp = nullptr, *dlp = nullptr, *dlu = nullptr, *dlocp = nullptr, *dlocu = nullptr;
+    double *dE = nullptr, *dY = nullptr, *dmu = nullptr, *dst = nullptr, *dq = nullptr;
+    hipStream_t s = f->stream;
+    int rc = 0;
+    do {
+        hipError_t e;
+#define CKS(expr) if ((e = (expr)) != hipSuccess) { rc = fail(-100 - (int)e, "cocons_sim_cond_dense: %s", hipGetErrorString(e)); break; }
+        CKS(hipMalloc(&dJ, ldj * (size_t)N * sizeof(double)));
+        CKS(hipMalloc(&dXp, (size_t)m * p * sizeof(double)));
+        CKS(hipMalloc(&dlp, (size_t)m * 2 * sizeof(double)));
+        CKS(hipMalloc(&dlu, (size_t)m * 2 * sizeof(double)));
+        CKS(hipMalloc(&dlocp, (size_t)LOCP_FIELDS * mpad * sizeof(double)));
+        CKS(hipMalloc(&dlocu, (size_t)LOCP_FIELDS * mpad * sizeof(double)));
+        CKS(hipMalloc(&dE, (size_t)m * nsim * sizeof(double)));
+        CKS(hipMalloc(&dY, (size_t)m * nsim * sizeof(double)));
+        CKS(hipMalloc(&dmu, (size_t)m * sizeof(double)));
+        CKS(hipMalloc(&dst, (size_t)m * sizeof(double)));
+        CKS(hipMalloc(&dq, (size_t)m * sizeof(double)));
+        CKS(hipMemcpyAsync(dXp, X_pred, (size_t)m * p * sizeof(double), hipMemcpyHostToDevice, s));
+        CKS(hipMemcpyAsync(dlp, locs_pred, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+        CKS(hipMemcpyAsync(dlu, locs_unobs, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+        CKS(hipMemcpyAsync(dE, iiderrors, (size_t)m * nsim * sizeof(double), hipMemcpyHostToDevice, s));
+        if ((rc = reset_info(f))) break;
+        f->nrhs_cur = 1;
+        ThetaVecs tv;
+        make_theta_vecs(theta, p, tv);
+        const ModeSel ms0 = select_mode(theta, p, f->smooth_limits, 0);   // cov_rns semantics
+        const ModeSel msp = select_mode(theta, p, f->smooth_limits, 2);   // cov_rns_pred semantics
+        LocArgs lo;   // observed side
+        lo.n = n; lo.p = p; lo.X = f->dX; lo.ldx = n; lo.locs = f->dlocs; lo.ldl = n;
+        lo.out = f->dloc; lo.stride = npad; lo.smooth_kind = ms0.smooth_kind;
+        lo.smooth_min = f->smooth_limits[0]; lo.smooth_max = f->smooth_limits[1]; lo.th = tv;
+        LocArgs lu = lo;   // new locations with the coordinates handed to cov_rns (covmat_unobs)
+        lu.n = m; lu.X = dXp; lu.ldx = m; lu.locs = dlu; lu.ldl = m; lu.out = dlocu; lu.stride = mpad;
+        LocArgs lp = lu;   // new locations with newlocs (cov_rns_pred), always logistic + sqrt
+        lp.locs = dlp; lp.out = dlocp; lp.smooth_kind = msp.smooth_kind;
+        launch_loc_params(lo, s);
+        launch_loc_params(lu, s);
+        launch_loc_params(lp, s);
+        PairArgs pa;
+        // Sigma_oo  (rows/cols [0, npad))
+        memset(&pa, 0, sizeof pa);
+        pa.n = n; pa.m = n; pa.rows = f->dloc; pa.cols = f->dloc; pa.stride = npad; pa.stride_rows = npad;
+        pa.out = dJ; pa.ld = ldj; pa.nrows_out = npad; pa.ncols_out = npad; pa.gr = ms0.gr; pa.nu_fixed = ms0.nu_fixed;
+        launch_pair_sym(ms0.mode, false, pa, s);
+        // Sigma_uu  (rows/cols [npad, N))
+        memset(&pa, 0, sizeof pa);
+        pa.n = m; pa.m = m; pa.rows = dlocu; pa.cols = dlocu; pa.stride = mpad; pa.stride_rows = mpad;
+        pa.out = dJ + (size_t)npad + (size_t)npad * ldj; pa.ld = ldj; pa.nrows_out = mpad; pa.ncols_out = mpad;
+        pa.gr = ms0.gr; pa.nu_fixed = ms0.nu_fixed;
+        launch_pair_sym(ms0.mode, false, pa, s);
+        // cross block (rows [npad, N) x cols [0, npad)): observed side needs the pred-branch smoothness
+        if (ms0.smooth_kind != msp.smooth_kind) { lo.smooth_kind = msp.smooth_kind; launch_loc_params(lo, s); }
+        memset(&pa, 0, sizeof pa);
+        pa.n = n; pa.m = m; pa.rows = dlocp; pa.stride_rows = mpad; pa.cols = f->dloc; pa.stride = npad;
+        pa.out = dJ + npad; pa.ld = ldj; pa.nrows_out = mpad; pa.ncols_out = npad; pa.gr = msp.gr;
+        launch_pair_rect(MODE_GEOM, pa, s);
+        {   // border row N: residual of realization z_col over the observed columns, zero elsewhere
+            RhsArgs ra;
+            memset(&ra, 0, sizeof ra);
+            ra.n = n; ra.p = p; ra.X = f->dX; ra.ldx = n; ra.use_trend = 1;
+            for (int i = 0; i < p; ++i) ra.mean[i] = mean[i];
+            ra.src = f->dz + (size_t)z_col * n; ra.lds = n;
+            ra.out = dJ; ra.ld = ldj; ra.row0 = N; ra.nrows = 1; ra.nrows_zero = TILE - 1;
+            ra.col0 = 0; ra.ncols_out = N;
+            launch_rhs_rows(ra, s);
+        }
+        FactorView v;
+        v.A = dJ; v.lda = ldj; v.nt = N / TILE; v.mt = N / TILE + 1;
+        factorize(f, v, nullptr);
+        // kriging mean: stochastic_i = sum_{c<n} J(npad+i, c) J(N, c);  tmp_mu = X_pred mean + stochastic
+        launch_row_reduce(dJ, ldj, n, N, npad, m, dst, dq, s);
+        std::vector<double> mu(m), stv(m);
+        CKS(hipMemcpyAsync(stv.data(), dst, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+        CKS(hipStreamSynchronize(s));
+        for (int i = 0; i < m; ++i) {
+            double sys = 0;
+            for (int j = 0; j < p; ++j) sys += X_pred[(size_t)i + (size_t)j * m] * mean[j];
+            mu[i] = sys + stv[i];
+        }
+        CKS(hipMemcpyAsync(dmu, mu.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, s));
+        // fields = L_S E + tmp_mu with L_S = lower-right block of the joint factor
+        launch_trmm_lower(dJ + (size_t)npad + (size_t)npad * ldj, ldj, m, dE, m, nsim, dmu, dY, m, s);
+        CKS(hipMemcpyAsync(out, dY, (size_t)m * nsim * sizeof(double), hipMemcpyDeviceToHost, s));
+        CKS(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+        CKS(hipGetLastError());
+        CKS(hipStreamSynchronize(s));
+#undef CKS
+        rc = info_status(f);
+        if (rc > n) rc = n;    // a failure inside the Schur block is still "Cholesky error"
+    } while (0);
+    hipFree(dJ); hipFree(dXp); hipFree(dlp); hipFree(dlu); hipFree(dlocp); hipFree(dlocu);
+    hipFree(dE); hipFree(dY); hipFree(dmu); hipFree(dst); hipFree(dq);
     return rc;
 }
 
@@ -940,7 +1066,6 @@ extern "C" int cocons_chol_solve(int n, const double *Ain, int nrhs, const doubl
     do {
         if ((rc = fit_alloc_matrix(f, nrhs > 0 ? nrhs : 1))) break;
         hipStream_t s = f->stream;
-        const int mt = f->nt + f->rhs_cap / TILE;
         // identity everywhere in the padded square, zero rhs rows, then copy A and rhs^T in
         std::vector<double> hostA(f->lda * (size_t)f->npad, 0.0);
         for (int c = 0; c < f->npad; ++c) hostA[(size_t)c + (size_t)c * f->lda] = 1.0;
@@ -951,7 +1076,7 @@ extern "C" int cocons_chol_solve(int n, const double *Ain, int nrhs, const doubl
         hipError_t e = hipMemcpy(f->dA, hostA.data(), hostA.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) { rc = fail(-100, "cocons_chol_solve: %s", hipGetErrorString(e)); break; }
         if ((rc = reset_info(f))) break;
-        factorize(f, mt, nullptr);
+        factorize(f, main_view(f), nullptr);
         launch_finalize(f->dA, f->lda, n, f->npad, 0, f->dout, s);
         e = hipStreamSynchronize(s);     // the fit's stream is non-blocking: order the copies below
         if (e != hipSuccess) { rc = fail(-100, "cocons_chol_solve: %s", hipGetErrorString(e)); break; }

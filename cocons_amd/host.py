@@ -261,6 +261,17 @@ class CoconsFit:
                    "cocons_sim_dense")
         return out
 
+    def sim_cond_core(self, theta_list, locs_pred, x_covariates_pred, locs_unobs, iiderrors, z_col=0):
+        lp, Xp, lu = _f(locs_pred), _f(x_covariates_pred), _f(np.asarray(locs_unobs, dtype=np.float64)[:, :2])
+        m = Xp.shape[0]
+        E = _f(np.asarray(iiderrors, dtype=np.float64).reshape(m, -1))
+        T = theta_table(theta_list)
+        mean = np.ascontiguousarray(np.asarray(theta_list["mean"], dtype=np.float64))
+        out = np.empty(E.shape, order="F")
+        _lib.check(self._L.cocons_sim_cond_dense(self._h, _p(T), _p(mean), int(z_col), m, _p(lp), _p(Xp), _p(lu),
+                                                 E.shape[1], _p(E), _p(out)), "cocons_sim_cond_dense")
+        return out
+
     def profile_stages(self, theta_list, reps=3):
         """Stage timings (ms) from HIP events on the fit's stream; see cocons_fit_profile."""
         T = theta_table(theta_list)
@@ -421,6 +432,24 @@ def cocoSim_dense(theta_list, locs, X_std, smooth_limits, iiderrors, type="class
             return f.sim_core(theta_list, E.reshape(n, -1), classic=(type == "classic"))
         except CholeskyError:
             raise RuntimeError("Cholesky error")          # base::chol's error propagates in the reference
+    finally:
+        if own:
+            f.close()
+
+
+def cocoSim_cond_dense(theta_list, locs, newlocs, newdataset, X_std, X_pred_std, smooth_limits, z, iiderrors,
+                       fit=None):
+    """Conditional branch of cocoSim (sim.type = "cond") for a dense object, R/sim.R:69-127, from the
+    point where the scaled design matrices and the theta list exist.  `newdataset` supplies the
+    coordinates of covmat_unobs exactly as the reference passes it (`locs = as.matrix(newdataset)`,
+    i.e. its first two columns, :96-99).  Returns m x nsim."""
+    f, own = _with_fit(fit, locs, X_std, z, smooth_limits)
+    try:
+        try:
+            return f.sim_cond_core(theta_list, newlocs, X_pred_std, np.asarray(newdataset, dtype=np.float64),
+                                   iiderrors)
+        except CholeskyError:
+            raise RuntimeError("Cholesky error")
     finally:
         if own:
             f.close()

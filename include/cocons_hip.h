@@ -122,6 +122,15 @@ int cocons_predict_dense(cocons_fit *fit, const double *theta, const double *mea
 int cocons_sim_dense(cocons_fit *fit, const double *theta, const double *mean, int classic,
                      int nsim, const double *iiderrors, double *out);
 
+/* Conditional simulation core: replaces R/sim.R:84-127 (cov_rns, cov_rns_pred, cov_rns on the new
+ * locations, solve, chol of the Schur complement, cocoPredict(type = "mean")) by ONE Cholesky of the
+ * joint covariance of (observed, new) locations.  locs_pred = newlocs (cross-covariance),
+ * locs_unobs = the coordinates the reference hands to cov_rns for covmat_unobs (the first two
+ * columns of newdataset, :96-99); iiderrors / out are m x nsim column-major.               */
+int cocons_sim_cond_dense(cocons_fit *fit, const double *theta, const double *mean, int z_col,
+                          int m, const double *locs_pred, const double *X_pred,
+                          const double *locs_unobs, int nsim, const double *iiderrors, double *out);
+
 /* Dense Cholesky of a caller-supplied SPD matrix (host, n x n column-major, lower
  * triangle read) with nrhs right-hand sides: replaces base::chol + forwardsolve
  * (R/neg2loglikelihood.R:200,214) for callers that already hold Sigma.

@@ -329,6 +329,22 @@ def cocoSim_dense(theta_list, locs, X_std, smooth_limits, iiderrors, type="class
     return (E.T @ R + mu[None, :]).T
 
 
+def cocoSim_cond_dense(theta_list, locs, newlocs, newdataset, X_std, X_pred_std, smooth_limits, z, iiderrors):
+    """Conditional branch of cocoSim (dense), R/sim.R:84-127, literal."""
+    covmat = cov_rns(theta_list, locs, X_std, smooth_limits)
+    covmat_pred = cov_rns_pred(theta_list, locs, newlocs, X_std, X_pred_std, smooth_limits)
+    covmat_unobs = cov_rns(theta_list, np.asarray(newdataset, float)[:, :2], X_pred_std, smooth_limits)
+    S = covmat_unobs - covmat_pred @ np.linalg.solve(covmat, covmat_pred.T)
+    S = (S + S.T) / 2
+    L, info = _chol_upper(np.asfortranarray(S))
+    if L is None:
+        raise RuntimeError("Cholesky error")
+    step_one = cocoPredict_dense(theta_list, locs, newlocs, X_std, X_pred_std, smooth_limits, z, type="mean")
+    tmp_mu = step_one["systematic"] + step_one["stochastic"]
+    E = np.asarray(iiderrors, float).reshape(covmat_unobs.shape[0], -1)
+    return (E.T @ L + tmp_mu[None, :]).T
+
+
 def chol_ld(A, rhs):
     """long-double Cholesky truth: returns (info, sum(log(diag)), quad[nrhs], Y)."""
     A = _f(A)

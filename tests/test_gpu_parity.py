@@ -363,3 +363,23 @@ def test_cocoSim_marginal_vs_cpu(oracle, type_):
     want = oracle.cocoSim_dense(th, locs, X, wl.SMOOTH_LIMITS, E, type=type_)
     assert got.shape == (n, 11)
     assert np.max(np.abs(got - want)) < 1e-10 * np.max(np.abs(want))
+
+
+def test_cocoSim_conditional_vs_cpu(oracle):
+    """cocoSim, conditional branch (R/sim.R:69-127): one joint Cholesky against the literal
+    solve + Schur complement + chol + cocoPredict(type='mean') of the CPU restatement."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n, m = 300, 170
+    locs, X, th, rng = _problem(n, seed=41)
+    th["mean"] = np.array([0.3, -0.2, 0.1])
+    lp = rng.uniform(0, 1, size=(m, 2))
+    sc = wl.design_from_locs(locs)
+    Xp = wl.design_from_locs(lp, sc["mean.vector"], sc["sd.vector"])["std.covs"]
+    newdataset = np.column_stack([lp, rng.standard_normal((m, 2))])     # x, y, covariates...
+    z = rng.standard_normal(n)
+    E = rng.standard_normal((m, 5))
+    got = ca.cocoSim_cond_dense(th, locs, lp, newdataset, X, Xp, wl.SMOOTH_LIMITS, z, E)
+    want = oracle.cocoSim_cond_dense(th, locs, lp, newdataset, X, Xp, wl.SMOOTH_LIMITS, z, E)
+    assert got.shape == (m, 5)
+    assert np.max(np.abs(got - want)) < 1e-8 * np.max(np.abs(want))
