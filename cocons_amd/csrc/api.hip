@@ -126,6 +126,7 @@ struct cocons_fit {
     pid_t pid;
     int npad, nt;            // padded order, tiles of 128
     int rhs_cap;             // rows reserved under the matrix (multiple of 128)
+    int rhs_act;             // rows under the matrix the CURRENT operation uses (multiple of 128, <= rhs_cap)
     size_t lda;
     hipStream_t stream;
     bool own_stream;
@@ -169,6 +170,7 @@ static int fit_check(cocons_fit *f)
 static int fit_alloc_matrix(cocons_fit *f, int rhs_rows)
 {
     int cap = round_up(rhs_rows > 0 ? rhs_rows : 1, TILE);
+    f->rhs_act = cap;        // a buffer grown by an earlier predict call must not slow later evaluations
     if (f->dA && cap <= f->rhs_cap) return 0;
     if (f->dA) { HIPCHK(hipFree(f->dA)); f->dA = nullptr; }
     f->rhs_cap = cap;
@@ -346,14 +348,14 @@ static void assemble_rhs(cocons_fit *f, const double *mean, bool use_trend, cons
     ra.src = f->dz; ra.lds = f->n;
     ra.out = f->dA; ra.ld = f->lda;
     ra.row0 = f->npad; ra.nrows = f->r;
-    ra.nrows_zero = (nxb > 0) ? 0 : f->rhs_cap - f->r;
+    ra.nrows_zero = (nxb > 0) ? 0 : f->rhs_act - f->r;
     ra.col0 = col0; ra.ncols_out = col1;
     launch_rhs_rows(ra, f->stream);
     if (nxb > 0) {
         ra.use_trend = 0;
         ra.src = xb; ra.lds = f->n;
         ra.row0 = f->npad + f->r; ra.nrows = nxb;
-        ra.nrows_zero = f->rhs_cap - f->r - nxb;
+        ra.nrows_zero = f->rhs_act - f->r - nxb;
         launch_rhs_rows(ra, f->stream);
     }
 }
@@ -375,7 +377,7 @@ struct FactorView {
 static FactorView main_view(cocons_fit *f)
 {
     FactorView v;
-    v.A = f->dA; v.lda = f->lda; v.nt = f->nt; v.mt = f->nt + f->rhs_cap / TILE;
+    v.A = f->dA; v.lda = f->lda; v.nt = f->nt; v.mt = f->nt + f->rhs_act / TILE;
     return v;
 }
 
@@ -853,7 +855,7 @@ extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const do
         for (int i = 0; i < p; ++i) ra.mean[i] = mean[i];
         ra.src = f->dz + (size_t)z_col * n; ra.lds = n;
         ra.out = f->dA; ra.ld = f->lda; ra.row0 = f->npad; ra.nrows = 1;
-        ra.nrows_zero = f->rhs_cap - 1;      // also clears padding rows and columns >= n
+        ra.nrows_zero = f->rhs_act - 1;      // also clears padding rows and columns >= n
         ra.col0 = 0; ra.ncols_out = f->npad;
         launch_rhs_rows(ra, s);
         ThetaVecs tv;
@@ -921,7 +923,7 @@ extern "C" int cocons_sim_dense(cocons_fit *f, const double *theta, const double
             RhsArgs ra;
             memset(&ra, 0, sizeof ra);
             ra.n = n; ra.p = p; ra.X = f->dX; ra.ldx = n; ra.src = f->dX; ra.lds = n;
-            ra.out = f->dA; ra.ld = f->lda; ra.row0 = f->npad; ra.nrows = 0; ra.nrows_zero = f->rhs_cap;
+            ra.out = f->dA; ra.ld = f->lda; ra.row0 = f->npad; ra.nrows = 0; ra.nrows_zero = f->rhs_act;
             ra.col0 = 0; ra.ncols_out = f->npad;
             launch_rhs_rows(ra, s);
         }
@@ -1176,7 +1178,7 @@ extern "C" int cocons_shard_panel_factor(cocons_fit *f, int k)
     if (int rc = fit_check(f)) return rc;
     const int np = cocons_shard_num_panels(f);
     if (k < 0 || k >= np) return fail(-1, "cocons_shard_panel_factor: bad panel");
-    const int mt = f->nt + f->rhs_cap / TILE;
+    const int mt = f->nt + f->rhs_act / TILE;
     const int t0 = k * PT;
     hipStream_t s = f->stream;
     double *A = f->dA;
@@ -1207,7 +1209,7 @@ static int shard_apply_range(cocons_fit *f, int k, int j0, int j1)
     if (j1 < 0 || j1 > np) j1 = np;
     if (j0 < k + 1) j0 = k + 1;
     if (j0 >= j1) return 0;
-    const int mt = f->nt + f->rhs_cap / TILE;
+    const int mt = f->nt + f->rhs_act / TILE;
     const int t0 = k * PT;
     const int w = (f->nt - t0) < PT ? (f->nt - t0) : PT;
     int c0 = j0 * PT, c1 = j1 * PT;               // tile-column range

@@ -383,3 +383,20 @@ def test_cocoSim_conditional_vs_cpu(oracle):
     want = oracle.cocoSim_cond_dense(th, locs, lp, newdataset, X, Xp, wl.SMOOTH_LIMITS, z, E)
     assert got.shape == (m, 5)
     assert np.max(np.abs(got - want)) < 1e-8 * np.max(np.abs(want))
+
+
+def test_evaluation_after_predict_uses_small_border(oracle):
+    """a predict call grows the buffer under the matrix; later evaluations on the same handle must
+    still give the same value (and only carry their own right-hand-side rows)."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n, m = 260, 700
+    locs, X, th, rng = _problem(n, seed=51)
+    z = rng.standard_normal(n)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    v0, p0 = fit.neg2loglik_core(th)
+    lp = rng.uniform(0, 1, size=(m, 2))
+    Xp = wl.design_from_locs(lp)["std.covs"]
+    fit.predict_core(th, lp, Xp)
+    v1, p1 = fit.neg2loglik_core(th)
+    assert v1 == v0 and np.array_equal(p0, p1)
