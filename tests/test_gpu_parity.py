@@ -333,11 +333,15 @@ def test_handle_refuses_use_after_fork():
     fit.neg2loglik_core(th)
 
     def child(q):
+        import os
         try:
             fit.neg2loglik_core(th)
             q.put("ran")
         except Exception as e:            # noqa: BLE001
             q.put(str(e))
+        q.close()
+        q.join_thread()
+        os._exit(0)                       # no atexit / HIP runtime teardown in the forked child
 
     ctx = mp.get_context("fork")
     q = ctx.Queue()
@@ -400,3 +404,36 @@ def test_evaluation_after_predict_uses_small_border(oracle):
     fit.predict_core(th, lp, Xp)
     v1, p1 = fit.neg2loglik_core(th)
     assert v1 == v0 and np.array_equal(p0, p1)
+
+
+def test_fuzz_random_parameters(oracle):
+    """30 random parameter sets (ranges 0.03..0.6, nuggets 1e-4..0.1, smoothness limits varied,
+    strong covariate effects) at n = 400: every GPU value within the north-star tolerance of the CPU
+    path, or both sides agree that the Cholesky fails."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    rng = np.random.default_rng(2025)
+    n = 400
+    locs = rng.uniform(0, 1, size=(n, 2))
+    X = wl.design_from_locs(locs)["std.covs"]
+    z = rng.standard_normal(n)
+    pp = wl.par_pos_full()
+    worst = 0.0
+    nfail = 0
+    for it in range(30):
+        lim = [(0.5, 2.5), (0.3, 1.2), (1.0, 3.0)][it % 3]
+        th = wl.theta_full(scale0=np.log(rng.uniform(0.03, 0.6)))
+        for k in ("std.dev", "scale", "aniso", "tilt", "smooth"):
+            th[k] = th[k] + np.r_[0.0, rng.normal(0, 0.4, size=2)]
+        th["nugget"] = np.array([np.log(10 ** rng.uniform(-4, -1)), 0.0, 0.0])
+        tv = wl.theta_vector_from_lists(th, pp)
+        fit = ca.CoconsFit(locs, X, z, lim)
+        got = ca.GetNeg2loglikelihood(tv, pp, locs, X, lim, z, n, (0.1, 0.1, 0.1), fit=fit)
+        want = oracle.GetNeg2loglikelihood(tv, pp, locs, X, lim, z, n, (0.1, 0.1, 0.1))
+        if want == 1e6 or got == 1e6:
+            assert got == want, (it, got, want)
+            nfail += 1
+            continue
+        worst = max(worst, abs(got - want) / abs(want))
+    assert worst <= N2LL_RTOL, worst
+    assert nfail < 10
