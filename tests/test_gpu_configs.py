@@ -208,7 +208,7 @@ def _shard_worker(rank, world, port, g, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,g", [(2, 40), (3, 50)])
+@pytest.mark.parametrize("world,g", [(2, 40), (3, 50), (4, 15)])
 def test_sharded_hip_engine_over_gloo(tmp_path, world, g):
     """The production sharded path (HIP kernels + cocons_amd.shard schedule) with `world`
     ranks sharing this box's single GPU and gloo carrying the panel broadcasts (RCCL refuses

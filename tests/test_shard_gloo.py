@@ -45,7 +45,7 @@ def _worker(rank, world, port, n, seed, out_dir, lookahead=True):
 
 
 @pytest.mark.parametrize("world,n,lookahead", [(2, 700, True), (3, 900, True), (2, 200, True), (2, 700, False),
-                                                  (4, 1300, True)])
+                                                  (4, 1300, True), (4, 200, True), (3, 100, False)])
 def test_sharded_schedule_over_gloo(oracle, tmp_path, world, n, lookahead):
     import torch.multiprocessing as mp
     from cocons_amd import workloads as wl
