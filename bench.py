@@ -288,7 +288,7 @@ def main():
             flops, launches = st["update_flops"], st["update_launches"]
             if st["update_launches"] > 0 and st["update_sum_ms"] > 0:
                 achieved = flops / (st["update_sum_ms"] * 1e-3) / 1e12
-                roofline = {"bound": "mfma", "kernel": "update_kernel (trailing SYRK/GEMM, v_mfma_f64_16x16x4_f64)",
+                roofline = {"bound": "mfma", "kernel": "cocons::update_kernel<64, 8, 0> (trailing SYRK/GEMM, v_mfma_f64_16x16x4_f64)",
                             "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
                             "flops_per_launch": flops / max(launches, 1),
