@@ -1285,3 +1285,17 @@ extern "C" int cocons_vfma_f64_probe(int blocks_per_cu, double *tflops)
     HIPCHK(hipFree(d));
     return 0;
 }
+
+// diagnostic (not part of the public header): MFMA and FMA probes concurrently on two streams
+extern "C" int cocons_corun_probe(int bpc_mfma, int bpc_vfma, int iters_mfma, int iters_vfma, double *out4)
+{
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, 0));
+    int bm = prop.multiProcessorCount * bpc_mfma, bv = prop.multiProcessorCount * bpc_vfma;
+    double *d = nullptr;
+    HIPCHK(hipMalloc(&d, (size_t)(bm + bv) * 256 * sizeof(double)));
+    run_corun_probe(bm, bv, iters_mfma, iters_vfma, d, out4);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipFree(d));
+    return 0;
+}

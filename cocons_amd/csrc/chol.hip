@@ -801,6 +801,36 @@ double run_vfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf)
     return flops / (ms * 1e-3) / 1e12;
 }
 
+// both probes at once on two streams: do the matrix and the vector fp64 pipes run concurrently?
+// out[0], out[1] = TFLOP/s of the MFMA / FMA kernel while the other one is running
+void run_corun_probe(int blocks_mfma, int blocks_vfma, int iters_mfma, int iters_vfma, double *dbuf, double *out)
+{
+    hipStream_t s0, s1;
+    hipStreamCreateWithFlags(&s0, hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
+    hipEvent_t a0, a1, b0, b1;
+    hipEventCreate(&a0); hipEventCreate(&a1); hipEventCreate(&b0); hipEventCreate(&b1);
+    double *d0 = dbuf, *d1 = dbuf + (size_t)blocks_mfma * 256;
+    hipLaunchKernelGGL(mfma_f64_probe_kernel, dim3(blocks_mfma), dim3(256), 0, s0, d0, 100, 1.0);
+    hipLaunchKernelGGL(vfma_f64_probe_kernel, dim3(blocks_vfma), dim3(256), 0, s1, d1, 100, 1.0);
+    hipStreamSynchronize(s0); hipStreamSynchronize(s1);
+    hipEventRecord(a0, s0);
+    hipLaunchKernelGGL(mfma_f64_probe_kernel, dim3(blocks_mfma), dim3(256), 0, s0, d0, iters_mfma, 1.0);
+    hipEventRecord(a1, s0);
+    hipEventRecord(b0, s1);
+    hipLaunchKernelGGL(vfma_f64_probe_kernel, dim3(blocks_vfma), dim3(256), 0, s1, d1, iters_vfma, 1.0);
+    hipEventRecord(b1, s1);
+    hipStreamSynchronize(s0); hipStreamSynchronize(s1);
+    float ma = 0, mb = 0;
+    hipEventElapsedTime(&ma, a0, a1);
+    hipEventElapsedTime(&mb, b0, b1);
+    out[0] = (double)blocks_mfma * 4 * (double)iters_mfma * 4 * 2048.0 / (ma * 1e-3) / 1e12;
+    out[1] = (double)blocks_vfma * 256.0 * (double)iters_vfma * 16.0 * 2.0 / (mb * 1e-3) / 1e12;
+    out[2] = ma; out[3] = mb;
+    hipEventDestroy(a0); hipEventDestroy(a1); hipEventDestroy(b0); hipEventDestroy(b1);
+    hipStreamDestroy(s0); hipStreamDestroy(s1);
+}
+
 double run_mfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf)
 {
     hipEvent_t e0, e1;
