@@ -15,6 +15,7 @@
 //
 // Compile with -ffp-contract=off (see matern_device.hpp).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "kernels.h"
 #include "matern_device.hpp"
 
@@ -100,28 +101,41 @@ pair_sym_kernel(PairArgs a)
     }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int r = bi * TS + lane;
     const int n = a.n;
     const bool offdiag = (bi != bj);           // wave-uniform: then r > c for every entry
+    // Lane mapping inside the wave's 64 x 16 share of the tile.  Plain: lane = row, one column per
+    // step (column side wave-uniform -> scalar loads).  Blocked (Bessel modes): each step covers an
+    // 8 x 8 patch of pairs, so that for spatially ordered inputs the 64 lanes see similar distances
+    // and the data-dependent K_nu iteration counts diverge less (the step costs its slowest lane).
+    const bool blocked = a.blocked != 0;
     for (int cc = 0; cc < TS / 4; ++cc) {
-        int cl = wave * (TS / 4) + cc;
-        int c = bj * TS + cl;
-        if (c >= a.ncols_out) break;
-        double v;
-        if (r >= n || c >= n) {
-            v = (r == c) ? 1.0 : 0.0;
-        } else if (r == c) {
-            v = a.rows[r + 11 * a.stride];
+        int rl, cl;
+        if (blocked) {
+            rl = 8 * (cc & 7) + (lane & 7);
+            cl = wave * (TS / 4) + 8 * (cc >> 3) + (lane >> 3);
         } else {
-            int rr = r;
-            asm volatile("" : "+v"(rr));         // keep the row-side loads inside the loop
-            if (offdiag || r > c)                // ii = c (wave-uniform -> scalar loads), jj = r
-                v = pair_value_idx<MODE>(a.rows, a.stride, c, a.rows, a.stride, rr, a.gr, a.nu_fixed, false);
-            else
-                v = pair_value_idx<MODE>(a.rows, a.stride, rr, a.rows, a.stride, c, a.gr, a.nu_fixed, false);
+            rl = lane;
+            cl = wave * (TS / 4) + cc;
         }
-        if (r < a.nrows_out) a.out[(size_t)r + (size_t)c * a.ld] = v;
-        if (MIRROR) tile[cl * (TS + 1) + lane] = v;
+        const int r = bi * TS + rl;
+        const int c = bj * TS + cl;
+        double v = 0.0;
+        if (c < a.ncols_out) {
+            if (r >= n || c >= n) {
+                v = (r == c) ? 1.0 : 0.0;
+            } else if (r == c) {
+                v = a.rows[r + 11 * a.stride];
+            } else {
+                int rr = r;
+                asm volatile("" : "+v"(rr));         // keep the row-side loads inside the loop
+                if (offdiag || r > c)                // ii = c, jj = r
+                    v = pair_value_idx<MODE>(a.rows, a.stride, c, a.rows, a.stride, rr, a.gr, a.nu_fixed, false);
+                else
+                    v = pair_value_idx<MODE>(a.rows, a.stride, rr, a.rows, a.stride, c, a.gr, a.nu_fixed, false);
+            }
+            if (r < a.nrows_out) a.out[(size_t)r + (size_t)c * a.ld] = v;
+        }
+        if (MIRROR) tile[cl * (TS + 1) + rl] = v;
     }
     if (MIRROR && bi != bj) {
         __syncthreads();
@@ -145,11 +159,20 @@ pair_rect_kernel(PairArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * TS + lane;          // prediction location
     const int m = a.m;
+    const bool blocked = a.blocked != 0;           // 8 x 8 pair patches, see pair_sym_kernel
     for (int cc = 0; cc < TS / 4; ++cc) {
-        int c = blockIdx.y * TS + wave * (TS / 4) + cc;
-        if (c >= a.ncols_out) break;
+        int rl, cl;
+        if (blocked) {
+            rl = 8 * (cc & 7) + (lane & 7);
+            cl = wave * (TS / 4) + 8 * (cc >> 3) + (lane >> 3);
+        } else {
+            rl = lane;
+            cl = wave * (TS / 4) + cc;
+        }
+        const int r = blockIdx.x * TS + rl;        // prediction location
+        const int c = blockIdx.y * TS + cl;
+        if (c >= a.ncols_out) continue;
         double v = 0.0;
         if (r < m && c < a.n) {
             int rr = r;
@@ -209,6 +232,11 @@ void launch_pair_sym(int mode, bool mirror, const PairArgs &a, hipStream_t s)
     int tj1 = (a.ncols_out + TS - 1) / TS;
     if (tj1 <= a.bj0) return;
     PairArgs b = a;
+    {
+        static int blk = -1;
+        if (blk < 0) { const char *e = getenv("COCONS_PAIR_BLOCKED"); blk = e ? atoi(e) : 1; }
+        b.blocked = (blk && (mode == MODE_GEOM || mode == MODE_MEAN)) ? 1 : 0;
+    }
     const long long H = T - a.bj0, W = tj1 - a.bj0;
     b.H = (int)H;
     dim3 g((unsigned)(W * H - W * (W - 1) / 2));
@@ -220,8 +248,14 @@ void launch_pair_rect(int mode, const PairArgs &a, hipStream_t s)
 {
     if (a.nrows_out <= 0 || a.ncols_out <= 0) return;
     dim3 g((a.nrows_out + TS - 1) / TS, (a.ncols_out + TS - 1) / TS), b(256);
-    if (mode == MODE_MEAN) hipLaunchKernelGGL((pair_rect_kernel<MODE_MEAN>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((pair_rect_kernel<MODE_GEOM>), g, b, 0, s, a);
+    PairArgs pa = a;
+    {
+        static int blk = -1;
+        if (blk < 0) { const char *e = getenv("COCONS_PAIR_BLOCKED"); blk = e ? atoi(e) : 1; }
+        pa.blocked = blk ? 1 : 0;
+    }
+    if (mode == MODE_MEAN) hipLaunchKernelGGL((pair_rect_kernel<MODE_MEAN>), g, b, 0, s, pa);
+    else hipLaunchKernelGGL((pair_rect_kernel<MODE_GEOM>), g, b, 0, s, pa);
 }
 
 void launch_rhs_rows(const RhsArgs &a, hipStream_t s)

@@ -47,6 +47,7 @@ struct PairArgs {
     int nrows_out, ncols_out;   // extent to write (>= n pads with identity / zeros)
     int bj0;               // sym: first 64-wide tile column to assemble (sharded path), else 0
     int H;                 // sym: tile rows of the trapezoid (set by the launcher)
+    int blocked;           // sym: 8 x 8 pair patches per wave step (set by the launcher, Bessel modes)
     double gr;             // global_range
     double nu_fixed;       // closed-form modes
 };
