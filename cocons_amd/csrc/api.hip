@@ -10,6 +10,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -155,6 +156,8 @@ struct cocons_fit {
     // host copies of the inputs + lazily created clones: the slots of cocons_neg2loglik_batch
     std::vector<double> *h_locs, *h_X, *h_z;
     std::vector<cocons_fit *> *slots;
+    bool sorted;                  // observations are stored in Morton order (see fit_create_impl)
+    cocons_fit *unsorted;         // lazily created clone in the ORIGINAL order (marginal simulation)
 };
 
 static int fit_check(cocons_fit *f)
@@ -193,6 +196,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
         if (f->la_ev) { for (auto e : *f->la_ev) hipEventDestroy(e); delete f->la_ev; }
         if (f->slots) { for (auto c : *f->slots) cocons_fit_destroy(c); delete f->slots; f->slots = nullptr; }
+        if (f->unsorted) { cocons_fit_destroy(f->unsorted); f->unsorted = nullptr; }
         if (f->stream2) hipStreamDestroy(f->stream2);
         if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     }
@@ -200,9 +204,9 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
     delete f;
 }
 
-extern "C" cocons_fit *cocons_fit_create(int n, int p, int r, int q, const double *locs,
-                                         const double *X, const double *z, const double *x_betas,
-                                         const double *smooth_limits, int device)
+static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *locs,
+                                   const double *X, const double *z, const double *x_betas,
+                                   const double *smooth_limits, int device, bool allow_sort)
 {
     if (n <= 0 || p <= 0 || p > COCONS_P_MAX || r < 0 || q < 0 || !locs || !X || !smooth_limits ||
         (r > 0 && !z) || (q > 0 && !x_betas)) {
@@ -253,6 +257,63 @@ extern "C" cocons_fit *cocons_fit_create(int n, int p, int r, int q, const doubl
         if (!masked) CK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
     }
     f->own_stream = true;
+    // Spatial (Morton / Z-order) permutation of the observations.  -2 loglik, the kriging outputs and
+    // the simulated fields do not depend on the order of the observed locations (a symmetric
+    // permutation of Sigma), but the Bessel kernels run faster when neighbouring indices are
+    // neighbouring points (8 x 8 pair patches then see similar distances).  Everything the handle
+    // keeps -- locs, X, z, x_betas, host copies -- is stored in the permuted order.
+    std::vector<int> perm(n);
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    {
+        const char *e = getenv("COCONS_SPATIAL_SORT");
+        if (allow_sort && (e ? atoi(e) : 1) && n > 64) {
+            double lo[2] = {locs[0], locs[n]}, hi[2] = {locs[0], locs[n]};
+            for (int i = 0; i < n; ++i)
+                for (int d = 0; d < 2; ++d) {
+                    double v = locs[i + (size_t)d * n];
+                    if (v < lo[d]) lo[d] = v;
+                    if (v > hi[d]) hi[d] = v;
+                }
+            std::vector<unsigned long long> key(n);
+            bool finite = true;
+            for (int i = 0; i < n && finite; ++i) {
+                unsigned q[2];
+                for (int d = 0; d < 2; ++d) {
+                    double span = hi[d] - lo[d];
+                    double t = span > 0 ? (locs[i + (size_t)d * n] - lo[d]) / span : 0.0;
+                    if (!(t >= 0.0 && t <= 1.0)) { finite = false; t = 0; }
+                    q[d] = (unsigned)(t * 65535.0);
+                }
+                unsigned long long k = 0;
+                for (int b = 0; b < 16; ++b)
+                    k |= ((unsigned long long)((q[0] >> b) & 1u) << (2 * b)) | ((unsigned long long)((q[1] >> b) & 1u) << (2 * b + 1));
+                key[i] = (k << 32) | (unsigned)i;          // ties keep the input order
+            }
+            if (finite) {
+                std::sort(key.begin(), key.end());
+                for (int i = 0; i < n; ++i) perm[i] = (int)(key[i] & 0xffffffffu);
+            }
+        }
+    }
+    auto permute_cols = [&](const double *src, int ncol) {
+        std::vector<double> out((size_t)n * ncol);
+        for (int c = 0; c < ncol; ++c)
+            for (int i = 0; i < n; ++i) out[(size_t)i + (size_t)c * n] = src[(size_t)perm[i] + (size_t)c * n];
+        return out;
+    };
+    f->h_locs = new std::vector<double>(locs, locs + (size_t)2 * n);      // host copies: ORIGINAL order
+    f->h_X = new std::vector<double>(X, X + (size_t)n * p);
+    f->h_z = new std::vector<double>();
+    if (r > 0) f->h_z->assign(z, z + (size_t)n * r);
+    f->sorted = false;
+    for (int i = 0; i < n; ++i)
+        if (perm[i] != i) { f->sorted = true; break; }
+    std::vector<double> plocs = permute_cols(locs, 2), pX = permute_cols(X, p), pz, pxb;
+    if (r > 0) pz = permute_cols(z, r);
+    if (q > 0) pxb = permute_cols(x_betas, q);
+    locs = plocs.data(); X = pX.data();
+    if (r > 0) z = pz.data();
+    if (q > 0) x_betas = pxb.data();
     CK(hipMalloc(&f->dX, (size_t)n * p * sizeof(double)));
     CK(hipMalloc(&f->dlocs, (size_t)n * 2 * sizeof(double)));
     CK(hipMemcpy(f->dX, X, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice));
@@ -280,13 +341,16 @@ extern "C" cocons_fit *cocons_fit_create(int n, int p, int r, int q, const doubl
         CK(hipStreamCreateWithPriority(&f->stream2, hipStreamNonBlocking, hi));
     }
     f->la_ev = new std::vector<hipEvent_t>();
-    f->h_locs = new std::vector<double>(locs, locs + (size_t)2 * n);
-    f->h_X = new std::vector<double>(X, X + (size_t)n * p);
-    f->h_z = new std::vector<double>();
-    if (r > 0) f->h_z->assign(z, z + (size_t)n * r);
     if (fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
 #undef CK
     return f;
+}
+
+extern "C" cocons_fit *cocons_fit_create(int n, int p, int r, int q, const double *locs,
+                                         const double *X, const double *z, const double *x_betas,
+                                         const double *smooth_limits, int device)
+{
+    return fit_create_impl(n, p, r, q, locs, X, z, x_betas, smooth_limits, device, true);
 }
 
 extern "C" void *cocons_fit_stream(cocons_fit *f) { return f ? (void *)f->stream : nullptr; }
@@ -898,6 +962,17 @@ extern "C" int cocons_sim_dense(cocons_fit *f, const double *theta, const double
 {
     if (int rc = fit_check(f)) return rc;
     if (!theta || !mean || nsim <= 0 || !iiderrors || !out) return fail(-1, "cocons_sim_dense: bad argument");
+    if (f->sorted) {
+        // L E depends on the ORDER of the observations (the factor of a permuted matrix is not the
+        // permuted factor): the field for given draws is only reproduced in the caller's order
+        if (!f->unsorted) {
+            f->unsorted = fit_create_impl(f->n, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(),
+                                          f->r > 0 ? f->h_z->data() : nullptr, nullptr, f->smooth_limits,
+                                          f->device, false);
+            if (!f->unsorted) return -1;
+        }
+        return cocons_sim_dense(f->unsorted, theta, mean, classic, nsim, iiderrors, out);
+    }
     const int n = f->n, p = f->p;
     double *dE = nullptr, *dY = nullptr, *dtr = nullptr;
     int rc = 0;

@@ -437,3 +437,30 @@ def test_fuzz_random_parameters(oracle):
         worst = max(worst, abs(got - want) / abs(want))
     assert worst <= N2LL_RTOL, worst
     assert nfail < 10
+
+
+def test_spatial_sort_is_transparent(oracle, monkeypatch):
+    """The handle stores the observations in Morton order (faster Bessel kernels on scattered data).
+    Scalars, kriging outputs and conditional fields must not depend on it; the marginal simulation
+    must come back in the caller's order for the caller's draws."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n, m = 500, 60
+    locs, X, th, rng = _problem(n, seed=61)
+    th["mean"] = np.array([0.2, 0.1, -0.1])
+    z = rng.standard_normal(n)
+    lp = rng.uniform(0, 1, size=(m, 2))
+    Xp = wl.design_from_locs(lp)["std.covs"]
+    E = rng.standard_normal((n, 3))
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("COCONS_SPATIAL_SORT", flag)
+        fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+        res[flag] = (fit.neg2loglik_core(th)[0], fit.predict_core(th, lp, Xp), fit.sim_core(th, E))
+        fit.close()
+    assert abs(res["0"][0] - res["1"][0]) < 1e-11 * abs(res["0"][0])
+    assert np.allclose(res["0"][1][0], res["1"][1][0], rtol=1e-9, atol=1e-12)
+    assert np.allclose(res["0"][1][1], res["1"][1][1], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(res["0"][2], res["1"][2])          # same (unsorted) path either way
+    want = oracle.cocoSim_dense(th, locs, X, wl.SMOOTH_LIMITS, E, type="diff")
+    assert np.max(np.abs(res["1"][2] - want)) < 1e-10 * np.max(np.abs(want))
