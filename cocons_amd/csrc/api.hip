@@ -291,7 +291,21 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
             }
             if (finite) {
                 std::sort(key.begin(), key.end());
-                for (int i = 0; i < n; ++i) perm[i] = (int)(key[i] & 0xffffffffu);
+                // keep the caller's order when it is already as coherent as the Morton order (e.g. a
+                // regular grid listed row by row): compare the path lengths through the points
+                auto path = [&](auto idx) {
+                    double s = 0;
+                    for (int i = 0; i + 1 < n; ++i) {
+                        int a = idx(i), b = idx(i + 1);
+                        double dx = locs[a] - locs[b], dy = locs[a + (size_t)n] - locs[b + (size_t)n];
+                        s += std::sqrt(dx * dx + dy * dy);
+                    }
+                    return s;
+                };
+                double p_in = path([&](int i) { return i; });
+                double p_mo = path([&](int i) { return (int)(key[i] & 0xffffffffu); });
+                if (p_mo < 0.8 * p_in)
+                    for (int i = 0; i < n; ++i) perm[i] = (int)(key[i] & 0xffffffffu);
             }
         }
     }
