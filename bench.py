@@ -101,6 +101,19 @@ def main():
                          "(separate fit handles / streams, as optimParallel's workers issue them); 0 = skip")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Started without a launcher: this process never touches the GPU; it starts one fresh rank
+        # per GPU (torch.distributed.run), relays rank 0's JSON line and returns the children's code.
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import torch
     import cocons_amd as ca
     from cocons_amd import workloads as wl
@@ -109,8 +122,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
     # rehearsal knob for boxes with a single GPU: every rank on device 0, gloo instead of RCCL

@@ -54,6 +54,7 @@ SIGNATURES = {
     "cocons_fit_profile": (c_int, [c_vp, c_dp, c_dp, c_int, c_dp]),
     "cocons_mfma_f64_probe": (c_int, [c_int, c_dp]),
     "cocons_vfma_f64_probe": (c_int, [c_int, c_dp]),
+    "cocons_debug_matern": (c_int, [c_int, c_dp, c_dp, c_dp]),
     "cocons_shard_begin": (c_int, [c_vp, c_dp, c_dp, c_int, c_int]),
     "cocons_shard_panel_factor": (c_int, [c_vp, c_int]),
     "cocons_shard_panel_buffer": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(ctypes.c_longlong)]),

@@ -1,7 +1,6 @@
 // api.hip -- C ABI of the dense hot path (see include/cocons_hip.h for the contract and the
 // reference interface each entry point replaces).
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <limits.h>
 #include <math.h>
 #include <stdint.h>
@@ -142,7 +141,7 @@ struct cocons_fit {
     double smooth_limits[2];
     size_t out_cap;
     // predict scratch
-    double *dlocp, *dXp, *dlocsp, *dstoch, *dquad;
+    double *dlocp, *dXp, *dlocsp, *dstoch, *dquad, *dred;
     int pred_cap;
     // sharded state
     int rank, world, nrhs_cur;
@@ -190,7 +189,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->stream) hipStreamSynchronize(f->stream);
         hipFree(f->dX); hipFree(f->dlocs); hipFree(f->dz); hipFree(f->dxb); hipFree(f->dloc);
         hipFree(f->dA); hipFree(f->dinv); hipFree(f->dinfo); hipFree(f->dout);
-        hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad);
+        hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad); hipFree(f->dred);
         if (f->xbuf_own) { hipFree(f->xbuf[0]); hipFree(f->xbuf[1]); }
         hipHostFree(f->hout); hipHostFree(f->hinfo);
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
@@ -233,29 +232,8 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
         }                                                                         \
     } while (0)
     CK(hipSetDevice(f->device));
-    {
-        // Look-ahead needs the single-workgroup diagonal-tile kernel (147 KB of LDS) to find an
-        // empty CU while the trailing update saturates the chip: keep a few CUs out of the main
-        // stream's CU mask.  The panel stream sees every CU and has the higher priority.
-        int reserve = 0;
-        if (lookahead_enabled()) {
-            // off by default: with CU-masked queues created and destroyed repeatedly in one
-            // process, later launches were observed to hang on ROCm 7.2 (round-1 test runs)
-            const char *e = getenv("COCONS_RESERVED_CUS");
-            reserve = e ? atoi(e) : 0;
-        }
-        hipDeviceProp_t prop;
-        CK(hipGetDeviceProperties(&prop, f->device));
-        const int ncu = prop.multiProcessorCount;
-        bool masked = false;
-        if (reserve > 0 && reserve < ncu) {
-            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-            for (int c = reserve; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
-            masked = hipExtStreamCreateWithCUMask(&f->stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
-            if (!masked) (void)hipGetLastError();
-        }
-        if (!masked) CK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
-    }
+    // every stream the library creates is non-blocking: nothing here ever joins the NULL stream
+    CK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
     f->own_stream = true;
     // Spatial (Morton / Z-order) permutation of the observations.  -2 loglik, the kriging outputs and
     // the simulated fields do not depend on the order of the observed locations (a symmetric
@@ -330,16 +308,17 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     if (q > 0) x_betas = pxb.data();
     CK(hipMalloc(&f->dX, (size_t)n * p * sizeof(double)));
     CK(hipMalloc(&f->dlocs, (size_t)n * 2 * sizeof(double)));
-    CK(hipMemcpy(f->dX, X, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice));
-    CK(hipMemcpy(f->dlocs, locs, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice));
+    CK(hipMemcpyAsync(f->dX, X, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    CK(hipMemcpyAsync(f->dlocs, locs, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
     if (r > 0) {
         CK(hipMalloc(&f->dz, (size_t)n * r * sizeof(double)));
-        CK(hipMemcpy(f->dz, z, (size_t)n * r * sizeof(double), hipMemcpyHostToDevice));
+        CK(hipMemcpyAsync(f->dz, z, (size_t)n * r * sizeof(double), hipMemcpyHostToDevice, f->stream));
     }
     if (q > 0) {
         CK(hipMalloc(&f->dxb, (size_t)n * q * sizeof(double)));
-        CK(hipMemcpy(f->dxb, x_betas, (size_t)n * q * sizeof(double), hipMemcpyHostToDevice));
+        CK(hipMemcpyAsync(f->dxb, x_betas, (size_t)n * q * sizeof(double), hipMemcpyHostToDevice, f->stream));
     }
+    CK(hipStreamSynchronize(f->stream));      // the staging vectors above go out of scope
     CK(hipMalloc(&f->dloc, (size_t)LOCP_FIELDS * f->npad * sizeof(double)));
     CK(hipMalloc(&f->dinv, 2 * 8 * 256 * sizeof(double)));
     CK(hipMalloc(&f->dinfo, sizeof(int)));
@@ -372,7 +351,10 @@ extern "C" void *cocons_fit_stream(cocons_fit *f) { return f ? (void *)f->stream
 extern "C" int cocons_fit_set_stream(cocons_fit *f, void *stream)
 {
     if (int rc = fit_check(f)) return rc;
+    // both streams idle before the swap: no event wait of the panel stream may refer to work on a
+    // stream that is about to be destroyed
     HIPCHK(hipStreamSynchronize(f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream2));
     if (f->own_stream) { HIPCHK(hipStreamDestroy(f->stream)); f->own_stream = false; }
     f->stream = (hipStream_t)stream;
     return 0;
@@ -648,14 +630,19 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
         if (nslots_env < 1) nslots_env = 1;
         if (nslots_env > 8) nslots_env = 8;
     }
-    const int S = nb < nslots_env ? (nb > 0 ? nb : 1) : nslots_env;
+    int S = nb < nslots_env ? (nb > 0 ? nb : 1) : nslots_env;
     if (!f->slots) f->slots = new std::vector<cocons_fit *>();
-    while ((int)f->slots->size() < S - 1) {          // slot 0 is the fit itself
+    // every extra slot is a clone of the handle with its own n x n factorisation buffer
+    // (lda * npad * 8 bytes: 0.83 GB at n = 10^4); if one cannot be created (out of memory) the
+    // batch runs on the slots that exist -- slot 0 is the fit itself, so it always completes
+    while ((int)f->slots->size() < S - 1) {
         cocons_fit *c = cocons_fit_create(f->n, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(),
                                           f->h_z->data(), nullptr, f->smooth_limits, f->device);
-        if (!c) return -1;
+        if (!c) { (void)hipGetLastError(); break; }
         f->slots->push_back(c);
     }
+    if (S > (int)f->slots->size() + 1) S = (int)f->slots->size() + 1;
+    for (int i = 0; i < nb; ++i) { values[i] = NAN; status[i] = -1; }   // never left unwritten
     std::vector<int> pending(S, -1);
     const int tp = 6 * f->p;
     int rc_all = 0;
@@ -829,7 +816,7 @@ static int cov_common(int which, int n, int m, int p, const double *theta, const
     ThetaVecs tv;
     make_theta_vecs(theta, p, tv);
     ModeSel ms = select_mode(theta, p, sl, which);
-    hipStream_t s = nullptr;
+    hipStream_t s = nullptr;     // own non-blocking stream (the library never launches on the NULL stream)
     double *dX = nullptr, *dl = nullptr, *dloc = nullptr, *dXp = nullptr, *dlp = nullptr, *dlocp = nullptr, *dout = nullptr;
     const size_t rows = which == 2 ? (size_t)m : (size_t)n;
     int rc = 0;
@@ -841,12 +828,13 @@ static int cov_common(int which, int n, int m, int p, const double *theta, const
             goto done;                                                            \
         }                                                                         \
     } while (0)
+    CKG(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     CKG(hipMalloc(&dX, (size_t)n * p * sizeof(double)));
     CKG(hipMalloc(&dl, (size_t)n * 2 * sizeof(double)));
     CKG(hipMalloc(&dloc, (size_t)LOCP_FIELDS * n * sizeof(double)));
     CKG(hipMalloc(&dout, rows * (size_t)n * sizeof(double)));
-    CKG(hipMemcpy(dX, X, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice));
-    CKG(hipMemcpy(dl, locs, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice));
+    CKG(hipMemcpyAsync(dX, X, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice, s));
+    CKG(hipMemcpyAsync(dl, locs, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, s));
     {
         LocArgs la;
         la.n = n; la.p = p; la.X = dX; la.ldx = n; la.locs = dl; la.ldl = n;
@@ -860,8 +848,8 @@ static int cov_common(int which, int n, int m, int p, const double *theta, const
             CKG(hipMalloc(&dXp, (size_t)m * p * sizeof(double)));
             CKG(hipMalloc(&dlp, (size_t)m * 2 * sizeof(double)));
             CKG(hipMalloc(&dlocp, (size_t)LOCP_FIELDS * m * sizeof(double)));
-            CKG(hipMemcpy(dXp, X_pred, (size_t)m * p * sizeof(double), hipMemcpyHostToDevice));
-            CKG(hipMemcpy(dlp, locs_pred, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice));
+            CKG(hipMemcpyAsync(dXp, X_pred, (size_t)m * p * sizeof(double), hipMemcpyHostToDevice, s));
+            CKG(hipMemcpyAsync(dlp, locs_pred, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
             LocArgs lp = la;
             lp.n = m; lp.X = dXp; lp.ldx = m; lp.locs = dlp; lp.ldl = m; lp.out = dlocp; lp.stride = m;
             launch_loc_params(lp, s);
@@ -873,8 +861,10 @@ static int cov_common(int which, int n, int m, int p, const double *theta, const
         }
     }
     CKG(hipGetLastError());
-    CKG(hipMemcpy(out, dout, rows * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    CKG(hipMemcpyAsync(out, dout, rows * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    CKG(hipStreamSynchronize(s));
 done:
+    if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); }
     hipFree(dX); hipFree(dl); hipFree(dloc); hipFree(dXp); hipFree(dlp); hipFree(dlocp); hipFree(dout);
 #undef CKG
     return rc;
@@ -909,14 +899,15 @@ extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const do
         return fail(-1, "cocons_predict_dense: bad argument");
     const int p = f->p, n = f->n;
     if (m > f->pred_cap) {
-        hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad);
-        f->dlocp = f->dXp = f->dlocsp = f->dstoch = f->dquad = nullptr;
+        hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad); hipFree(f->dred);
+        f->dlocp = f->dXp = f->dlocsp = f->dstoch = f->dquad = f->dred = nullptr;
         f->pred_cap = 0;
         HIPCHK(hipMalloc(&f->dlocp, (size_t)LOCP_FIELDS * m * sizeof(double)));
         HIPCHK(hipMalloc(&f->dXp, (size_t)m * p * sizeof(double)));
         HIPCHK(hipMalloc(&f->dlocsp, (size_t)m * 2 * sizeof(double)));
         HIPCHK(hipMalloc(&f->dstoch, (size_t)m * sizeof(double)));
         HIPCHK(hipMalloc(&f->dquad, (size_t)m * sizeof(double)));
+        HIPCHK(hipMalloc(&f->dred, row_reduce_scratch_doubles(n, m) * sizeof(double)));
         f->pred_cap = m;
     }
     if (int rc = fit_alloc_matrix(f, m + 1)) return rc;
@@ -959,7 +950,7 @@ extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const do
         launch_pair_rect(MODE_GEOM, pa, s);
     }
     factorize(f, main_view(f), nullptr);
-    launch_row_reduce(f->dA, f->lda, n, f->npad, f->npad + 1, m, f->dstoch, f->dquad, s);
+    launch_row_reduce(f->dA, f->lda, n, f->npad, f->npad + 1, m, f->dstoch, f->dquad, f->dred, s);
     HIPCHK(hipMemcpyAsync(stochastic, f->dstoch, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(quadform, f->dquad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1003,7 +994,8 @@ extern "C" int cocons_sim_dense(cocons_fit *f, const double *theta, const double
             std::vector<double> tr(n, 0.0);
             for (int j = 0; j < p; ++j)
                 for (int i = 0; i < n; ++i) tr[i] += (*f->h_X)[(size_t)i + (size_t)j * n] * mean[j];
-            CKS(hipMemcpy(dtr, tr.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+            CKS(hipMemcpyAsync(dtr, tr.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+            CKS(hipStreamSynchronize(s));
         }
         if ((rc = reset_info(f))) break;
         f->nrhs_cur = 0;
@@ -1048,7 +1040,7 @@ extern "C" int cocons_sim_cond_dense(cocons_fit *f, const double *theta, const d
     const int mpad = round_up(m, TILE), N = npad + mpad;
     const size_t ldj = (size_t)N + TILE;
     double *dJ = nullptr, *dXp = nullptr, *dlp = nullptr, *dlu = nullptr, *dlocp = nullptr, *dlocu = nullptr;
-    double *dE = nullptr, *dY = nullptr, *dmu = nullptr, *dst = nullptr, *dq = nullptr;
+    double *dE = nullptr, *dY = nullptr, *dmu = nullptr, *dst = nullptr, *dq = nullptr, *dred = nullptr;
     hipStream_t s = f->stream;
     int rc = 0;
     do {
@@ -1065,6 +1057,7 @@ extern "C" int cocons_sim_cond_dense(cocons_fit *f, const double *theta, const d
         CKS(hipMalloc(&dmu, (size_t)m * sizeof(double)));
         CKS(hipMalloc(&dst, (size_t)m * sizeof(double)));
         CKS(hipMalloc(&dq, (size_t)m * sizeof(double)));
+        CKS(hipMalloc(&dred, row_reduce_scratch_doubles(n, m) * sizeof(double)));
         CKS(hipMemcpyAsync(dXp, X_pred, (size_t)m * p * sizeof(double), hipMemcpyHostToDevice, s));
         CKS(hipMemcpyAsync(dlp, locs_pred, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
         CKS(hipMemcpyAsync(dlu, locs_unobs, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1118,7 +1111,7 @@ extern "C" int cocons_sim_cond_dense(cocons_fit *f, const double *theta, const d
         v.A = dJ; v.lda = ldj; v.nt = N / TILE; v.mt = N / TILE + 1;
         factorize(f, v, nullptr);
         // kriging mean: stochastic_i = sum_{c<n} J(npad+i, c) J(N, c);  tmp_mu = X_pred mean + stochastic
-        launch_row_reduce(dJ, ldj, n, N, npad, m, dst, dq, s);
+        launch_row_reduce(dJ, ldj, n, N, npad, m, dst, dq, dred, s);
         std::vector<double> mu(m), stv(m);
         CKS(hipMemcpyAsync(stv.data(), dst, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
         CKS(hipStreamSynchronize(s));
@@ -1139,7 +1132,7 @@ extern "C" int cocons_sim_cond_dense(cocons_fit *f, const double *theta, const d
         if (rc > n) rc = n;    // a failure inside the Schur block is still "Cholesky error"
     } while (0);
     hipFree(dJ); hipFree(dXp); hipFree(dlp); hipFree(dlu); hipFree(dlocp); hipFree(dlocu);
-    hipFree(dE); hipFree(dY); hipFree(dmu); hipFree(dst); hipFree(dq);
+    hipFree(dE); hipFree(dY); hipFree(dmu); hipFree(dst); hipFree(dq); hipFree(dred);
     return rc;
 }
 
@@ -1164,17 +1157,17 @@ extern "C" int cocons_chol_solve(int n, const double *Ain, int nrhs, const doubl
             for (int r_ = c; r_ < n; ++r_) hostA[(size_t)r_ + (size_t)c * f->lda] = Ain[(size_t)r_ + (size_t)c * n];
             for (int k = 0; k < nrhs; ++k) hostA[(size_t)(f->npad + k) + (size_t)c * f->lda] = rhs[(size_t)c + (size_t)k * n];
         }
-        hipError_t e = hipMemcpy(f->dA, hostA.data(), hostA.size() * sizeof(double), hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpyAsync(f->dA, hostA.data(), hostA.size() * sizeof(double), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) { rc = fail(-100, "cocons_chol_solve: %s", hipGetErrorString(e)); break; }
         if ((rc = reset_info(f))) break;
         factorize(f, main_view(f), nullptr);
         launch_finalize(f->dA, f->lda, n, f->npad, 0, f->dout, s);
-        e = hipStreamSynchronize(s);     // the fit's stream is non-blocking: order the copies below
+        e = hipMemcpyAsync(hostA.data(), f->dA, hostA.size() * sizeof(double), hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) { rc = fail(-100, "cocons_chol_solve: %s", hipGetErrorString(e)); break; }
-        e = hipMemcpy(hostA.data(), f->dA, hostA.size() * sizeof(double), hipMemcpyDeviceToHost);
+        hipMemcpyAsync(f->hout, f->dout, sizeof(double), hipMemcpyDeviceToHost, s);
+        hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, s);
+        e = hipStreamSynchronize(s);
         if (e != hipSuccess) { rc = fail(-100, "cocons_chol_solve: %s", hipGetErrorString(e)); break; }
-        hipMemcpy(f->hout, f->dout, sizeof(double), hipMemcpyDeviceToHost);
-        hipMemcpy(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost);
         if ((rc = info_status(f))) break;
         if (logdet_half) *logdet_half = f->hout[0];
         if (L)
@@ -1195,11 +1188,15 @@ static const int PT = 2;     // tiles per panel
 
 extern "C" int cocons_shard_num_panels(cocons_fit *f) { return f ? (f->nt + PT - 1) / PT : -1; }
 
+// rows a packed panel carries: the matrix rows plus the right-hand-side rows the sharded evaluation
+// uses (r rows rounded up to a tile) -- NOT the buffer's leading dimension, which an earlier
+// cocons_predict_dense on the same handle may have grown
+static inline size_t shard_rows(cocons_fit *f) { return (size_t)f->npad + round_up(f->r > 0 ? f->r : 1, TILE); }
+
 extern "C" long long cocons_shard_exchange_bytes(cocons_fit *f)
 {
     if (!f) return -1;
-    size_t rows = (size_t)f->npad + round_up(f->r > 0 ? f->r : 1, TILE);
-    return (long long)(rows * PT * TILE * sizeof(double));
+    return (long long)(shard_rows(f) * PT * TILE * sizeof(double));
 }
 
 // the caller may hand in two exchange buffers it owns (e.g. torch tensors, so that
@@ -1220,6 +1217,9 @@ extern "C" int cocons_shard_begin(cocons_fit *f, const double *theta, const doub
     if (f->r < 1) return fail(-1, "cocons_shard_begin: fit has no z");
     f->rank = rank; f->world = world; f->nrhs_cur = f->r;
     if (int rc = fit_alloc_matrix(f, f->r)) return rc;
+    if ((size_t)f->npad + f->rhs_act != shard_rows(f)) return fail(-1, "cocons_shard_begin: inconsistent right-hand-side rows");
+    if (f->xbuf[0] && f->xbuf_bytes < (size_t)cocons_shard_exchange_bytes(f))
+        return fail(-1, "cocons_shard_begin: exchange buffer too small");
     if (!f->xbuf[0]) {
         size_t bytes = (size_t)cocons_shard_exchange_bytes(f);
         HIPCHK(hipMalloc(&f->xbuf[0], bytes));
@@ -1251,7 +1251,7 @@ extern "C" int cocons_shard_begin(cocons_fit *f, const double *theta, const doub
     return 0;
 }
 
-static inline size_t panel_rows(cocons_fit *f, int k) { return f->lda - (size_t)k * PT * TILE; }
+static inline size_t panel_rows(cocons_fit *f, int k) { return shard_rows(f) - (size_t)k * PT * TILE; }
 
 extern "C" int cocons_shard_panel_buffer(cocons_fit *f, int k, void **dev_ptr, long long *bytes)
 {
@@ -1280,8 +1280,10 @@ extern "C" int cocons_shard_panel_factor(cocons_fit *f, int k)
         launch_potrf_tile(A, f->lda, (t0 + 1) * TILE, f->dinv + 8 * 256, f->dinfo, s);
         launch_trsm_tile(A, f->lda, (t0 + 1) * TILE, (t0 + 2) * TILE, mt * TILE, f->dinv + 8 * 256, s);
     }
-    // pack rows [t0*128, lda) of the panel's columns into the exchange buffer (ld = rows)
+    // pack rows [t0*128, npad + rhs rows) of the panel's columns into the exchange buffer (ld = rows)
     size_t rows = panel_rows(f, k);
+    if (rows * (size_t)w * TILE * sizeof(double) > f->xbuf_bytes || mt * TILE != (int)shard_rows(f))
+        return fail(-1, "cocons_shard_panel_factor: exchange buffer too small for this panel");
     HIPCHK(hipMemcpy2DAsync(f->xbuf[k & 1], rows * sizeof(double),
                             A + (size_t)t0 * TILE + (size_t)t0 * TILE * f->lda, f->lda * sizeof(double),
                             rows * sizeof(double), (size_t)w * TILE, hipMemcpyDeviceToDevice, s));
@@ -1346,6 +1348,32 @@ extern "C" int cocons_shard_finish(cocons_fit *f, double *partial, int *info)
 }
 
 // ---------------------------------------------------------------------------
+// diagnostic: the device Matern correlation 2^(1-nu)/Gamma(nu) u^nu K_nu(u) at n points (host in/out)
+extern "C" int cocons_debug_matern(int n, const double *nu, const double *u, double *out)
+{
+    if (n <= 0 || !nu || !u || !out) return fail(-1, "cocons_debug_matern: bad argument");
+    hipStream_t s = nullptr;
+    double *d = nullptr;
+    int rc = 0;
+    do {
+        hipError_t e;
+#define CKD(expr) if ((e = (expr)) != hipSuccess) { rc = fail(-100 - (int)e, "cocons_debug_matern: %s", hipGetErrorString(e)); break; }
+        CKD(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        CKD(hipMalloc(&d, (size_t)3 * n * sizeof(double)));
+        CKD(hipMemcpyAsync(d, nu, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+        CKD(hipMemcpyAsync(d + n, u, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+        launch_matern_points(n, d, d + n, d + 2 * (size_t)n, s);
+        CKD(hipGetLastError());
+        CKD(hipMemcpyAsync(out, d + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+        CKD(hipStreamSynchronize(s));
+#undef CKD
+    } while (0);
+    if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); }
+    hipFree(d);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
 extern "C" int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops)
 {
     if (!tflops || blocks_per_cu < 1 || blocks_per_cu > 8) return fail(-1, "cocons_mfma_f64_probe: bad argument");
@@ -1355,8 +1383,11 @@ extern "C" int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops)
     double *d = nullptr;
     HIPCHK(hipMalloc(&d, (size_t)blocks * 256 * sizeof(double)));
     // blocks_per_cu > 0: MFMA probe; the vector-FMA companion is reported through cocons_vfma_f64_probe
-    *tflops = run_mfma_f64_probe(nullptr, blocks, 20000, d);
+    hipStream_t ps = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    *tflops = run_mfma_f64_probe(ps, blocks, 20000, d);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamDestroy(ps));
     HIPCHK(hipFree(d));
     return 0;
 }
@@ -1369,8 +1400,11 @@ extern "C" int cocons_vfma_f64_probe(int blocks_per_cu, double *tflops)
     int blocks = prop.multiProcessorCount * blocks_per_cu;
     double *d = nullptr;
     HIPCHK(hipMalloc(&d, (size_t)blocks * 256 * sizeof(double)));
-    *tflops = run_vfma_f64_probe(nullptr, blocks, 20000, d);
+    hipStream_t ps = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    *tflops = run_vfma_f64_probe(ps, blocks, 20000, d);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamDestroy(ps));
     HIPCHK(hipFree(d));
     return 0;
 }

@@ -204,6 +204,23 @@ rhs_rows_kernel(RhsArgs a)
         a.out[(size_t)(a.row0 + k) + (size_t)c * a.ld] = 0.0;
 }
 
+// Diagnostic: the device Matern/Bessel routine evaluated pointwise, so that it can be pinned
+// directly against the mpmath grid (tests/golden/besselk_grid.json) instead of only through Sigma.
+__global__ void __launch_bounds__(64)
+matern_points_kernel(int n, const double *nu, const double *x, double *out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double u = x[i], v = nu[i];
+    out[i] = (u < 706.0) ? matern_bessel(v, u) : matern_asymptotic(v, u);
+}
+
+void launch_matern_points(int n, const double *nu, const double *x, double *out, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(matern_points_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, nu, x, out);
+}
+
 // ---------------------------------------------------------------------------
 void launch_loc_params(const LocArgs &a, hipStream_t s)
 {

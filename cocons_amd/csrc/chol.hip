@@ -568,9 +568,13 @@ finalize_kernel(const double *A, size_t lda, int c0, int c1, int n, int row0, in
     if (threadIdx.x == 0) out[b == nr * nr ? 0 : 1 + b] = s;
 }
 
+// Per-row reductions for predict, in two deterministic stages (no floating-point atomics, so the
+// kriging outputs are bit-reproducible run to run like the reference's crossprod / rowSums):
+// stage 1: partial sums over chunks of `cchunk` columns -> scratch[(chunk * 2 + {0,1}) * m + i]
+// stage 2: the chunks of one row summed in ascending order.
 __global__ void __launch_bounds__(256)
 row_reduce_kernel(const double *A, size_t lda, int n, int rowy, int row0, int m,
-                  double *stoch, double *quad, int cchunk)
+                  double *scratch, int cchunk)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cb = blockIdx.y * cchunk;
@@ -583,8 +587,22 @@ row_reduce_kernel(const double *A, size_t lda, int n, int rowy, int row0, int m,
         s = fma(v, y, s);
         q = fma(v, v, q);
     }
-    atomicAdd(&stoch[i], s);
-    atomicAdd(&quad[i], q);
+    scratch[((size_t)blockIdx.y * 2 + 0) * m + i] = s;
+    scratch[((size_t)blockIdx.y * 2 + 1) * m + i] = q;
+}
+
+__global__ void __launch_bounds__(256)
+row_reduce_final_kernel(const double *scratch, int m, int nchunks, double *stoch, double *quad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+        s += scratch[((size_t)c * 2 + 0) * m + i];
+        q += scratch[((size_t)c * 2 + 1) * m + i];
+    }
+    stoch[i] = s;
+    quad[i] = q;
 }
 
 // ---------------------------------------------------------------------------
@@ -734,15 +752,20 @@ void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, doubl
     launch_finalize_cols(A, lda, 0, n, n, row0, nr, out, s);
 }
 
+size_t row_reduce_scratch_doubles(int n, int m)
+{
+    return (size_t)2 * (size_t)m * (size_t)((n + 255) / 256);
+}
+
 void launch_row_reduce(const double *A, size_t lda, int n, int rowy, int row0, int m,
-                       double *stoch, double *quad, hipStream_t s)
+                       double *stoch, double *quad, double *scratch, hipStream_t s)
 {
     if (m <= 0) return;
-    const int cchunk = 256;
-    hipMemsetAsync(stoch, 0, (size_t)m * sizeof(double), s);
-    hipMemsetAsync(quad, 0, (size_t)m * sizeof(double), s);
-    hipLaunchKernelGGL(row_reduce_kernel, dim3((m + 255) / 256, (n + cchunk - 1) / cchunk), dim3(256), 0, s,
-                       A, lda, n, rowy, row0, m, stoch, quad, cchunk);
+    const int cchunk = 256, nchunks = (n + cchunk - 1) / cchunk;
+    hipLaunchKernelGGL(row_reduce_kernel, dim3((m + 255) / 256, nchunks), dim3(256), 0, s,
+                       A, lda, n, rowy, row0, m, scratch, cchunk);
+    hipLaunchKernelGGL(row_reduce_final_kernel, dim3((m + 255) / 256), dim3(256), 0, s,
+                       scratch, m, nchunks, stoch, quad);
 }
 
 }  // namespace cocons

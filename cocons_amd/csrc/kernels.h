@@ -68,6 +68,8 @@ void launch_loc_params(const LocArgs &a, hipStream_t s);
 void launch_pair_sym(int mode, bool mirror, const PairArgs &a, hipStream_t s);
 void launch_pair_rect(int mode, const PairArgs &a, hipStream_t s);
 void launch_rhs_rows(const RhsArgs &a, hipStream_t s);
+// out[i] = 2^(1-nu)/Gamma(nu) u^nu K_nu(u) by the device routine of the pair kernels (diagnostic)
+void launch_matern_points(int n, const double *nu, const double *x, double *out, hipStream_t s);
 
 // ---- factorisation (chol.hip) -------------------------------------------------
 constexpr int TILE = 128;          // tile edge of the blocked factorisation
@@ -98,8 +100,10 @@ void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, doubl
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
                           double *out, hipStream_t s);
 // per-row reductions for predict: stoch[i] = sum_c A(rowy,c) A(row0+i,c); quad[i] = sum_c A(row0+i,c)^2
+// deterministic two-stage reduction; scratch must hold row_reduce_scratch_doubles(n, m) doubles
+size_t row_reduce_scratch_doubles(int n, int m);
 void launch_row_reduce(const double *A, size_t lda, int n, int rowy, int row0, int m,
-                       double *stoch, double *quad, hipStream_t s);
+                       double *stoch, double *quad, double *scratch, hipStream_t s);
 
 // Y = L E + trend (lower factor L in A), E n x nsim, Y n x nsim
 void launch_trmm_lower(const double *A, size_t lda, int n, const double *E, int lde, int nsim,

@@ -47,7 +47,8 @@ class ShardedFit(CoconsFit):
         L = self._L
         nbytes = int(L.cocons_shard_exchange_bytes(self._h))
         self._xbuf = [torch.empty(nbytes // 8, dtype=torch.float64, device=self.device) for _ in range(2)]
-        _lib.check(L.cocons_fit_set_stream(self._h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+        self._pinned_stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.cocons_fit_set_stream(self._h, ctypes.c_void_p(self._pinned_stream)),
                    "cocons_fit_set_stream")
         _lib.check(L.cocons_shard_set_exchange(self._h, ctypes.c_void_p(self._xbuf[0].data_ptr()),
                                                ctypes.c_void_p(self._xbuf[1].data_ptr()), nbytes),
@@ -55,6 +56,12 @@ class ShardedFit(CoconsFit):
 
     # engine interface ------------------------------------------------------
     def begin(self, theta_list, rank, world):
+        # (re)pin the handle to the stream that is current NOW: torch orders the collectives of this
+        # evaluation against its current stream, so the kernels must be on the same one
+        cur = self.torch.cuda.current_stream().cuda_stream
+        if cur != self._pinned_stream:
+            _lib.check(self._L.cocons_fit_set_stream(self._h, ctypes.c_void_p(cur)), "cocons_fit_set_stream")
+            self._pinned_stream = cur
         T = theta_table(theta_list)
         mean = np.ascontiguousarray(np.asarray(theta_list["mean"], dtype=np.float64))
         _lib.check(self._L.cocons_shard_begin(self._h, _p(T), _p(mean), rank, world), "cocons_shard_begin")

@@ -157,6 +157,12 @@ int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops);
 /* companion: independent v_fma_f64 chains -- the fp64 vector rate the chip sustains */
 int cocons_vfma_f64_probe(int blocks_per_cu, double *tflops);
 
+/* Diagnostic: the device routine that replaces boost::math::cyl_bessel_k + tgamma + pow at
+ * src/cocons_full.cpp:293-297 (:301-305 for u >= 706), evaluated pointwise:
+ * out[i] = 2^(1-nu_i)/Gamma(nu_i) * u_i^nu_i * K_nu_i(u_i).  Pinned against the mpmath grid in
+ * tests/golden/besselk_grid.json (host arrays in, host array out).                    */
+int cocons_debug_matern(int n, const double *nu, const double *u, double *out);
+
 /* ---- column-panel sharded evaluation across GPUs (one process per GPU) ---------
  * The reference's chol reads the UPPER triangle of Sigma row by row; its row
  * blocks are exactly the column panels of the lower factor kept here.  Panels

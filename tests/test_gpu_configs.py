@@ -128,6 +128,35 @@ def test_c4_optimizer_in_the_loop(oracle):
         assert abs(a - b) <= 1e-8 * abs(b)
 
 
+def test_c4_optimizer_in_the_loop_n4096(oracle):
+    """C4 as BASELINE states it: 64x64 grid (n = 4096), full nonstationary model, P = 16 free
+    parameters, L-BFGS-B with central differences, ~50 objective evaluations on the GPU (the 2P
+    gradient points through the batch entry).  GPU objective vs the CPU oracle at the start and at
+    the end point (R/optim.R:237-259)."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from optim_loop import lbfgsb_central
+    locs, X, th, z = _grid_problem(64)
+    n = 4096
+    pp = wl.par_pos_full()
+    t0 = wl.theta_vector_from_lists(th, pp) + 0.1
+    lam = (0.0, 0.0, 0.0)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+
+    def f_gpu(t):
+        return ca.GetNeg2loglikelihood(t, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+
+    def f_batch(ts):
+        return ca.GetNeg2loglikelihood_batch(ts, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+
+    res = lbfgsb_central(f_gpu, t0, lower=t0 - 3, upper=t0 + 3, max_evals=50, fn_batch=f_batch)
+    assert res["nfev"] >= 34 and res["fun"] < f_gpu(t0)
+    for t in (t0, res["x"]):
+        a, b = f_gpu(t), oracle.GetNeg2loglikelihood(t, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+        assert abs(a - b) <= 1e-8 * abs(b)
+
+
 def test_getHessian_batch_vs_cpu(oracle):
     """getHessian: 3 P (P+1)/2 objective evaluations as one GPU batch against
     the serial CPU restatement.  The finite-difference quotient divides differences of O(1e3)
@@ -208,11 +237,12 @@ def _shard_worker(rank, world, port, g, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,g", [(2, 40), (3, 50), (4, 15)])
+@pytest.mark.parametrize("world,g", [(2, 40), (3, 50), (4, 15), (2, 100)])
 def test_sharded_hip_engine_over_gloo(tmp_path, world, g):
     """The production sharded path (HIP kernels + cocons_amd.shard schedule) with `world`
     ranks sharing this box's single GPU and gloo carrying the panel broadcasts (RCCL refuses
-    several ranks on one device).  Must reproduce the single-GPU value."""
+    several ranks on one device).  Must reproduce the single-GPU value.  (2, 100) is BASELINE
+    config C3 at its full size n = 10 000 in sharded form."""
     import torch.multiprocessing as mp
     import cocons_amd as ca
     from cocons_amd import workloads as wl
@@ -228,3 +258,52 @@ def test_sharded_hip_engine_over_gloo(tmp_path, world, g):
     val, parts = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS).neg2loglik_core(th)
     assert abs(res[0][0] - val) < 1e-10 * abs(val)
     assert np.allclose(res[0][1:], parts, rtol=1e-10, atol=0)
+
+
+def _predict_shard_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch                      # noqa: F401
+    import torch.distributed as dist
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    from cocons_amd.shard import sharded_predict_core
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    locs, X, th, z, lp, Xp = _c5_problem()
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, device=0)
+    st, qf = sharded_predict_core(fit, th, lp, Xp, dist, rank, world)
+    np.save(os.path.join(out_dir, "pred%d.npy" % rank), np.stack([st, qf]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _c5_problem():
+    from cocons_amd import workloads as wl
+    locs = wl.grid_locs(128, 64)
+    sc = wl.design_from_locs(locs)
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.3, -0.1, 0.2])
+    z = wl.synthetic_z(8192)
+    lp = locs + np.array([0.5 / 127, 0.5 / 63])
+    Xp = wl.design_from_locs(lp, sc["mean.vector"], sc["sd.vector"])["std.covs"]
+    return locs, X, th, z, lp, Xp
+
+
+def test_c5_predict_split_two_ranks(tmp_path):
+    """C5 as BASELINE states it: n_train = m_pred = 8192 with the prediction locations split over
+    2 ranks (cocons_amd.shard.sharded_predict_core with real fit handles; both ranks share this
+    box's GPU, gloo carries the final gather).  Must equal the unsharded call: each prediction
+    row's solve is independent of the other rows (R/predict.R:150-173)."""
+    import torch.multiprocessing as mp
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    world = 2
+    mp.spawn(_predict_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), "pred%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(res[0], res[1])
+    locs, X, th, z, lp, Xp = _c5_problem()
+    st, qf = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS).predict_core(th, lp, Xp)
+    assert np.max(np.abs(res[0][0] - st)) <= 1e-10 * np.max(np.abs(st))
+    assert np.max(np.abs(res[0][1] - qf)) <= 1e-10 * np.max(np.abs(qf))

@@ -464,3 +464,23 @@ def test_spatial_sort_is_transparent(oracle, monkeypatch):
     assert np.array_equal(res["0"][2], res["1"][2])          # same (unsorted) path either way
     want = oracle.cocoSim_dense(th, locs, X, wl.SMOOTH_LIMITS, E, type="diff")
     assert np.max(np.abs(res["1"][2] - want)) < 1e-10 * np.max(np.abs(want))
+
+
+def test_device_matern_against_mpmath_grid(golden_dir):
+    """The DEVICE Bessel/Matern routine (Temme series / CF2 in A-B product form / rgamma table /
+    exp2 -- a different algorithmic form from the oracle's) evaluated pointwise on the 468-point
+    mpmath grid: nu 0.25..3.3, x 2.3e-16..705.99, including the x = 2 switch."""
+    import json
+    from cocons_amd import _lib
+    rows = json.load(open(os.path.join(golden_dir, "besselk_grid.json")))
+    nu = np.array([r["nu"] for r in rows])
+    x = np.array([r["x"] for r in rows])
+    want = np.array([r["matern"] for r in rows])
+    out = np.empty_like(x)
+    L = _lib.load()
+    _lib.check(L.cocons_debug_matern(x.size, nu.ctypes.data_as(_lib.c_dp), x.ctypes.data_as(_lib.c_dp),
+                                     out.ctypes.data_as(_lib.c_dp)), "cocons_debug_matern")
+    ok = want > 1e-290          # below that the product underflows gradually in both
+    rel = np.abs(out[ok] - want[ok]) / want[ok]
+    assert rel.max() < 1e-13, (rel.max(), nu[ok][rel.argmax()], x[ok][rel.argmax()])
+    assert np.all(np.abs(out[~ok] - want[~ok]) < 1e-290)
