@@ -53,6 +53,7 @@ SIGNATURES = {
     "cocons_chol_solve": (c_int, [c_int, c_dp, c_int, c_dp, c_dp, c_dp, c_dp]),
     "cocons_fit_profile": (c_int, [c_vp, c_dp, c_dp, c_int, c_dp]),
     "cocons_mfma_f64_probe": (c_int, [c_int, c_dp]),
+    "cocons_mfma_f64_probe_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_dp]),
     "cocons_vfma_f64_probe": (c_int, [c_int, c_dp]),
     "cocons_debug_matern": (c_int, [c_int, c_dp, c_dp, c_dp]),
     "cocons_shard_begin": (c_int, [c_vp, c_dp, c_dp, c_int, c_int]),

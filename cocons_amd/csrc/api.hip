@@ -66,6 +66,7 @@ extern "C" double cocons_sumsmoothlone(const double *x, int len, double lambda, 
 
 // ---------------------------------------------------------------------------
 // theta -> kernel arguments, exactly the host-side preamble of the reference functions
+enum { ENGINE_ABORT = -5 };
 enum { TH_SD = 0, TH_SCALE = 1, TH_ANISO = 2, TH_TILT = 3, TH_SMOOTH = 4, TH_NUGGET = 5 };
 
 struct ModeSel {
@@ -118,7 +119,6 @@ static ModeSel select_mode(const double *theta, int p, const double *smooth_limi
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-static bool lookahead_enabled();
 
 // ---------------------------------------------------------------------------
 struct cocons_fit {
@@ -149,8 +149,11 @@ struct cocons_fit {
     size_t xbuf_bytes;
     bool xbuf_own;
     hipEvent_t ev[8];
-    hipStream_t stream2;          // panel stream of the look-ahead schedule
-    std::vector<hipEvent_t> *la_ev;
+    hipStream_t stream2;          // stream the resident diagonal-tile engine is launched on
+    hipEvent_t ev_eng;            // orders the engine launch behind the reset of its flag words
+    unsigned *dflags;             // 2 * flags_cap words: in[t], out[t] (see launch_potrf_engine)
+    int flags_cap;
+    bool engine_ok;               // false: plain schedule (batch slots; or after a hand-off timed out)
     double upd_flops;             // algorithmic flops of the event-timed trailing updates (profile runs)
     // host copies of the inputs + lazily created clones: the slots of cocons_neg2loglik_batch
     std::vector<double> *h_locs, *h_X, *h_z;
@@ -187,13 +190,15 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
     if (f->pid == getpid()) {
         hipSetDevice(f->device);
         if (f->stream) hipStreamSynchronize(f->stream);
+        if (f->stream2) hipStreamSynchronize(f->stream2);
         hipFree(f->dX); hipFree(f->dlocs); hipFree(f->dz); hipFree(f->dxb); hipFree(f->dloc);
         hipFree(f->dA); hipFree(f->dinv); hipFree(f->dinfo); hipFree(f->dout);
         hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad); hipFree(f->dred);
         if (f->xbuf_own) { hipFree(f->xbuf[0]); hipFree(f->xbuf[1]); }
         hipHostFree(f->hout); hipHostFree(f->hinfo);
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
-        if (f->la_ev) { for (auto e : *f->la_ev) hipEventDestroy(e); delete f->la_ev; }
+        if (f->ev_eng) hipEventDestroy(f->ev_eng);
+        hipFree(f->dflags);
         if (f->slots) { for (auto c : *f->slots) cocons_fit_destroy(c); delete f->slots; f->slots = nullptr; }
         if (f->unsorted) { cocons_fit_destroy(f->unsorted); f->unsorted = nullptr; }
         if (f->stream2) hipStreamDestroy(f->stream2);
@@ -222,6 +227,7 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     f->smooth_limits[0] = smooth_limits[0];
     f->smooth_limits[1] = smooth_limits[1];
     f->world = 1;
+    f->engine_ok = true;
 #define CK(expr)                                                                  \
     do {                                                                          \
         hipError_t e__ = (expr);                                                  \
@@ -321,19 +327,15 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     CK(hipStreamSynchronize(f->stream));      // the staging vectors above go out of scope
     CK(hipMalloc(&f->dloc, (size_t)LOCP_FIELDS * f->npad * sizeof(double)));
     CK(hipMalloc(&f->dinv, 2 * 8 * 256 * sizeof(double)));
-    CK(hipMalloc(&f->dinfo, sizeof(int)));
+    CK(hipMalloc(&f->dinfo, 2 * sizeof(int)));      // [0] failing minor (atomicMin), [1] abort word of the engine hand-offs
     int nr_max = r + (q > p ? q : p);
     f->out_cap = (size_t)(1 + nr_max * nr_max) * (size_t)(f->nt + 2);
     CK(hipMalloc(&f->dout, f->out_cap * sizeof(double)));
     CK(hipHostMalloc(&f->hout, f->out_cap * sizeof(double)));
-    CK(hipHostMalloc(&f->hinfo, sizeof(int)));
+    CK(hipHostMalloc(&f->hinfo, 2 * sizeof(int)));
     for (auto &e : f->ev) CK(hipEventCreate(&e));
-    {
-        int lo = 0, hi = 0;
-        CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        CK(hipStreamCreateWithPriority(&f->stream2, hipStreamNonBlocking, hi));
-    }
-    f->la_ev = new std::vector<hipEvent_t>();
+    CK(hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&f->ev_eng, hipEventDisableTiming));
     if (fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
 #undef CK
     return f;
@@ -441,108 +443,142 @@ static FactorView main_view(cocons_fit *f)
     return v;
 }
 
-static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s, bool no_lds = false)
+static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
 {
     const int nt = v.nt, mt = v.mt;
     double *A = v.A;
     const size_t lda = v.lda;
     double *q0 = f->dinv, *q1 = f->dinv + 8 * 256;
     launch_potrf_tile(A, lda, k * TILE, q0, f->dinfo, s);
-    launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, mt * TILE, q0, s, no_lds);
+    launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, mt * TILE, q0, s);
     if (k + 1 < nt) {
         launch_update(A, lda, k * TILE, TILE, k + 1, mt, k + 1, k + 2, true, s);
         launch_potrf_tile(A, lda, (k + 1) * TILE, q1, f->dinfo, s);
-        launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, mt * TILE, q1, s, no_lds);
+        launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, mt * TILE, q1, s);
     }
 }
 
-static bool lookahead_enabled()
+// COCONS_ENGINE: 1 (default) = diagonal tiles are factored by the resident engine while the trailing
+// update runs; 0 = every kernel in order on one stream
+static bool engine_enabled()
 {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("COCONS_LOOKAHEAD");
-        v = e ? atoi(e) : 0;   // experimental, off by default
+        const char *e = getenv("COCONS_ENGINE");
+        v = e ? atoi(e) : 1;
     }
     return v != 0;
 }
 
+// one trailing-update launch (tile columns [t0, t1) of the trapezoid below (t0, t0)), optionally
+// bracketed by timing events (profile runs): appended as (start, stop)
 static void timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int t0, int t1, hipStream_t s,
-                         std::vector<hipEvent_t> *ev_upd)
+                         std::vector<hipEvent_t> *ev_upd, unsigned *sig, int sig_tile)
 {
     const int mt = v.mt;
+    if (t1 <= t0) return;
     if (ev_upd) {
-        // algorithmic flops of this launch: lower triangle of the trailing block of order m
-        // (real columns only) times K, plus the rhs rows:  K m (m+1) + 2 K r m
-        double m = (double)f->n - (double)t0 * TILE;
-        if (m < 0) m = 0;
-        double K = (double)kw * TILE;
-        f->upd_flops += K * m * (m + 1.0) + 2.0 * K * (double)f->nrhs_cur * m;
         hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a, s);
-        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s);
+        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile);
         hipEventRecord(b, s);
         ev_upd->push_back(a); ev_upd->push_back(b);
     } else {
-        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s);
+        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile);
     }
 }
 
-static void factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t> *ev_upd)
+// algorithmic flops of the trailing update of block k (tile columns [t0, nt)): lower triangle of the
+// trailing block of order m (real columns only) times K, plus the rhs rows:  K m (m+1) + 2 K r m
+static void count_update_flops(cocons_fit *f, int kw, int t0)
+{
+    double m = (double)f->n - (double)t0 * TILE;
+    if (m < 0) m = 0;
+    const double K = (double)kw * TILE;
+    f->upd_flops += K * m * (m + 1.0) + 2.0 * K * (double)f->nrhs_cur * m;
+}
+
+// Bordered right-looking factorisation, outer block = 2 tiles (256 columns).
+//
+// Plain schedule (COCONS_ENGINE=0, or fewer than 5 tiles), everything on the main stream:
+//   potrf(t) | trsm(t) | in-panel update of tile column t+1 | potrf(t+1) | trsm(t+1) | trailing update
+//
+// Engine schedule: the diagonal tiles 2 .. nt-1 are factored by ONE resident workgroup
+// (potrf_engine_kernel, launched once per factorisation on the second stream, owning a CU) as soon
+// as the kernel that finishes a diagonal tile has published it; the main stream runs, per block k
+// with t = k + 2:
+//   Ua(k): first half (by area) of the trailing update with panel k, starting with tile column t;
+//          its three workgroups inside diagonal tile t raise in[t]      -> engine factors tile t
+//   trsm(t)   : waits for out[t] (normally long set: the engine worked while Ua ran)
+//   in-panel update of tile column t+1 with column t; raises in[t+1]    -> engine factors tile t+1
+//   Ub(k): second half of the trailing update                           (engine works meanwhile)
+//   trsm(t+1) : waits for out[t+1]
+// So the two 30 us single-workgroup diagonal factorisations per block leave the critical path; the
+// main stream needs no events and issues the same number of launches as the plain schedule.
+static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t> *ev_upd)
 {
     const int nt = v.nt, mt = v.mt;
     hipStream_t M = f->stream;
-    if (!lookahead_enabled() || nt <= 4) {
+    if (!engine_enabled() || !f->engine_ok || nt <= 4) {
         for (int k = 0; k < nt; k += 2) {
             panel_ops(f, v, k, M);
-            if (k + 2 < nt) timed_update(f, v, k, 2, k + 2, nt, M, ev_upd);
+            if (k + 2 < nt) {
+                if (ev_upd) count_update_flops(f, 2, k + 2);
+                timed_update(f, v, k, 2, k + 2, nt, M, ev_upd, nullptr, -1);
+            }
         }
-        return;
+        return 0;
     }
-    hipStream_t P = f->stream2;
-    std::vector<hipEvent_t> &ev = *f->la_ev;
-    const size_t need = (size_t)nt + 4;
-    while (ev.size() < need) {
-        hipEvent_t e;
-        hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        ev.push_back(e);
+    if (f->flags_cap < nt) {
+        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->dflags) { HIPCHK(hipFree(f->dflags)); f->dflags = nullptr; }
+        f->flags_cap = round_up(nt + 8, 64);
+        HIPCHK(hipMalloc(&f->dflags, 2 * (size_t)f->flags_cap * sizeof(unsigned)));
     }
-    // Look-ahead pays while the trailing update is longer than the panel chain it hides; in
-    // the tail the chain is the critical path either way and the plain schedule has the
-    // shorter chain (LDS panel solve, no split update).  Switch when fewer than `tail`
-    // tile columns remain.
-    static int tail = -1;
-    if (tail < 0) {
-        const char *e = getenv("COCONS_LOOKAHEAD_TAIL");
-        tail = e ? atoi(e) : 20;
-    }
-    size_t ne = 0;
+    unsigned *in = f->dflags, *out = f->dflags + f->flags_cap;
+    unsigned *abort_word = (unsigned *)(f->dinfo + 1);
+    HIPCHK(hipMemsetAsync(f->dflags, 0, 2 * (size_t)f->flags_cap * sizeof(unsigned), M));
+    HIPCHK(hipEventRecord(f->ev_eng, M));
+    HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
+    launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, abort_word, f->stream2);
     panel_ops(f, v, 0, M);
-    int k = 0;
-    for (; k + 2 < nt && (nt - k) > tail; k += 2) {
-        const int u1_end = (k + 4 < nt) ? k + 4 : nt;
-        // U1: the next block's tile columns, then hand them to the panel stream
-        launch_update(v.A, v.lda, k * TILE, 2 * TILE, k + 2, mt, k + 2, u1_end, true, M);
-        hipEvent_t e_u1 = ev[ne++];
-        hipEventRecord(e_u1, M);
-        hipStreamWaitEvent(P, e_u1, 0);
-        panel_ops(f, v, k + 2, P, true);
-        hipEvent_t e_p = ev[ne++];
-        hipEventRecord(e_p, P);
-        // U2: the rest of the trailing matrix, concurrent with panel(k+2)
-        if (k + 4 < nt) timed_update(f, v, k, 2, k + 4, nt, M, ev_upd);
-        hipStreamWaitEvent(M, e_p, 0);
+    for (int k = 0; k + 2 < nt; k += 2) {
+        const int t = k + 2;
+        // split the trapezoid of tile columns [t, nt) (heights mt - j) into two halves of equal area;
+        // the first half always holds the block's own two tile columns
+        int split = nt;
+        {
+            long long total = 0, acc = 0;
+            for (int j = t; j < nt; ++j) total += mt - j;
+            for (int j = t; j < nt; ++j) {
+                acc += mt - j;
+                if (2 * acc >= total) { split = j + 1; break; }
+            }
+            if (split < t + 2) split = t + 2;
+            if (split > nt) split = nt;
+            static int nosplit = -1;
+            if (nosplit < 0) { const char *e = getenv("COCONS_NOSPLIT"); nosplit = e ? atoi(e) : 0; }
+            if (nosplit) split = nt;
+        }
+        if (ev_upd) count_update_flops(f, 2, t);
+        timed_update(f, v, k, 2, t, split, M, ev_upd, in + t, t);
+        launch_trsm_tile(v.A, v.lda, t * TILE, (t + 1) * TILE, mt * TILE, f->dinv + (size_t)(t & 1) * 2048, M,
+                         out + t, abort_word);
+        if (t + 1 < nt)
+            launch_update(v.A, v.lda, t * TILE, TILE, t + 1, mt, t + 1, t + 2, true, M, in + t + 1, t + 1);
+        timed_update(f, v, k, 2, split, nt, M, ev_upd, nullptr, -1);
+        if (t + 1 < nt)
+            launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, (t + 2) * TILE, mt * TILE,
+                             f->dinv + (size_t)((t + 1) & 1) * 2048, M, out + t + 1, abort_word);
     }
-    // tail: panel(k) is factored; plain right-looking steps from here
-    for (; k < nt; k += 2) {
-        if (k + 2 < nt) timed_update(f, v, k, 2, k + 2, nt, M, ev_upd);
-        if (k + 2 < nt) panel_ops(f, v, k + 2, M);
-    }
+    return 0;
 }
 
 static int reset_info(cocons_fit *f)
 {
     HIPCHK(hipMemsetAsync(f->dinfo, 0x7f, sizeof(int), f->stream));
+    HIPCHK(hipMemsetAsync(f->dinfo + 1, 0, sizeof(int), f->stream));
     return 0;
 }
 
@@ -558,12 +594,12 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
     assemble_sigma(f, theta, 0, 0, f->npad);
     assemble_rhs(f, mean, use_trend, xb, nxb, 0, f->npad);
     if (stage_events) hipEventRecord(f->ev[1], f->stream);
-    factorize(f, main_view(f), ev_upd);
+    if (int rc = factorize(f, main_view(f), ev_upd)) return rc;
     if (stage_events) hipEventRecord(f->ev[2], f->stream);
     launch_finalize(f->dA, f->lda, f->n, f->npad, nrhs, f->dout, f->stream);
     HIPCHK(hipMemcpyAsync(f->hout, f->dout, (size_t)(1 + nrhs * nrhs) * sizeof(double),
                           hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, f->stream));
     if (stage_events) hipEventRecord(f->ev[3], f->stream);
     HIPCHK(hipGetLastError());
     return 0;
@@ -571,13 +607,26 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
 
 static int info_status(cocons_fit *f)
 {
-    int info = *f->hinfo;
+    if (f->hinfo[1] != 0)
+        return fail(ENGINE_ABORT, "hand-off between the diagonal-tile engine and the main stream timed out");
+    int info = f->hinfo[0];
     if (info != 0x7f7f7f7f) {
         if (info > f->n) info = f->n;   // failure reported inside the identity padding cannot happen; clamp anyway
         g_err = "leading minor not positive";
         return info;
     }
     return 0;
+}
+
+// The engine could not be scheduled in time (another process or stream kept every CU busy, or a
+// profiler serialises kernels): this fit falls back to the plain schedule for good and the caller
+// repeats the operation once.
+static bool engine_retry(cocons_fit *f, int st)
+{
+    if (st != ENGINE_ABORT || !f->engine_ok) return false;
+    f->engine_ok = false;
+    hipStreamSynchronize(f->stream2);
+    return true;
 }
 
 static const double LOG_2PI = 1.8378770664093454835606594728112;
@@ -589,9 +638,14 @@ extern "C" int cocons_neg2loglik_dense(cocons_fit *f, const double *theta, const
     if (int rc = fit_check(f)) return rc;
     if (!theta || !mean || !sum_logliks) return fail(-1, "cocons_neg2loglik_dense: null argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_dense: fit has no z");
-    if (int rc = enqueue_eval(f, theta, mean, true, nullptr, 0, nullptr, false)) return rc;
-    HIPCHK(hipStreamSynchronize(f->stream));
-    if (int st = info_status(f)) return st;
+    for (;;) {
+        if (int rc = enqueue_eval(f, theta, mean, true, nullptr, 0, nullptr, false)) return rc;
+        HIPCHK(hipStreamSynchronize(f->stream));
+        int st = info_status(f);
+        if (engine_retry(f, st)) continue;
+        if (st) return st;
+        break;
+    }
     dense_collect(f, sum_logliks, parts);
     return 0;
 }
@@ -641,6 +695,11 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
         if (!c) { (void)hipGetLastError(); break; }
         f->slots->push_back(c);
     }
+    // several evaluations in flight already hide each other's panel chains; the resident engine is
+    // for an evaluation that has the GPU to itself
+    const bool engine_saved = f->engine_ok;
+    if (S > 1) f->engine_ok = false;
+    for (auto c : *f->slots) c->engine_ok = false;
     if (S > (int)f->slots->size() + 1) S = (int)f->slots->size() + 1;
     for (int i = 0; i < nb; ++i) { values[i] = NAN; status[i] = -1; }   // never left unwritten
     std::vector<int> pending(S, -1);
@@ -671,6 +730,7 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
     }
     for (int s = 0; s < S; ++s)
         if (int rc = collect(s)) rc_all = rc_all ? rc_all : rc;
+    f->engine_ok = engine_saved;
     return rc_all;
 }
 
@@ -750,9 +810,14 @@ extern "C" int cocons_neg2loglik_profile(cocons_fit *f, const double *theta, dou
     if (int rc = fit_check(f)) return rc;
     if (!theta || !sum_logliks) return fail(-1, "cocons_neg2loglik_profile: null argument");
     if (f->r < 1 || f->q < 1) return fail(-1, "cocons_neg2loglik_profile: fit needs z and x_betas");
-    if (int rc = enqueue_eval(f, theta, nullptr, false, f->dxb, f->q, nullptr, false)) return rc;
-    HIPCHK(hipStreamSynchronize(f->stream));
-    if (int st = info_status(f)) return st;
+    for (;;) {
+        if (int rc = enqueue_eval(f, theta, nullptr, false, f->dxb, f->q, nullptr, false)) return rc;
+        HIPCHK(hipStreamSynchronize(f->stream));
+        int st = info_status(f);
+        if (engine_retry(f, st)) continue;
+        if (st) return st;
+        break;
+    }
     return profile_tail(f, f->q, (double)f->n, false, sum_logliks, parts);   // R/neg2loglikelihood.R:155-160
 }
 
@@ -761,9 +826,14 @@ extern "C" int cocons_neg2loglik_reml(cocons_fit *f, const double *theta, int ra
     if (int rc = fit_check(f)) return rc;
     if (!theta || !sum_logliks) return fail(-1, "cocons_neg2loglik_reml: null argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_reml: fit has no z");
-    if (int rc = enqueue_eval(f, theta, nullptr, false, f->dX, f->p, nullptr, false)) return rc;
-    HIPCHK(hipStreamSynchronize(f->stream));
-    if (int st = info_status(f)) return st;
+    for (;;) {
+        if (int rc = enqueue_eval(f, theta, nullptr, false, f->dX, f->p, nullptr, false)) return rc;
+        HIPCHK(hipStreamSynchronize(f->stream));
+        int st = info_status(f);
+        if (engine_retry(f, st)) continue;
+        if (st) return st;
+        break;
+    }
     return profile_tail(f, f->p, (double)(f->n - rank), true, sum_logliks, parts);   // :283-287
 }
 
@@ -799,7 +869,9 @@ extern "C" int cocons_fit_profile(cocons_fit *f, const double *theta, const doub
     ms[6] = acc[6] / reps;
     ms[4] = acc[5] > 0 ? ms[6] / acc[5] : 0.0;
     ms[7] = f->upd_flops;
-    return info_status(f);
+    int st = info_status(f);
+    if (engine_retry(f, st)) return cocons_fit_profile(f, theta, mean, reps, ms);
+    return st;
 }
 
 // ---------------------------------------------------------------------------
@@ -953,10 +1025,12 @@ extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const do
     launch_row_reduce(f->dA, f->lda, n, f->npad, f->npad + 1, m, f->dstoch, f->dquad, f->dred, s);
     HIPCHK(hipMemcpyAsync(stochastic, f->dstoch, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(quadform, f->dquad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
-    return info_status(f);
+    int st = info_status(f);
+    if (engine_retry(f, st)) return cocons_predict_dense(f, theta, mean, z_col, m, locs_pred, X_pred, stochastic, quadform);
+    return st;
 }
 
 // ---------------------------------------------------------------------------
@@ -1011,13 +1085,14 @@ extern "C" int cocons_sim_dense(cocons_fit *f, const double *theta, const double
         factorize(f, main_view(f), nullptr);
         launch_trmm_lower(f->dA, f->lda, n, dE, n, nsim, dtr, dY, n, s);
         CKS(hipMemcpyAsync(out, dY, (size_t)n * nsim * sizeof(double), hipMemcpyDeviceToHost, s));
-        CKS(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+        CKS(hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         CKS(hipGetLastError());
         CKS(hipStreamSynchronize(s));
 #undef CKS
         rc = info_status(f);
     } while (0);
     hipFree(dE); hipFree(dY); hipFree(dtr);
+    if (engine_retry(f, rc)) return cocons_sim_dense(f, theta, mean, classic, nsim, iiderrors, out);
     return rc;
 }
 
@@ -1124,7 +1199,7 @@ extern "C" int cocons_sim_cond_dense(cocons_fit *f, const double *theta, const d
         // fields = L_S E + tmp_mu with L_S = lower-right block of the joint factor
         launch_trmm_lower(dJ + (size_t)npad + (size_t)npad * ldj, ldj, m, dE, m, nsim, dmu, dY, m, s);
         CKS(hipMemcpyAsync(out, dY, (size_t)m * nsim * sizeof(double), hipMemcpyDeviceToHost, s));
-        CKS(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+        CKS(hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         CKS(hipGetLastError());
         CKS(hipStreamSynchronize(s));
 #undef CKS
@@ -1133,6 +1208,8 @@ extern "C" int cocons_sim_cond_dense(cocons_fit *f, const double *theta, const d
     } while (0);
     hipFree(dJ); hipFree(dXp); hipFree(dlp); hipFree(dlu); hipFree(dlocp); hipFree(dlocu);
     hipFree(dE); hipFree(dY); hipFree(dmu); hipFree(dst); hipFree(dq); hipFree(dred);
+    if (engine_retry(f, rc))
+        return cocons_sim_cond_dense(f, theta, mean, z_col, m, locs_pred, X_pred, locs_unobs, nsim, iiderrors, out);
     return rc;
 }
 
@@ -1146,6 +1223,7 @@ extern "C" int cocons_chol_solve(int n, const double *Ain, int nrhs, const doubl
     double sl[2] = {0.5, 0.5};
     cocons_fit *f = cocons_fit_create(n, 1, 0, 0, locs.data(), X.data(), nullptr, nullptr, sl, -1);
     if (!f) return -1;
+    f->engine_ok = false;     // one-shot handle whose input is uploaded once: plain schedule
     int rc = 0;
     do {
         if ((rc = fit_alloc_matrix(f, nrhs > 0 ? nrhs : 1))) break;
@@ -1165,7 +1243,7 @@ extern "C" int cocons_chol_solve(int n, const double *Ain, int nrhs, const doubl
         e = hipMemcpyAsync(hostA.data(), f->dA, hostA.size() * sizeof(double), hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) { rc = fail(-100, "cocons_chol_solve: %s", hipGetErrorString(e)); break; }
         hipMemcpyAsync(f->hout, f->dout, sizeof(double), hipMemcpyDeviceToHost, s);
-        hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, s);
+        hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) { rc = fail(-100, "cocons_chol_solve: %s", hipGetErrorString(e)); break; }
         if ((rc = info_status(f))) break;
@@ -1338,7 +1416,7 @@ extern "C" int cocons_shard_finish(cocons_fit *f, double *partial, int *info)
     }
     if (cnt > 0)
         HIPCHK(hipMemcpyAsync(f->hout, f->dout, (size_t)cnt * len * sizeof(double), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));
     for (int i = 0; i < len; ++i) partial[i] = 0.0;
     for (int c = 0; c < cnt; ++c)
@@ -1389,6 +1467,35 @@ extern "C" int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamDestroy(ps));
     HIPCHK(hipFree(d));
+    return 0;
+}
+
+// diagnostic (COCONS_UPD_STAMP=1): out3 = {in-kernel clock of the update kernels in GHz, mean shader
+// cycles per workgroup, workgroups} since the last call; resets the counters
+extern "C" int cocons_debug_upd_clock(double *out3)
+{
+    unsigned long long *d = upd_stamp_buffer();
+    if (!d || !out3) return fail(-1, "cocons_debug_upd_clock: stamps are off (set COCONS_UPD_STAMP=1)");
+    unsigned long long h[3];
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(d, 0, sizeof h));
+    out3[0] = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+    out3[1] = h[2] ? (double)h[0] / (double)h[2] : 0.0;
+    out3[2] = (double)h[2];
+    return 0;
+}
+
+// extended probe: see run_mfma_f64_probe_ex (chol.hip) for the meaning of out[0..3]
+extern "C" int cocons_mfma_f64_probe_ex(int blocks_per_cu, int nacc, int form, int iters, int gap_us, int reps, double *out4)
+{
+    if (!out4 || blocks_per_cu < 1 || blocks_per_cu > 8 || (nacc != 4 && nacc != 8 && nacc != 16) || form < 0 || form > 3 ||
+        iters < 1 || reps < 1 || gap_us < 0)
+        return fail(-1, "cocons_mfma_f64_probe_ex: bad argument");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, 0));
+    if (run_mfma_f64_probe_ex(prop.multiProcessorCount * blocks_per_cu, nacc, form, iters, gap_us, reps, out4))
+        return fail(-100, "cocons_mfma_f64_probe_ex: HIP error");
     return 0;
 }
 

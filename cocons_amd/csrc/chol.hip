@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 #include "kernels.h"
 
 namespace cocons {
@@ -217,13 +219,10 @@ __constant__ int c_tri_ib[36] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5,
 //   S: symmetric update of the remaining blocks; wave 0 takes block (jb+1,jb+1) first and
 //      factors it in registers (potrf16_regs) while waves 1..7 finish the other updates.
 // Also exports, per diagonal block, the Q operands (4 x 64 lanes) the panel solve needs.
-__global__ void __launch_bounds__(512)
-potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
+__device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, double *q_out, int *info, double *smem)
 {
-    extern __shared__ double smem[];
     // lower-packed image: block (ib,kb), ib >= kb, at (ib (ib+1)/2 + kb) * 256  (72 KB), plus the
-    // Q operands of the CURRENT diagonal block (2 KB): 74 KB in all, so the kernel fits on a CU
-    // beside four resident update workgroups (look-ahead without reserving CUs)
+    // Q operands of the CURRENT diagonal block (2 KB): 74 KB in all
     double *S = smem;
     double *QS = smem + 36 * 256;
 #define SB(ib, kb) (S + ((ib) * ((ib) + 1) / 2 + (kb)) * 256)
@@ -322,16 +321,102 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
 #undef SB
 }
 
+__global__ void __launch_bounds__(512)
+potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
+{
+    extern __shared__ double smem[];
+    potrf_tile_body(A, lda, c0, q_out, info, smem);
+}
+
+// ---------------------------------------------------------------------------
+// Hand-offs between workgroups of DIFFERENT kernels that are resident at the same time (the
+// diagonal-tile engine below and the update / panel-solve kernels of the main stream).  Protocol
+// (agent scope; per-XCD L2s are not coherent and a CU's L1 is never refreshed by other CUs):
+//   producer: every storing wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane:
+//             release fence (L2 write-back) -> drain -> relaxed agent-scope atomic on the flag word
+//   consumer: ONE lane polls the flag relaxed (s_sleep between polls), then ONE acquire fence (L1
+//             invalidate), drain, workgroup barrier, then plain loads.
+// Every spin is bounded: after ENGINE_TIMEOUT_TICKS of the 100 MHz constant clock the waiter sets the
+// abort word and every party leaves; the host then repeats the factorisation on the plain schedule
+// instead of hanging the GPU.  A legitimate wait lasts at most one trailing-update launch (< 1 ms).
+#define ENGINE_TIMEOUT_TICKS 25000000ull    // 250 ms
+
+__device__ __forceinline__ void signal_add(unsigned *word)
+{
+    // caller: all storing waves have executed s_waitcnt vmcnt(0) and passed a barrier; one lane calls
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one lane; returns false on abort / timeout
+__device__ __forceinline__ bool wait_ge(unsigned *word, unsigned need, unsigned *abort_word)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > ENGINE_TIMEOUT_TICKS) {
+            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
+// Diagonal-tile engine: ONE persistent workgroup that factors the diagonal tiles t0 .. nt-1 of a
+// factorisation, each as soon as the main stream has finished updating it (flag in[t] reaches
+// `need`), and publishes the factor (flag out[t]).  It asks for the whole LDS of a CU, so no update
+// workgroup shares its CU: the fp64 pivot chains of potrf16_regs run on the same DP units as the
+// fp64 MFMAs and take 3x as long beside them (measured).  Being resident, it needs no stream
+// dependency and no room to be found mid-factorisation.
+struct EngineArgs {
+    double *A; size_t lda;
+    int t0, nt;
+    double *dinv;            // 2 x 2048 doubles, parity of the tile index
+    int *info;
+    unsigned *in, *out;      // per-tile flag words
+    unsigned *abort_word;
+    unsigned need;
+};
+
+__global__ void __launch_bounds__(512)
+potrf_engine_kernel(EngineArgs e)
+{
+    extern __shared__ double smem[];
+    int *okp = (int *)(smem + 37 * 256);
+    const int tid = threadIdx.x;
+    for (int t = e.t0; t < e.nt; ++t) {
+        if (tid == 0) *okp = wait_ge(e.in + t, e.need, e.abort_word) ? 1 : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (*okp == 0) return;
+        potrf_tile_body(e.A, e.lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) signal_add(e.out + t);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Panel solve: rows [r0, r1) of block column c0:  X <- X * L(c0)^-T.
 // One workgroup = 64 rows; each wave owns a 16 x 128 strip held in registers (8 blocks).
 // LDS holds the 36 lower 16x16 blocks of L and the 8 x 4 Q operands.
 __global__ void __launch_bounds__(256)
-trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin)
+trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsigned *wait_word, unsigned *abort_word)
 {
     __shared__ double SL[36 * 256];
     __shared__ double QS[8 * 256];
+    __shared__ int ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wait_word) {     // the diagonal tile comes from the engine, which may still be at work
+        if (tid == 0) ok = wait_ge(wait_word, 1u, abort_word) ? 1 : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!ok) return;
+    }
     {
         int i = tid & 15, k = tid >> 4, b = 0;
         for (int ib = 0; ib < 8; ++ib)
@@ -363,48 +448,9 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin)
 }
 
 // ---------------------------------------------------------------------------
-// Panel solve without LDS: the factor's 16x16 blocks and the Q operands are read straight
-// from global memory (L2-resident: every workgroup reads the same 72 KB) in blk layout.
-// Needs only registers, so its waves can slot in beside resident update workgroups -- this
-// is the variant the look-ahead schedule runs on the panel stream.
-__global__ void __launch_bounds__(256, 2)
-trsm_tile_l2_kernel(double *A, size_t lda, int c0, int r0, const double *qin)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rs = r0 + 64 * blockIdx.x + 16 * wave;
-    d4 B[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) B[j] = glb_blk(A, lda, rs, c0 + 16 * j, lane);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        d4 L = glb_blk(A, lda, c0 + 16 * j, c0 + 16 * j, lane);
-        // the strictly-upper part of a diagonal block is not stored as zero in global memory
-        // only the lower part is meaningful: trsm16 reads L[s] rows >= columns via MFMA, and
-        // rows above the diagonal must contribute nothing -> mask them
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if ((lane & 15) < 4 * r + (lane >> 4)) L[r] = 0.0;
-        double Q[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) Q[s] = qin[j * 256 + s * 64 + lane];
-        trsm16(B[j], L, Q);
-        d4 NX = -B[j];
-#pragma unroll
-        for (int jj = j + 1; jj < 8; ++jj) {
-            d4 Lb = glb_blk(A, lda, c0 + 16 * jj, c0 + 16 * j, lane);
-            blk_mma(B[jj], NX, Lb);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c0 + 16 * j, lane, B[j]);
-}
-
-// ---------------------------------------------------------------------------
-// Trailing update: C(ti,tj) -= P(ti,:) P(tj,:)^T over K panel columns.  TM x TM tiles
-// (TM = 128: 4 waves x 64x64 = 4x4 MFMA blocks each, the throughput shape; TM = 64:
-// 4 waves x 32x32, four times as many workgroups -- used where the grid is too small to
-// fill 256 CUs: the narrow in-panel update, the look-ahead update and the late steps).
-// Operand tiles stream through LDS in chunks of KC=16 panel columns, register-staged
+// Trailing update: C(ti,tj) -= P(ti,:) P(tj,:)^T over K panel columns.  TM x TM tiles, 4 waves x
+// (TM/2 x TM/2); instantiated with TM = 64 (each wave 2 x 2 MFMA blocks, up to 8 workgroups per CU).
+// Operand tiles stream through LDS in chunks of KC panel columns (KC = 8: 20 KB), register-staged
 // double buffering, one barrier per chunk.
 
 struct UpdArgs {
@@ -414,11 +460,14 @@ struct UpdArgs {
     int ti0, tj0, lower_only;      // tile indices in units of TM
     int H;                         // lower_only: rows of the trapezoid (ti1 - tj0), 1-D grid over its tiles
     int xcd_swizzle;
+    unsigned *sig; int sig_tile;   // engine hand-off: add 1 to *sig when a 64-tile of diagonal 128-tile sig_tile is stored
+    int dbg;                       // diagnostic timing knob (COCONS_UPD_DBG): 1 = no operand staging after chunk 0, 2 = also no C read-modify-write
+    unsigned long long *stamp;     // diagnostic (COCONS_UPD_STAMP=1): += {shader cycles, 100 MHz ticks, 1} per workgroup
     int ptiles, world, rank;       // sharded path: only 128-tile columns whose panel (tj128 / ptiles) is owned
 };
 
-// ROLE only names the instantiation (0 = trailing update, 1 = in-panel / sharded / look-ahead
-// update) so that profiler summaries keep the dominant trailing launches apart from the narrow ones
+// ROLE only names the instantiation (0 = trailing update, 1 = in-panel / sharded update) so that
+// profiler summaries keep the dominant trailing launches apart from the narrow ones
 template <int TM, int KC, int ROLE>
 __global__ void __launch_bounds__(256, (TM == 128 ? 2 : 4))
 update_kernel(UpdArgs a)
@@ -456,6 +505,8 @@ update_kernel(UpdArgs a)
     __shared__ double sJ[2][KC * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
+    unsigned long long st_c = 0, st_r = 0;
+    if (a.stamp) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
 
     // staging map: thread -> (panel column kc, RPT consecutive rows)
     const int kc = tid / TPC, rg = (tid % TPC) * RPT;
@@ -519,18 +570,242 @@ update_kernel(UpdArgs a)
         }
         __syncthreads();
     }
-    // C -= acc
+    // C -= acc (loads first, then stores: see update4_kernel)
     double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi + (lane & 15)) +
                  (size_t)(tj * TM + (TM / 2) * wj + (lane >> 4)) * a.ldc;
+    d4 cv[NB][NB];
 #pragma unroll
     for (int x = 0; x < NB; ++x)
 #pragma unroll
         for (int y = 0; y < NB; ++y)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double *p = Cb + 16 * x + (size_t)(16 * y + 4 * r) * a.ldc;
-                *p -= acc[x][y][r];
+            for (int r = 0; r < 4; ++r) cv[x][y][r] = Cb[16 * x + (size_t)(16 * y + 4 * r) * a.ldc];
+#pragma unroll
+    for (int x = 0; x < NB; ++x)
+#pragma unroll
+        for (int y = 0; y < NB; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cb[16 * x + (size_t)(16 * y + 4 * r) * a.ldc] = cv[x][y][r] - acc[x][y][r];
+    if (a.stamp && tid == 0) {
+        atomicAdd(a.stamp, __builtin_amdgcn_s_memtime() - st_c);
+        atomicAdd(a.stamp + 1, __builtin_amdgcn_s_memrealtime() - st_r);
+        atomicAdd(a.stamp + 2, 1ull);
+    }
+    if (a.sig != nullptr && (ti * TM) / TILE == a.sig_tile && (tj * TM) / TILE == a.sig_tile) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) signal_add(a.sig);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Trailing update on v_mfma_f64_4x4x4_4b_f64.  Measured on MI355X (tools/probe_mfma_ex.py): the
+// 16x16x4 fp64 form sustains one instruction per ~102 cycles per SIMD (48.7 TFLOP/s chip-wide, 62 % of
+// the 78.6 peak, at an unthrottled 2.37 GHz), the 4x4x4 four-block form one per 16 cycles
+// (76.2 TFLOP/s, 97 %).  The four-block form multiplies, per block b, a 4x4 slice of each operand:
+//   D[lane 16 i + 4 b + j] += sum_k A[lane 16 k + 4 b + i] * B[lane 16 k + 4 b + j]
+// (mapping determined with one-hot operands, tools/diag/mfma4_layout.hip), i.e. of the 16 x 16 outer
+// product of two 16-row operand slices it delivers only the four diagonal 4x4 blocks.  The other twelve
+// come from operand slices whose 4-row groups are rotated: rows rotated by s in {0,1} and columns by
+// t in {0,2} give every relative rotation 2t - s mod 4 once, so a 16x16 block of C costs 4 instructions
+// (the same 2048 flop as one 16x16x4) fed by 2 + 2 operand reads.  The rotated slices are plain
+// ds_read_b64 with a different per-lane row offset from the same conflict-free LDS image as before.
+// Per wave and k-step of 4: 32x32 of C = 16 instructions (256 pipe cycles) and 8 LDS reads.
+//
+// Accumulator acc[x][y][s][t], lane (i = l >> 4, b = (l >> 2) & 3, j = l & 3) holds
+//   C(row = 16 x + 4 ((b + s) & 3) + j,  col = 16 y + 4 ((b + 2 t) & 3) + i)   of the wave's 32x32 tile.
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
+
+template <int KC, int ROLE>
+__global__ void __launch_bounds__(256, (KC <= 8 ? 4 : 2))
+update4_kernel(UpdArgs a)
+{
+    constexpr int TM = 64;
+    constexpr int LDT = TM + 16;   // lanes l and l+16 land 128 B apart mod 256 -> conflict-free b64 reads
+    constexpr int TPC = 256 / KC;  // threads per panel column
+    constexpr int RPT = TM / TPC;  // rows staged per thread and side
+    int ti, tj;
+    if (a.lower_only) {
+        // 1-D grid over the tiles (ti >= tj) of the trapezoid, column by column: column j (0-based
+        // from tj0) holds H - j tiles and starts at j H - j (j-1)/2.  No empty workgroups.
+        long long L = blockIdx.x;
+        const double hh = 2.0 * a.H + 1.0;
+        int j = (int)((hh - sqrt(hh * hh - 8.0 * (double)L)) * 0.5);
+        while (j > 0 && (long long)j * a.H - (long long)j * (j - 1) / 2 > L) --j;
+        while ((long long)(j + 1) * a.H - (long long)(j + 1) * j / 2 <= L) ++j;
+        const long long c0 = (long long)j * a.H - (long long)j * (j - 1) / 2;
+        tj = a.tj0 + j;
+        ti = a.tj0 + j + (int)(L - c0);
+    } else {
+        ti = a.ti0 + blockIdx.x;
+        tj = a.tj0 + blockIdx.y;
+    }
+    if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;
+    extern __shared__ double upd4_smem[];      // 4 * KC * LDT doubles (dynamic: KC = 32 needs 80 KB)
+    double (*sI)[KC * LDT] = (double (*)[KC * LDT])upd4_smem;
+    double (*sJ)[KC * LDT] = (double (*)[KC * LDT])(upd4_smem + 2 * KC * LDT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    unsigned long long st_c = 0, st_r = 0;
+    if (a.stamp) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
+
+    // staging map: thread -> (panel column kc, RPT consecutive rows)
+    const int kc = tid / TPC, rg = (tid % TPC) * RPT;
+    const double *gI = a.P + (size_t)(ti * TM + rg) + (size_t)kc * a.ldp;
+    const double *gJ = a.P + (size_t)(tj * TM + rg) + (size_t)kc * a.ldp;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    // two register stages: chunk c+1 (loaded one iteration ago, stored to LDS at the end of this one) and
+    // chunk c+2 (loaded now) -- the operand panels come from L2 / Infinity Cache under full load, where a
+    // load takes far longer than one chunk of MFMAs
+    d2 stI[2][RPT / 2], stJ[2][RPT / 2];
+
+    double acc[2][2][2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[x][y][s][t] = 0.0;
+
+    const int nch = a.K / KC;
+#pragma unroll
+    for (int v = 0; v < RPT / 2; ++v) {
+        stI[0][v] = *(const d2 *)(gI + 2 * v);
+        stJ[0][v] = *(const d2 *)(gJ + 2 * v);
+    }
+    if (nch > 1) {
+#pragma unroll
+        for (int v = 0; v < RPT / 2; ++v) {
+            stI[1][v] = *(const d2 *)(gI + (size_t)KC * a.ldp + 2 * v);
+            stJ[1][v] = *(const d2 *)(gJ + (size_t)KC * a.ldp + 2 * v);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < RPT / 2; ++v) {
+        *(d2 *)(&sI[0][kc * LDT + rg + 2 * v]) = stI[0][v];
+        *(d2 *)(&sJ[0][kc * LDT + rg + 2 * v]) = stJ[0][v];
+    }
+    __syncthreads();
+
+    const int kq = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
+    // Operand slices are read with hand-placed ds_read_b64 (the compiler fuses neighbouring reads into
+    // ds_read2_b64 / ds_read2st64_b64, which run at half the LDS rate) and explicit lgkmcnt waits: the
+    // eight reads of k-step s+1 are in flight while the sixteen instructions of k-step s issue.
+    // LDS byte addresses of this lane's element in the row / column operand images, rotation 0:
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)upd4_smem;
+    const unsigned aR0 = lds0 + 8u * (unsigned)(kq * LDT + 4 * bq + jq + (TM / 2) * wi);
+    const unsigned aR1 = lds0 + 8u * (unsigned)(kq * LDT + 4 * ((bq + 1) & 3) + jq + (TM / 2) * wi);
+    const unsigned aC0 = lds0 + 8u * (unsigned)(2 * KC * LDT + kq * LDT + 4 * bq + jq + (TM / 2) * wj);
+    const unsigned aC2 = lds0 + 8u * (unsigned)(2 * KC * LDT + kq * LDT + 4 * ((bq + 2) & 3) + jq + (TM / 2) * wj);
+#define DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    // issue the eight operand reads of k-step S4 of buffer half `bo` (byte offset of the buffer)
+#define ISSUE_STEP(P, bo, S4)                                                            \
+    do {                                                                                 \
+        const unsigned o_ = (bo);                                                        \
+        DSR64(P[0], aR0 + o_, (S4) * 4 * LDT * 8);                                       \
+        DSR64(P[1], aR1 + o_, (S4) * 4 * LDT * 8);                                       \
+        DSR64(P[2], aC0 + o_, (S4) * 4 * LDT * 8);                                       \
+        DSR64(P[3], aC2 + o_, (S4) * 4 * LDT * 8);                                       \
+        DSR64(P[4], aR0 + o_, (S4) * 4 * LDT * 8 + 128);                                 \
+        DSR64(P[5], aR1 + o_, (S4) * 4 * LDT * 8 + 128);                                 \
+        DSR64(P[6], aC0 + o_, (S4) * 4 * LDT * 8 + 128);                                 \
+        DSR64(P[7], aC2 + o_, (S4) * 4 * LDT * 8 + 128);                                 \
+    } while (0)
+    // wait until at most N LDS operations are outstanding; ties the wait to the registers it guards
+#define WAIT_LGKM(N, P)                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                             \
+                 : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(P[5]), "+v"(P[6]), "+v"(P[7]))
+    // P = { rows x=0 rot 0, rows x=0 rot 1, cols y=0 rot 0, cols y=0 rot 2, then the same for x = y = 1 }
+#define MFMA_STEP(P)                                                                     \
+    do {                                                                                 \
+        _Pragma("unroll") for (int x = 0; x < 2; ++x)                                    \
+        _Pragma("unroll") for (int y = 0; y < 2; ++y)                                    \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                    \
+            acc[x][y][s][t] = MFMA4(P[4 * y + 2 + t], P[4 * x + s], acc[x][y][s][t]);   \
+    } while (0)
+    // the loop body handles two chunks so that the register stages have static indices
+    auto chunk = [&](int ch, d2 (&nI)[RPT / 2], d2 (&nJ)[RPT / 2], d2 (&fI)[RPT / 2], d2 (&fJ)[RPT / 2]) {
+        // nI/nJ: chunk ch+1, already in flight; fI/fJ: receives chunk ch+2
+        const int cur = ch & 1;
+        const unsigned bo = (unsigned)cur * (unsigned)(KC * LDT * 8);
+        double PA[8], PB[8];
+        ISSUE_STEP(PA, bo, 0);
+        if (ch + 2 < nch && !a.dbg) {
+            const double *pI = gI + (size_t)(ch + 2) * KC * a.ldp;
+            const double *pJ = gJ + (size_t)(ch + 2) * KC * a.ldp;
+#pragma unroll
+            for (int v = 0; v < RPT / 2; ++v) {
+                fI[v] = *(const d2 *)(pI + 2 * v);
+                fJ[v] = *(const d2 *)(pJ + 2 * v);
             }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < KC / 4; s4 += 2) {
+            ISSUE_STEP(PB, bo, s4 + 1);
+            WAIT_LGKM(8, PA);
+            MFMA_STEP(PA);
+            // (the last accumulator of the step above is tied in so that the compiler keeps this wait
+            // behind all sixteen instructions of that step)
+            if (s4 + 2 < KC / 4) {
+                ISSUE_STEP(PA, bo, s4 + 2);
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(PB[0]), "+v"(PB[1]), "+v"(PB[2]), "+v"(PB[3]), "+v"(PB[4]),
+                             "+v"(PB[5]), "+v"(PB[6]), "+v"(PB[7]), "+v"(acc[1][1][1][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(PB[0]), "+v"(PB[1]), "+v"(PB[2]), "+v"(PB[3]), "+v"(PB[4]),
+                             "+v"(PB[5]), "+v"(PB[6]), "+v"(PB[7]), "+v"(acc[1][1][1][1]));
+            }
+            MFMA_STEP(PB);
+        }
+        if (ch + 1 < nch && !a.dbg) {
+#pragma unroll
+            for (int v = 0; v < RPT / 2; ++v) {
+                *(d2 *)(&sI[cur ^ 1][kc * LDT + rg + 2 * v]) = nI[v];
+                *(d2 *)(&sJ[cur ^ 1][kc * LDT + rg + 2 * v]) = nJ[v];
+            }
+        }
+        __syncthreads();
+    };
+    for (int ch = 0; ch < nch; ch += 2) {
+        chunk(ch, stI[1], stJ[1], stI[0], stJ[0]);
+        if (ch + 1 < nch) chunk(ch + 1, stI[0], stJ[0], stI[1], stJ[1]);
+    }
+    // C -= acc: all sixteen loads first, then the stores (written as `*p -= acc` the compiler must assume
+    // that a store aliases the next load and serialises sixteen memory round trips)
+    double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi + jq) + (size_t)(tj * TM + (TM / 2) * wj + kq) * a.ldc;
+    if (a.dbg >= 2 && acc[0][0][0][0] != 12345.678) return;
+    double cv[2][2][2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    cv[x][y][s][t] = Cb[(16 * x + 4 * ((bq + s) & 3)) + (size_t)(16 * y + 4 * ((bq + 2 * t) & 3)) * a.ldc];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    Cb[(16 * x + 4 * ((bq + s) & 3)) + (size_t)(16 * y + 4 * ((bq + 2 * t) & 3)) * a.ldc] =
+                        cv[x][y][s][t] - acc[x][y][s][t];
+    if (a.stamp && tid == 0) {
+        atomicAdd(a.stamp, __builtin_amdgcn_s_memtime() - st_c);
+        atomicAdd(a.stamp + 1, __builtin_amdgcn_s_memrealtime() - st_r);
+        atomicAdd(a.stamp + 2, 1ull);
+    }
+    if (a.sig != nullptr && (ti * TM) / TILE == a.sig_tile && (tj * TM) / TILE == a.sig_tile) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) signal_add(a.sig);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -657,88 +932,96 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
     hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), shm, s, A, lda, c0, dinv, info);
 }
 
+void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
+                         unsigned *in, unsigned *out, unsigned *abort_word, hipStream_t s)
+{
+    if (t0 >= nt) return;
+    EngineArgs e;
+    e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
+    e.in = in; e.out = out; e.abort_word = abort_word;
+    e.need = 3;            // the three 64-tiles (2T,2T), (2T+1,2T), (2T+1,2T+1) of a diagonal 128-tile
+    // the whole LDS of a CU: nothing else is placed beside the engine (see potrf_engine_kernel)
+    const size_t shm = 160 * 1024;
+    (void)hipFuncSetAttribute((const void *)potrf_engine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(potrf_engine_kernel, dim3(1), dim3(512), shm, s, e);
+}
+
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
-                      bool no_lds)
+                      unsigned *wait_word, unsigned *abort_word)
 {
     int nb = (r1 - r0) / 64;
     if (nb <= 0) return;
-    if (no_lds) hipLaunchKernelGGL(trsm_tile_l2_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, dinv);
-    else hipLaunchKernelGGL(trsm_tile_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, dinv);
+    hipLaunchKernelGGL(trsm_tile_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, dinv, wait_word, abort_word);
 }
 
-static int upd64_max_tiles()
+// diagnostic stamps of the update kernels (COCONS_UPD_STAMP=1): three device counters
+unsigned long long *upd_stamp_buffer()
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("COCONS_UPD64_MAX_TILES");
-        v = e ? atoi(e) : 1000000;   // measured: the 64-tile shape wins at every step (45.7 vs 31 TF)
+    static int on = -1;
+    static unsigned long long *buf = nullptr;
+    if (on < 0) {
+        const char *e = getenv("COCONS_UPD_STAMP");
+        on = e ? atoi(e) : 0;
+        if (on) {
+            if (hipMalloc(&buf, 4 * sizeof(unsigned long long)) != hipSuccess) { buf = nullptr; on = 0; }
+            else hipMemset(buf, 0, 4 * sizeof(unsigned long long));
+        }
     }
-    return v;
-}
-
-// K-chunks of 8 (20 KB of LDS, up to 8 workgroups = 8 waves/SIMD per CU) measured 48.1 TFLOP/s
-// against 46.8 for chunks of 16 (40 KB, 4 workgroups/CU): default on; COCONS_UPD_KC8=0 to compare
-static bool upd_small_lds()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("COCONS_UPD_KC8");
-        v = e ? atoi(e) : 1;
-    }
-    return v != 0;
+    return buf;
 }
 
 void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
-                        int ptiles, int world, int rank)
+                        int ptiles, int world, int rank, unsigned *sig, int sig_tile)
 {
     if (ti1 <= ti0 || tj1 <= tj0 || K <= 0) return;
     UpdArgs a;
     a.C = A; a.ldc = lda; a.P = P; a.ldp = ldp; a.K = K;
     a.lower_only = lower_only ? 1 : 0;
     a.ptiles = ptiles; a.world = world; a.rank = rank;
-    // number of 128-tiles that do work
-    long nti = ti1 - ti0, ntj = tj1 - tj0;
-    long tiles = nti * ntj;
-    if (lower_only) {
-        tiles = 0;
-        for (int tj = tj0; tj < tj1; ++tj) tiles += (ti1 - (tj > ti0 ? tj : ti0));
-    }
-    if (world > 1) tiles = tiles / world + 1;
+    a.sig = sig; a.sig_tile = sig_tile;
+    a.stamp = upd_stamp_buffer();
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("COCONS_UPD_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     static int swz = -1;
     if (swz < 0) { const char *e = getenv("COCONS_XCD_SWIZZLE"); swz = e ? atoi(e) : 0; }
     a.xcd_swizzle = swz;
     a.H = 0;
-    const bool small = tiles <= upd64_max_tiles();
-    const int f = small ? 2 : 1;                 // tile indices in units of TM
-    a.ti0 = f * ti0; a.tj0 = f * tj0;
-    dim3 grid(f * (ti1 - ti0), f * (tj1 - tj0));
+    // 64 x 64 tiles throughout (the 128 x 128 shape measured 31 TFLOP/s against 50): tile indices in
+    // units of 64 from here on
+    a.ti0 = 2 * ti0; a.tj0 = 2 * tj0;
+    dim3 grid(2 * (ti1 - ti0), 2 * (tj1 - tj0));
     if (lower_only) {
         // requires ti0 >= tj0 == first column: the trapezoid rows tj0..ti1, columns tj0..tj1
         if (ti0 != tj0) { a.lower_only = 0; }    // strictly-below rectangle: every tile does work
         else {
-            const long long H = (long long)f * (ti1 - tj0), W = (long long)f * (tj1 - tj0);
+            const long long H = 2LL * (ti1 - tj0), W = 2LL * (tj1 - tj0);
             a.H = (int)H;
             grid = dim3((unsigned)(W * H - W * (W - 1) / 2), 1);
         }
     }
     const bool trailing = (K >= 2 * TILE) && world == 1;
-    if (small) {
-        if (upd_small_lds()) {
-            if (trailing) hipLaunchKernelGGL((update_kernel<64, 8, 0>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((update_kernel<64, 8, 1>), grid, dim3(256), 0, s, a);
-        } else {
-            hipLaunchKernelGGL((update_kernel<64, 16, 0>), grid, dim3(256), 0, s, a);
-        }
+    static int form16 = -1;     // COCONS_UPD_MFMA16=1: the 16x16x4 kernel, for comparison
+    if (form16 < 0) { const char *e = getenv("COCONS_UPD_MFMA16"); form16 = e ? atoi(e) : 0; }
+    if (form16) {
+        if (trailing) hipLaunchKernelGGL((update_kernel<64, 8, 0>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((update_kernel<64, 8, 1>), grid, dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL((update_kernel<128, 16, 0>), grid, dim3(256), 0, s, a);
+        static int kc = -1;     // COCONS_UPD_KC: K-chunk of the 4x4x4 kernel (8, 16, 32)
+        if (kc < 0) { const char *e = getenv("COCONS_UPD_KC"); kc = e ? atoi(e) : 8; }
+        const size_t shm8 = 4 * 8 * 80 * sizeof(double);
+        if (!trailing) hipLaunchKernelGGL((update4_kernel<8, 1>), grid, dim3(256), shm8, s, a);
+        else if (kc == 32) {
+            (void)hipFuncSetAttribute((const void *)update4_kernel<32, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * shm8));
+            hipLaunchKernelGGL((update4_kernel<32, 0>), grid, dim3(256), 4 * shm8, s, a);
+        } else if (kc == 16) hipLaunchKernelGGL((update4_kernel<16, 0>), grid, dim3(256), 2 * shm8, s, a);
+        else hipLaunchKernelGGL((update4_kernel<8, 0>), grid, dim3(256), shm8, s, a);
     }
 }
 
 void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
-                   bool lower_only, hipStream_t s)
+                   bool lower_only, hipStream_t s, unsigned *sig, int sig_tile)
 {
-    launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0);
+    launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile);
 }
 
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
@@ -806,6 +1089,232 @@ vfma_f64_probe_kernel(double *out, int iters, double seed)
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += x[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// Extended probe (settles what bounds the fp64 matrix pipe): NACC independent accumulators per wave,
+// either the 16x16x4 form (2048 flop) or the 4x4x4 four-block form (512 flop), with in-kernel stamps:
+// stamp[2 b] = shader cycles (s_memtime), stamp[2 b + 1] = ticks of the constant 100 MHz clock
+// (s_memrealtime) spent by workgroup b in the loop -- their ratio is the clock the chip actually held.
+template <int NACC, int FORM>
+__global__ void __launch_bounds__(256)
+mfma_f64_probe_ex_kernel(double *out, unsigned long long *stamp, int iters, double seed)
+{
+    double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    double res = 0.0;
+    if (FORM == 0) {
+        d4 acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = (d4){0, 0, 0, 0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = MFMA64((i & 1) ? a : b, (i & 2) ? a : b, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) res += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+        double acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NACC; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64((i & 1) ? a : b, (i & 2) ? a : b, acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) res += acc[i];
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = res;
+    if (threadIdx.x == 0) { stamp[2 * blockIdx.x] = c1 - c0; stamp[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+// FORM 2: the inner loop of update4_kernel without its global traffic and barriers: per k-step of 4,
+// eight ds_read_b64 operand slices feed sixteen 4x4x4 instructions (operands re-read from an LDS image)
+__global__ void __launch_bounds__(256)
+mfma4_lds_probe_kernel(double *out, unsigned long long *stamp, int iters, double seed)
+{
+    constexpr int LDT = 80, KC = 8;
+    __shared__ double sI[KC * LDT], sJ[KC * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < KC * LDT; e += 256) { sI[e] = seed + e * 1e-4; sJ[e] = seed - e * 1e-4; }
+    __syncthreads();
+    const int wi = wave & 1, wj = wave >> 1;
+    const int kq = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
+    const int roR0 = kq * LDT + 4 * bq + jq + 32 * wi, roR1 = kq * LDT + 4 * ((bq + 1) & 3) + jq + 32 * wi;
+    const int roC0 = kq * LDT + 4 * bq + jq + 32 * wj, roC2 = kq * LDT + 4 * ((bq + 2) & 3) + jq + 32 * wj;
+    double acc[2][2][2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[x][y][s][t] = 0.0;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        const double *bI = sI, *bJ = sJ;
+        asm volatile("" : "+v"(bI), "+v"(bJ));      // keep the reads inside the loop
+#pragma unroll
+        for (int s4 = 0; s4 < KC / 4; ++s4) {
+            double pr[2][2], pc[2][2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                pr[x][0] = bI[s4 * 4 * LDT + 16 * x + roR0];
+                pr[x][1] = bI[s4 * 4 * LDT + 16 * x + roR1];
+                pc[x][0] = bJ[s4 * 4 * LDT + 16 * x + roC0];
+                pc[x][1] = bJ[s4 * 4 * LDT + 16 * x + roC2];
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            acc[x][y][s][t] = MFMA4(pc[y][t], pr[x][s], acc[x][y][s][t]);
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    double res = 0.0;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) res += acc[x][y][s][t];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = res;
+    if (threadIdx.x == 0) { stamp[2 * blockIdx.x] = c1 - c0; stamp[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+// FORM 3: sixteen accumulators fed from four + four DISTINCT operand registers (no LDS traffic): tells
+// operand-register switching apart from the LDS feed
+__global__ void __launch_bounds__(256)
+mfma4_regs_probe_kernel(double *out, unsigned long long *stamp, int iters, double seed)
+{
+    double pr[2][2], pc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { pr[x][s] = seed + threadIdx.x * 1e-3 + x + 2 * s; pc[x][s] = seed - threadIdx.x * 1e-3 - x - 2 * s; }
+    double acc[2][2][2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[x][y][s][t] = 0.0;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < 2 * iters; ++it) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(pr[x][s]), "+v"(pc[x][s]));
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[x][y][s][t] = MFMA4(pc[y][t], pr[x][s], acc[x][y][s][t]);
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    double res = 0.0;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) res += acc[x][y][s][t];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = res;
+    if (threadIdx.x == 0) { stamp[2 * blockIdx.x] = c1 - c0; stamp[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+// idle filler: one wave that sleeps for `ticks` of the 100 MHz clock (a gap between bursts on the stream)
+__global__ void idle_kernel(unsigned long long ticks)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - r0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+template <int NACC, int FORM>
+static void launch_probe_ex(int blocks, double *dbuf, unsigned long long *stamp, int iters, hipStream_t s)
+{
+    hipLaunchKernelGGL((mfma_f64_probe_ex_kernel<NACC, FORM>), dim3(blocks), dim3(256), 0, s, dbuf, stamp, iters, 1.0);
+}
+
+// bursts of `iters` loop iterations separated by idle gaps of gap_us (0 = back to back), `reps` bursts
+// after a warm-up of the same pattern.  out[0] = TFLOP/s inside the bursts (event-timed, gaps excluded),
+// out[1] = in-kernel clock in GHz (median over workgroups of the last burst), out[2] = shader cycles per
+// MFMA instruction per wave, out[3] = mean burst duration in ms
+int run_mfma_f64_probe_ex(int blocks, int nacc, int form, int iters, int gap_us, int reps, double *out)
+{
+    hipStream_t s;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1;
+    double *dbuf = nullptr;
+    unsigned long long *dst = nullptr;
+    hipMalloc(&dbuf, (size_t)blocks * 256 * sizeof(double));
+    hipMalloc(&dst, (size_t)blocks * 2 * sizeof(unsigned long long));
+    auto burst = [&]() {
+        if (form == 2) {     // nacc is fixed at 16, iters counts k-steps of 8 (32 instructions)
+            hipLaunchKernelGGL(mfma4_lds_probe_kernel, dim3(blocks), dim3(256), 0, s, dbuf, dst, iters, 1.0);
+        } else if (form == 3) {
+            hipLaunchKernelGGL(mfma4_regs_probe_kernel, dim3(blocks), dim3(256), 0, s, dbuf, dst, iters, 1.0);
+        } else if (form == 0) {
+            if (nacc == 4) launch_probe_ex<4, 0>(blocks, dbuf, dst, iters, s);
+            else if (nacc == 8) launch_probe_ex<8, 0>(blocks, dbuf, dst, iters, s);
+            else launch_probe_ex<16, 0>(blocks, dbuf, dst, iters, s);
+        } else {
+            if (nacc == 4) launch_probe_ex<4, 1>(blocks, dbuf, dst, iters, s);
+            else if (nacc == 8) launch_probe_ex<8, 1>(blocks, dbuf, dst, iters, s);
+            else launch_probe_ex<16, 1>(blocks, dbuf, dst, iters, s);
+        }
+    };
+    const int warm = reps;
+    std::vector<hipEvent_t> ev(2 * (size_t)reps);
+    for (auto &e : ev) hipEventCreate(&e);
+    for (int r = 0; r < warm + reps; ++r) {
+        if (r >= warm) hipEventRecord(ev[2 * (r - warm)], s);
+        burst();
+        if (r >= warm) hipEventRecord(ev[2 * (r - warm) + 1], s);
+        if (gap_us > 0) hipLaunchKernelGGL(idle_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)gap_us * 100ull);
+    }
+    hipStreamSynchronize(s);
+    double ms_sum = 0;
+    for (int r = 0; r < reps; ++r) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]);
+        ms_sum += ms;
+    }
+    for (auto &e : ev) hipEventDestroy(e);
+    std::vector<unsigned long long> st((size_t)blocks * 2);
+    hipMemcpy(st.data(), dst, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    std::vector<double> clk(blocks), cyc(blocks);
+    for (int b = 0; b < blocks; ++b) {
+        clk[b] = (double)st[2 * b] / (double)st[2 * b + 1] * 0.1;      // cycles per 10 ns -> GHz
+        cyc[b] = (double)st[2 * b] / ((double)iters * (form >= 2 ? 32 : nacc));
+    }
+    std::sort(clk.begin(), clk.end());
+    std::sort(cyc.begin(), cyc.end());
+    const double flop_per = form == 0 ? 2048.0 : 512.0;
+    const double flops = (double)blocks * 4.0 * (double)iters * (form >= 2 ? 32 : nacc) * flop_per;
+    out[0] = flops / (ms_sum / reps * 1e-3) / 1e12;
+    out[1] = clk[blocks / 2];
+    out[2] = cyc[blocks / 2];
+    out[3] = ms_sum / reps;
+    hipFree(dbuf); hipFree(dst);
+    hipStreamDestroy(s);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 double run_vfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf)

@@ -154,6 +154,12 @@ int cocons_fit_profile(cocons_fit *fit, const double *theta, const double *mean,
  * `blocks_per_cu` 256-thread workgroups per CU; returns the sustained TFLOP/s.  Evidence
  * for the roofline peak the update kernel is priced against. */
 int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops);
+/* Extended probe: nacc (4 / 8 / 16) independent accumulators per wave, form 0 = v_mfma_f64_16x16x4_f64,
+ * 1 = v_mfma_f64_4x4x4_4b_f64; `reps` bursts of `iters` loop iterations separated by idle gaps of gap_us
+ * (0 = back to back).  out4[0] = TFLOP/s inside the bursts, [1] = clock the chip held inside the kernel
+ * in GHz (s_memtime / s_memrealtime), [2] = shader cycles per MFMA instruction per wave, [3] = mean
+ * burst duration in ms.  Tells issue rate per clock apart from the clock the chip sustains under load. */
+int cocons_mfma_f64_probe_ex(int blocks_per_cu, int nacc, int form, int iters, int gap_us, int reps, double *out4);
 /* companion: independent v_fma_f64 chains -- the fp64 vector rate the chip sustains */
 int cocons_vfma_f64_probe(int blocks_per_cu, double *tflops);
 
