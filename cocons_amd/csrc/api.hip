@@ -504,23 +504,29 @@ static void count_update_flops(cocons_fit *f, int kw, int t0)
 // Plain schedule (COCONS_ENGINE=0, or fewer than 5 tiles), everything on the main stream:
 //   potrf(t) | trsm(t) | in-panel update of tile column t+1 | potrf(t+1) | trsm(t+1) | trailing update
 //
-// Engine schedule: the diagonal tiles 2 .. nt-1 are factored by ONE resident workgroup
-// (potrf_engine_kernel, launched once per factorisation on the second stream, owning a CU) as soon
-// as the kernel that finishes a diagonal tile has published it; the main stream runs, per block k
-// with t = k + 2:
-//   Ua(k): first half (by area) of the trailing update with panel k, starting with tile column t;
-//          its three workgroups inside diagonal tile t raise in[t]      -> engine factors tile t
-//   trsm(t)   : waits for out[t] (normally long set: the engine worked while Ua ran)
-//   in-panel update of tile column t+1 with column t; raises in[t+1]    -> engine factors tile t+1
-//   Ub(k): second half of the trailing update                           (engine works meanwhile)
+// Engine schedule: the 256 x 256 diagonal blocks from tile 2 on are factored by ONE resident workgroup
+// (potrf_engine_kernel, launched once per factorisation on the second stream, on a CU of its own) as
+// soon as the trailing update has published them; the main stream runs, per block k with t = k + 2:
+//   U(k)      : trailing update with panel k, tile column t first; its workgroups inside the diagonal
+//               block raise in[t] / in[t+1]      -> the engine factors tile t, forms X = A(t+1,t) L(t)^-T,
+//                                                   updates and factors tile t+1 (all while U(k) runs)
+//   trsm(t)   : rows below the diagonal block; waits for out[t]
+//   in-panel update of tile column t+1 (rows below the block) with column t; waits for xr[t]
 //   trsm(t+1) : waits for out[t+1]
-// So the two 30 us single-workgroup diagonal factorisations per block leave the critical path; the
-// main stream needs no events and issues the same number of launches as the plain schedule.
+// So the serial part of every panel -- two 30 us single-workgroup factorisations and the tile between
+// them -- is off the critical path as long as U(k) lasts ~90 us; the main stream needs no events and
+// issues fewer launches than the plain schedule.
 static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t> *ev_upd)
 {
     const int nt = v.nt, mt = v.mt;
     hipStream_t M = f->stream;
     if (!engine_enabled() || !f->engine_ok || nt <= 4) {
+        {   // diagnostic: COCONS_DUMMY_RESIDENT="threads,lds_bytes,ms,mode"
+            const char *e = getenv("COCONS_DUMMY_RESIDENT");
+            int th = 0, mode = 0; long lds = 0; double ms = 0;
+            if (e && sscanf(e, "%d,%ld,%lf,%d", &th, &lds, &ms, &mode) == 4 && nt > 4)
+                launch_dummy_resident(f->stream2, th, (size_t)lds, ms, mode, (unsigned *)(f->dinfo + 1));
+        }
         for (int k = 0; k < nt; k += 2) {
             panel_ops(f, v, k, M);
             if (k + 2 < nt) {
@@ -534,43 +540,28 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->dflags) { HIPCHK(hipFree(f->dflags)); f->dflags = nullptr; }
         f->flags_cap = round_up(nt + 8, 64);
-        HIPCHK(hipMalloc(&f->dflags, 2 * (size_t)f->flags_cap * sizeof(unsigned)));
+        HIPCHK(hipMalloc(&f->dflags, 3 * (size_t)f->flags_cap * sizeof(unsigned)));
     }
-    unsigned *in = f->dflags, *out = f->dflags + f->flags_cap;
+    unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
     unsigned *abort_word = (unsigned *)(f->dinfo + 1);
-    HIPCHK(hipMemsetAsync(f->dflags, 0, 2 * (size_t)f->flags_cap * sizeof(unsigned), M));
+    HIPCHK(hipMemsetAsync(f->dflags, 0, 3 * (size_t)f->flags_cap * sizeof(unsigned), M));
     HIPCHK(hipEventRecord(f->ev_eng, M));
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
-    launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, abort_word, f->stream2);
+    launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, abort_word, f->stream2);
     panel_ops(f, v, 0, M);
     for (int k = 0; k + 2 < nt; k += 2) {
         const int t = k + 2;
-        // split the trapezoid of tile columns [t, nt) (heights mt - j) into two halves of equal area;
-        // the first half always holds the block's own two tile columns
-        int split = nt;
-        {
-            long long total = 0, acc = 0;
-            for (int j = t; j < nt; ++j) total += mt - j;
-            for (int j = t; j < nt; ++j) {
-                acc += mt - j;
-                if (2 * acc >= total) { split = j + 1; break; }
-            }
-            if (split < t + 2) split = t + 2;
-            if (split > nt) split = nt;
-            static int nosplit = -1;
-            if (nosplit < 0) { const char *e = getenv("COCONS_NOSPLIT"); nosplit = e ? atoi(e) : 0; }
-            if (nosplit) split = nt;
-        }
+        const bool two = t + 1 < nt;                 // the block has a second tile
+        const int r0 = two ? t + 2 : t + 1;          // first tile row below the diagonal block
         if (ev_upd) count_update_flops(f, 2, t);
-        timed_update(f, v, k, 2, t, split, M, ev_upd, in + t, t);
-        launch_trsm_tile(v.A, v.lda, t * TILE, (t + 1) * TILE, mt * TILE, f->dinv + (size_t)(t & 1) * 2048, M,
+        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t);
+        launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, mt * TILE, f->dinv + (size_t)(t & 1) * 2048, M,
                          out + t, abort_word);
-        if (t + 1 < nt)
-            launch_update(v.A, v.lda, t * TILE, TILE, t + 1, mt, t + 1, t + 2, true, M, in + t + 1, t + 1);
-        timed_update(f, v, k, 2, split, nt, M, ev_upd, nullptr, -1);
-        if (t + 1 < nt)
-            launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, (t + 2) * TILE, mt * TILE,
+        if (two) {
+            launch_update(v.A, v.lda, t * TILE, TILE, r0, mt, t + 1, t + 2, false, M, nullptr, -1, xr + t, abort_word);
+            launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, r0 * TILE, mt * TILE,
                              f->dinv + (size_t)((t + 1) & 1) * 2048, M, out + t + 1, abort_word);
+        }
     }
     return 0;
 }

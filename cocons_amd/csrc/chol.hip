@@ -79,6 +79,44 @@ __device__ __forceinline__ void glb_blk_store(double *A, size_t lda, int row0, i
     p[12 * lda] = v[3];
 }
 
+// Write-through (sc1) stores for data handed to another workgroup INSIDE a launch: the bytes leave the
+// XCD's L2 at once, so publishing them needs no release fence (buffer_wbl2 would write back every dirty
+// line of that L2 -- with a trailing update in flight that is megabytes, and it measurably slowed the
+// update chip-wide).  One 8-byte agent-scope relaxed atomic store per element = global_store_dwordx2 sc1.
+__device__ __forceinline__ void store_wt(double *p, double v)
+{
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// L1-bypassing (sc1) load of data another workgroup published with store_wt: with EVERY load of the
+// handed-off bytes of this form the consumer needs no acquire fence (buffer_inv)
+__device__ __forceinline__ double load_wt(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ __forceinline__ d4 glb_blk_wt(const double *A, size_t lda, int row0, int col0, int lane)
+{
+    const double *p = A + (size_t)(row0 + (lane & 15)) + (size_t)(col0 + (lane >> 4)) * lda;
+    d4 v;
+    v[0] = load_wt(p);
+    v[1] = load_wt(p + 4 * lda);
+    v[2] = load_wt(p + 8 * lda);
+    v[3] = load_wt(p + 12 * lda);
+    return v;
+}
+
+__device__ __forceinline__ void glb_blk_store_wt(double *A, size_t lda, int row0, int col0, int lane, const d4 &v)
+{
+    double *p = A + (size_t)(row0 + (lane & 15)) + (size_t)(col0 + (lane >> 4)) * lda;
+    store_wt(p, v[0]);
+    store_wt(p + 4 * lda, v[1]);
+    store_wt(p + 8 * lda, v[2]);
+    store_wt(p + 12 * lda, v[3]);
+}
+
 // ---------------------------------------------------------------------------
 // 16x16 diagonal block on ONE wave, all in registers (blk layout), MFMA-based:
 //   for each 4-column group s: broadcast the 4x4 diagonal sub-block (v_readlane), factor
@@ -219,7 +257,11 @@ __constant__ int c_tri_ib[36] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5,
 //   S: symmetric update of the remaining blocks; wave 0 takes block (jb+1,jb+1) first and
 //      factors it in registers (potrf16_regs) while waves 1..7 finish the other updates.
 // Also exports, per diagonal block, the Q operands (4 x 64 lanes) the panel solve needs.
-__device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, double *q_out, int *info, double *smem)
+// qall (LDS, may be null): receives the Q operands of all eight diagonal blocks (8 x 256 doubles)
+// WT: the factor and the Q operands are published with write-through stores (engine)
+template <bool WT>
+__device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, double *q_out, int *info, double *smem,
+                                                double *qall)
 {
     // lower-packed image: block (ib,kb), ib >= kb, at (ib (ib+1)/2 + kb) * 256  (72 KB), plus the
     // Q operands of the CURRENT diagonal block (2 KB): 74 KB in all
@@ -238,7 +280,8 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
         for (int t = 0; t < 18; ++t) {
             const int bb = 2 * t + half;
             const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
-            v[t] = src[(size_t)(16 * ib) + (size_t)(16 * kb) * lda];
+            v[t] = WT ? load_wt(src + (size_t)(16 * ib) + (size_t)(16 * kb) * lda)
+                      : src[(size_t)(16 * ib) + (size_t)(16 * kb) * lda];
         }
 #pragma unroll
         for (int t = 0; t < 18; ++t) {
@@ -255,7 +298,11 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
         if (f && lane == 0) atomicMin(info, c0 + f);
         lds_blk_store(S, lane, D);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { QS[s * 64 + lane] = Q[s]; q_out[s * 64 + lane] = Q[s]; }
+        for (int s = 0; s < 4; ++s) {
+            QS[s * 64 + lane] = Q[s];
+            if (WT) store_wt(q_out + s * 64 + lane, Q[s]); else q_out[s * 64 + lane] = Q[s];
+            if (qall) qall[s * 64 + lane] = Q[s];
+        }
     }
     __syncthreads();
 
@@ -290,7 +337,11 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
             // the single Q buffer is still being read by the T phase of this jb?  No: T ended at
             // the barrier above; the next reader is the T phase after the barrier below.
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { QS[s * 64 + lane] = Q[s]; q_out[nb * 256 + s * 64 + lane] = Q[s]; }
+            for (int s = 0; s < 4; ++s) {
+                QS[s * 64 + lane] = Q[s];
+                if (WT) store_wt(q_out + nb * 256 + s * 64 + lane, Q[s]); else q_out[nb * 256 + s * 64 + lane] = Q[s];
+                if (qall) qall[nb * 256 + s * 64 + lane] = Q[s];
+            }
         } else {
             int cnt = 0;
             for (int ib = jb + 1; ib < 8; ++ib) {
@@ -315,8 +366,10 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
         int b = 0;
         for (int ib = 0; ib < 8; ++ib)
             for (int kb = 0; kb <= ib; ++kb, ++b)
-                if ((b & 1) == half)
-                    dst[(size_t)(16 * ib) + (size_t)(16 * kb) * lda] = SB(ib, kb)[k * 16 + i];
+                if ((b & 1) == half) {
+                    if (WT) store_wt(dst + (size_t)(16 * ib) + (size_t)(16 * kb) * lda, SB(ib, kb)[k * 16 + i]);
+                    else dst[(size_t)(16 * ib) + (size_t)(16 * kb) * lda] = SB(ib, kb)[k * 16 + i];
+                }
     }
 #undef SB
 }
@@ -325,15 +378,16 @@ __global__ void __launch_bounds__(512)
 potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
 {
     extern __shared__ double smem[];
-    potrf_tile_body(A, lda, c0, q_out, info, smem);
+    potrf_tile_body<false>(A, lda, c0, q_out, info, smem, nullptr);
 }
 
 // ---------------------------------------------------------------------------
 // Hand-offs between workgroups of DIFFERENT kernels that are resident at the same time (the
 // diagonal-tile engine below and the update / panel-solve kernels of the main stream).  Protocol
 // (agent scope; per-XCD L2s are not coherent and a CU's L1 is never refreshed by other CUs):
-//   producer: every storing wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane:
-//             release fence (L2 write-back) -> drain -> relaxed agent-scope atomic on the flag word
+//   producer: payload stored WRITE-THROUGH (sc1: store_wt), every storing wave drains its stores
+//             (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane: relaxed agent-scope atomic on the flag word
+//             (no release fence: see store_wt)
 //   consumer: ONE lane polls the flag relaxed (s_sleep between polls), then ONE acquire fence (L1
 //             invalidate), drain, workgroup barrier, then plain loads.
 // Every spin is bounded: after ENGINE_TIMEOUT_TICKS of the 100 MHz constant clock the waiter sets the
@@ -343,13 +397,15 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
 
 __device__ __forceinline__ void signal_add(unsigned *word)
 {
-    // caller: all storing waves have executed s_waitcnt vmcnt(0) and passed a barrier; one lane calls
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // caller: the payload was stored write-through (store_wt), all storing waves have executed
+    // s_waitcnt vmcnt(0) and passed a barrier; one lane calls
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// one lane; returns false on abort / timeout
+// one lane; returns false on abort / timeout.  ACQUIRE = false: the caller reads the handed-off bytes with
+// load_wt only
+template <bool ACQUIRE = true>
 __device__ __forceinline__ bool wait_ge(unsigned *word, unsigned need, unsigned *abort_word)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -362,41 +418,110 @@ __device__ __forceinline__ bool wait_ge(unsigned *word, unsigned need, unsigned 
         }
         __builtin_amdgcn_s_sleep(16);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler ordering only
     return true;
 }
 
-// Diagonal-tile engine: ONE persistent workgroup that factors the diagonal tiles t0 .. nt-1 of a
-// factorisation, each as soon as the main stream has finished updating it (flag in[t] reaches
-// `need`), and publishes the factor (flag out[t]).  It asks for the whole LDS of a CU, so no update
-// workgroup shares its CU: the fp64 pivot chains of potrf16_regs run on the same DP units as the
-// fp64 MFMAs and take 3x as long beside them (measured).  Being resident, it needs no stream
-// dependency and no room to be found mid-factorisation.
+// Diagonal-block engine: ONE persistent workgroup (8 waves) that factors the 256x256 diagonal blocks
+// t = t0, t0+2, ... of a factorisation while the main stream's trailing update runs.  Per block (tiles
+// t and t+1):
+//   wait in[t]   >= 3 : diagonal tile t is updated            -> factor it (potrf_tile_body), raise out[t]
+//   wait in[t+1] >= 7 : tiles (t+1,t) and (t+1,t+1) are updated
+//   X = A(t+1,t) L(t)^-T   : 8 waves x 16-row strips in registers, L(t) and its Q operands still in LDS;
+//                            stored to global memory and to LDS, raise xr[t]
+//   A(t+1,t+1) -= X X^T    : 36 lower 16x16 blocks dealt over the waves, operands from the LDS copy of X
+//   factor tile t+1, raise out[t+1]
+// so the whole serial part of a panel (two single-workgroup factorisations and the tile between them)
+// leaves the main stream, whose panel kernels then only cover the rows below the diagonal block.
+// The engine asks for most of a CU's LDS (see launch_potrf_engine), which keeps all but one update
+// workgroup off its CU: the fp64 pivot chains of potrf16_regs run on the same DP units as the fp64
+// MFMAs and take 3x as long beside them (measured).  Being resident, it needs no stream dependency and
+// no room to be found mid-factorisation.
+// LDS map (doubles): [0, 36*256) tile image S | [36*256, 37*256) Q of the current block |
+// [37*256, 45*256) Q operands of all 8 diagonal blocks | [64*256] ok word; X (64 blocks) overlays from 0.
 struct EngineArgs {
     double *A; size_t lda;
     int t0, nt;
     double *dinv;            // 2 x 2048 doubles, parity of the tile index
     int *info;
-    unsigned *in, *out;      // per-tile flag words
+    unsigned *in, *out, *xr; // per-tile flag words
     unsigned *abort_word;
-    unsigned need;
 };
 
 __global__ void __launch_bounds__(512)
 potrf_engine_kernel(EngineArgs e)
 {
     extern __shared__ double smem[];
-    int *okp = (int *)(smem + 37 * 256);
-    const int tid = threadIdx.x;
-    for (int t = e.t0; t < e.nt; ++t) {
-        if (tid == 0) *okp = wait_ge(e.in + t, e.need, e.abort_word) ? 1 : 0;
+    double *QALL = smem + 37 * 256;
+    double *XS = smem;
+    int *okp = (int *)(smem + 64 * 256);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *A = e.A;
+    const size_t lda = e.lda;
+    for (int t = e.t0; t < e.nt; t += 2) {
+        if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
-        potrf_tile_body(e.A, e.lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem);
+        potrf_tile_body<true>(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem, QALL);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t);
+        if (t + 1 >= e.nt) return;
+
+        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word) ? 1 : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (*okp == 0) return;
+        const int c0 = t * TILE, c1 = (t + 1) * TILE;
+        {   // X = A(t+1,t) L(t)^-T : this wave's 16 x 128 strip
+            const int rs = c1 + 16 * wave;
+            d4 B[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) B[j] = glb_blk_wt(A, lda, rs, c0 + 16 * j, lane);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                d4 L = lds_blk(smem + (j * (j + 1) / 2 + j) * 256, lane);
+                double Q[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Q[s] = QALL[j * 256 + s * 64 + lane];
+                trsm16(B[j], L, Q);
+                d4 NX = -B[j];
+#pragma unroll
+                for (int jj = j + 1; jj < 8; ++jj) {
+                    d4 Lb = lds_blk(smem + (jj * (jj + 1) / 2 + j) * 256, lane);
+                    blk_mma(B[jj], NX, Lb);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) glb_blk_store_wt(A, lda, rs, c0 + 16 * j, lane, B[j]);
+            __syncthreads();                       // every wave is done with the image of L(t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lds_blk_store(XS + (wave * 8 + j) * 256, lane, B[j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) signal_add(e.xr + t);
+        // A(t+1,t+1) -= X X^T : lower blocks b = wave, wave + 8, ...
+        for (int bb = wave; bb < 36; bb += 8) {
+            const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+            d4 acc = glb_blk_wt(A, lda, c1 + 16 * ib, c1 + 16 * kb, lane);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                d4 P = lds_blk(XS + (ib * 8 + j) * 256, lane);
+                d4 Qk = lds_blk(XS + (kb * 8 + j) * 256, lane);
+                P = -P;
+                blk_mma(acc, P, Qk);
+            }
+            glb_blk_store_wt(A, lda, c1 + 16 * ib, c1 + 16 * kb, lane, acc);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // X in LDS is dead; the tile is re-read from memory
+        potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, nullptr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) signal_add(e.out + t + 1);
     }
 }
 
@@ -460,7 +585,9 @@ struct UpdArgs {
     int ti0, tj0, lower_only;      // tile indices in units of TM
     int H;                         // lower_only: rows of the trapezoid (ti1 - tj0), 1-D grid over its tiles
     int xcd_swizzle;
-    unsigned *sig; int sig_tile;   // engine hand-off: add 1 to *sig when a 64-tile of diagonal 128-tile sig_tile is stored
+    unsigned *sig; int sig_tile;   // engine hand-off: workgroups inside the diagonal block (tiles sig_tile, sig_tile+1)
+                                   // add 1 to sig[sig_tile] (tile (t,t)) or sig[sig_tile+1] (tiles (t+1,t), (t+1,t+1))
+    unsigned *wait_word, *abort_word;  // engine hand-off: every workgroup first waits for *wait_word >= 1
     int dbg;                       // diagnostic timing knob (COCONS_UPD_DBG): 1 = no operand staging after chunk 0, 2 = also no C read-modify-write
     unsigned long long *stamp;     // diagnostic (COCONS_UPD_STAMP=1): += {shader cycles, 100 MHz ticks, 1} per workgroup
     int ptiles, world, rank;       // sharded path: only 128-tile columns whose panel (tj128 / ptiles) is owned
@@ -469,7 +596,7 @@ struct UpdArgs {
 // ROLE only names the instantiation (0 = trailing update, 1 = in-panel / sharded update) so that
 // profiler summaries keep the dominant trailing launches apart from the narrow ones
 template <int TM, int KC, int ROLE>
-__global__ void __launch_bounds__(256, (TM == 128 ? 2 : 4))
+__global__ void __launch_bounds__(256, (TM == 128 ? 2 : 8))
 update_kernel(UpdArgs a)
 {
     constexpr int LDT = TM + 16;   // lanes l and l+16 land 128 B apart mod 256 -> conflict-free b64 reads
@@ -501,10 +628,22 @@ update_kernel(UpdArgs a)
         tj = a.tj0 + blockIdx.y;
     }
     if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;
+    // does this workgroup's tile lie inside the diagonal block the engine is waiting for?
+    const int sig_Ti = (ti * TM) / TILE - a.sig_tile, sig_Tj = (tj * TM) / TILE - a.sig_tile;
+    const bool sig_wg = a.sig != nullptr && sig_Ti >= 0 && sig_Ti <= 1 && sig_Tj >= 0 && sig_Tj <= sig_Ti;
     __shared__ double sI[2][KC * LDT];
     __shared__ double sJ[2][KC * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
+    if (a.wait_word) {     // operand tile comes from the engine
+        int *wait_ok = (int *)&sI[0][0];      // (no LDS of its own: 20,480 B is exactly an eighth of a CU's)
+        if (tid == 0) *wait_ok = wait_ge(a.wait_word, 1u, a.abort_word) ? 1 : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int ok = *wait_ok;
+        __syncthreads();
+        if (!ok) return;
+    }
     unsigned long long st_c = 0, st_r = 0;
     if (a.stamp) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
 
@@ -570,31 +709,37 @@ update_kernel(UpdArgs a)
         }
         __syncthreads();
     }
-    // C -= acc (loads first, then stores: see update4_kernel)
+    // C -= acc, one accumulator block (4 elements) at a time: loads first, then the stores (written as
+    // `*p -= acc` the compiler must assume that a store aliases the next load and serialises the memory
+    // round trips; all sixteen at once would cost the 8th wave per SIMD in registers)
     double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi + (lane & 15)) +
                  (size_t)(tj * TM + (TM / 2) * wj + (lane >> 4)) * a.ldc;
-    d4 cv[NB][NB];
 #pragma unroll
     for (int x = 0; x < NB; ++x)
 #pragma unroll
-        for (int y = 0; y < NB; ++y)
+        for (int y = 0; y < NB; ++y) {
+            double *p = Cb + 16 * x + (size_t)(16 * y) * a.ldc;
+            d4 cv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cv[x][y][r] = Cb[16 * x + (size_t)(16 * y + 4 * r) * a.ldc];
+            for (int r = 0; r < 4; ++r) cv[r] = p[(size_t)(4 * r) * a.ldc];
+            cv -= acc[x][y];
+            if (sig_wg) {
 #pragma unroll
-    for (int x = 0; x < NB; ++x)
+                for (int r = 0; r < 4; ++r) store_wt(p + (size_t)(4 * r) * a.ldc, cv[r]);
+            } else {
 #pragma unroll
-        for (int y = 0; y < NB; ++y)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cb[16 * x + (size_t)(16 * y + 4 * r) * a.ldc] = cv[x][y][r] - acc[x][y][r];
+                for (int r = 0; r < 4; ++r) p[(size_t)(4 * r) * a.ldc] = cv[r];
+            }
+        }
     if (a.stamp && tid == 0) {
         atomicAdd(a.stamp, __builtin_amdgcn_s_memtime() - st_c);
         atomicAdd(a.stamp + 1, __builtin_amdgcn_s_memrealtime() - st_r);
         atomicAdd(a.stamp + 2, 1ull);
     }
-    if (a.sig != nullptr && (ti * TM) / TILE == a.sig_tile && (tj * TM) / TILE == a.sig_tile) {
+    if (sig_wg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) signal_add(a.sig);
+        if (tid == 0) signal_add(a.sig + a.sig_tile + sig_Ti);
     }
 }
 
@@ -641,11 +786,23 @@ update4_kernel(UpdArgs a)
         tj = a.tj0 + blockIdx.y;
     }
     if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;
+    // does this workgroup's tile lie inside the diagonal block the engine is waiting for?
+    const int sig_Ti = (ti * TM) / TILE - a.sig_tile, sig_Tj = (tj * TM) / TILE - a.sig_tile;
+    const bool sig_wg = a.sig != nullptr && sig_Ti >= 0 && sig_Ti <= 1 && sig_Tj >= 0 && sig_Tj <= sig_Ti;
     extern __shared__ double upd4_smem[];      // 4 * KC * LDT doubles (dynamic: KC = 32 needs 80 KB)
     double (*sI)[KC * LDT] = (double (*)[KC * LDT])upd4_smem;
     double (*sJ)[KC * LDT] = (double (*)[KC * LDT])(upd4_smem + 2 * KC * LDT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
+    if (a.wait_word) {     // operand tile comes from the engine
+        int *wait_ok = (int *)upd4_smem;
+        if (tid == 0) *wait_ok = wait_ge(a.wait_word, 1u, a.abort_word) ? 1 : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int ok = *wait_ok;
+        __syncthreads();
+        if (!ok) return;
+    }
     unsigned long long st_c = 0, st_r = 0;
     if (a.stamp) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
 
@@ -733,7 +890,7 @@ update4_kernel(UpdArgs a)
         const unsigned bo = (unsigned)cur * (unsigned)(KC * LDT * 8);
         double PA[8], PB[8];
         ISSUE_STEP(PA, bo, 0);
-        if (ch + 2 < nch && !a.dbg) {
+        if (ch + 2 < nch && !(a.dbg & 3)) {
             const double *pI = gI + (size_t)(ch + 2) * KC * a.ldp;
             const double *pJ = gJ + (size_t)(ch + 2) * KC * a.ldp;
 #pragma unroll
@@ -759,7 +916,7 @@ update4_kernel(UpdArgs a)
             }
             MFMA_STEP(PB);
         }
-        if (ch + 1 < nch && !a.dbg) {
+        if (ch + 1 < nch && !(a.dbg & 3)) {
 #pragma unroll
             for (int v = 0; v < RPT / 2; ++v) {
                 *(d2 *)(&sI[cur ^ 1][kc * LDT + rg + 2 * v]) = nI[v];
@@ -775,7 +932,7 @@ update4_kernel(UpdArgs a)
     // C -= acc: all sixteen loads first, then the stores (written as `*p -= acc` the compiler must assume
     // that a store aliases the next load and serialises sixteen memory round trips)
     double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi + jq) + (size_t)(tj * TM + (TM / 2) * wj + kq) * a.ldc;
-    if (a.dbg >= 2 && acc[0][0][0][0] != 12345.678) return;
+    if ((a.dbg & 2) && acc[0][0][0][0] != 12345.678) return;
     double cv[2][2][2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -794,17 +951,19 @@ update4_kernel(UpdArgs a)
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    Cb[(16 * x + 4 * ((bq + s) & 3)) + (size_t)(16 * y + 4 * ((bq + 2 * t) & 3)) * a.ldc] =
-                        cv[x][y][s][t] - acc[x][y][s][t];
+                {
+                    double *p = Cb + (16 * x + 4 * ((bq + s) & 3)) + (size_t)(16 * y + 4 * ((bq + 2 * t) & 3)) * a.ldc;
+                    if (sig_wg) store_wt(p, cv[x][y][s][t] - acc[x][y][s][t]); else *p = cv[x][y][s][t] - acc[x][y][s][t];
+                }
     if (a.stamp && tid == 0) {
         atomicAdd(a.stamp, __builtin_amdgcn_s_memtime() - st_c);
         atomicAdd(a.stamp + 1, __builtin_amdgcn_s_memrealtime() - st_r);
         atomicAdd(a.stamp + 2, 1ull);
     }
-    if (a.sig != nullptr && (ti * TM) / TILE == a.sig_tile && (tj * TM) / TILE == a.sig_tile) {
+    if (sig_wg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) signal_add(a.sig);
+        if (tid == 0) signal_add(a.sig + a.sig_tile + sig_Ti);
     }
 }
 
@@ -933,15 +1092,17 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
 }
 
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
-                         unsigned *in, unsigned *out, unsigned *abort_word, hipStream_t s)
+                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s)
 {
     if (t0 >= nt) return;
     EngineArgs e;
     e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
-    e.in = in; e.out = out; e.abort_word = abort_word;
-    e.need = 3;            // the three 64-tiles (2T,2T), (2T+1,2T), (2T+1,2T+1) of a diagonal 128-tile
-    // the whole LDS of a CU: nothing else is placed beside the engine (see potrf_engine_kernel)
-    const size_t shm = 160 * 1024;
+    e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word;
+    // 136 KB: the 128 KB LDS copy of X plus the flag word; leaves room for ONE update workgroup beside the
+    // engine.  (Asking for all 160 KB measured 7 % slower trailing updates chip-wide while the engine was
+    // resident; 76 .. 152 KB did not.)
+    size_t shm = 136 * 1024;
+    { const char *x = getenv("COCONS_ENGINE_LDS"); if (x && (size_t)atol(x) >= shm) shm = (size_t)atol(x); }
     (void)hipFuncSetAttribute((const void *)potrf_engine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(potrf_engine_kernel, dim3(1), dim3(512), shm, s, e);
 }
@@ -972,7 +1133,8 @@ unsigned long long *upd_stamp_buffer()
 
 void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
-                        int ptiles, int world, int rank, unsigned *sig, int sig_tile)
+                        int ptiles, int world, int rank, unsigned *sig, int sig_tile,
+                        unsigned *wait_word, unsigned *abort_word)
 {
     if (ti1 <= ti0 || tj1 <= tj0 || K <= 0) return;
     UpdArgs a;
@@ -980,6 +1142,7 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     a.lower_only = lower_only ? 1 : 0;
     a.ptiles = ptiles; a.world = world; a.rank = rank;
     a.sig = sig; a.sig_tile = sig_tile;
+    a.wait_word = wait_word; a.abort_word = abort_word;
     a.stamp = upd_stamp_buffer();
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("COCONS_UPD_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     static int swz = -1;
@@ -1000,9 +1163,12 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
         }
     }
     const bool trailing = (K >= 2 * TILE) && world == 1;
-    static int form16 = -1;     // COCONS_UPD_MFMA16=1: the 16x16x4 kernel, for comparison
-    if (form16 < 0) { const char *e = getenv("COCONS_UPD_MFMA16"); form16 = e ? atoi(e) : 0; }
-    if (form16) {
+    // default: the 16x16x4 kernel (8 waves per SIMD, pipe-bound at the instruction's 48.7 TFLOP/s).
+    // COCONS_UPD_MFMA4=1 selects the 4x4x4 kernel: its instruction peaks at 76 TFLOP/s but the kernel
+    // around it (LDS feed, staging, 5 waves per SIMD) does not beat the default yet
+    static int form4 = -1;
+    if (form4 < 0) { const char *e = getenv("COCONS_UPD_MFMA4"); form4 = e ? atoi(e) : 0; }
+    if (!form4) {
         if (trailing) hipLaunchKernelGGL((update_kernel<64, 8, 0>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((update_kernel<64, 8, 1>), grid, dim3(256), 0, s, a);
     } else {
@@ -1019,9 +1185,11 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
 }
 
 void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
-                   bool lower_only, hipStream_t s, unsigned *sig, int sig_tile)
+                   bool lower_only, hipStream_t s, unsigned *sig, int sig_tile,
+                   unsigned *wait_word, unsigned *abort_word)
 {
-    launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile);
+    launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile,
+                       wait_word, abort_word);
 }
 
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
@@ -1245,6 +1413,28 @@ __global__ void idle_kernel(unsigned long long ticks)
 {
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - r0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+// diagnostic: a resident do-nothing workgroup of the engine's shape (does mere residency of a second
+// kernel slow the trailing update?)
+__global__ void __launch_bounds__(512) dummy_resident_kernel(unsigned long long ticks, int mode, unsigned *word)
+{
+    extern __shared__ double smem[];
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        while (__builtin_amdgcn_s_memrealtime() - r0 < ticks) {
+            if (mode == 1) (void)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_sleep(16);
+        }
+        smem[0] = 1.0;
+    }
+    __syncthreads();
+}
+
+void launch_dummy_resident(hipStream_t s, int threads, size_t lds, double ms, int mode, unsigned *word)
+{
+    (void)hipFuncSetAttribute((const void *)dummy_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dummy_resident_kernel, dim3(1), dim3(threads), lds, s, (unsigned long long)(ms * 1e5), mode, word);
 }
 
 template <int NACC, int FORM>

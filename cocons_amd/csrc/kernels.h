@@ -78,29 +78,35 @@ constexpr int TILE = 128;          // tile edge of the blocked factorisation
 // its eight 16x16 diagonal blocks to dinv (8*256 doubles).  info: atomicMin of the
 // 1-based failing column (initialise to INT_MAX).
 void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, hipStream_t s);
-// Resident diagonal-tile engine (one workgroup owning a whole CU) for the tiles t0 .. nt-1: tile t is
-// factored once in[t] has been raised to 3 by the update kernels (launch_update's sig / sig_tile),
-// its Q operands go to dinv + (t & 1) * 2048, and out[t] is raised to 1 when the factor is published.
+// Resident diagonal-BLOCK engine (one workgroup on a CU of its own) for the 256 x 256 diagonal blocks
+// starting at tile t0 (even): see potrf_engine_kernel.  Flag words, all zero at launch:
+//   in[t]    raised by the update kernels (launch_update's sig / sig_tile): 3 = tile (t,t) updated;
+//   in[t+1]  7 = tiles (t+1,t) and (t+1,t+1) updated;
+//   out[t], out[t+1]  raised to 1 when the factor of that diagonal tile (and its Q operands in
+//                     dinv + (tile & 1) * 2048) is published;
+//   xr[t]    raised to 1 when X = A(t+1,t) L(t)^-T is published.
 // abort_word: set by any party whose bounded wait ran out; everybody leaves when it is non-zero.
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
-                         unsigned *in, unsigned *out, unsigned *abort_word, hipStream_t s);
+                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s);
 // rows [r0, r1) x cols [c0, c0+128):  X <- X * L(c0)^{-T}, L read from A(c0,c0).
 // wait_word != NULL: the tile comes from the engine -- every workgroup first waits for *wait_word >= 1
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
                       unsigned *wait_word = nullptr, unsigned *abort_word = nullptr);
 // C(i,j) -= sum_{k in [k0,k0+K)} A(i,k) A(j,k) for tiles with tile-row in [ti0,ti1),
 // tile-col in [tj0,tj1); lower_only keeps ti >= tj.  All tile indices in units of TILE.
-// sig / sig_tile: each of the three 64x64 workgroups inside diagonal tile sig_tile adds 1 to *sig
-// after its stores are published (hand-off to the engine).
+// sig / sig_tile: hand-off to the engine (sig = the in[] array, sig_tile = even tile of the diagonal block);
+// wait_word: an operand tile comes from the engine -- every workgroup first waits for *wait_word >= 1.
 void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
-                   bool lower_only, hipStream_t s, unsigned *sig = nullptr, int sig_tile = -1);
+                   bool lower_only, hipStream_t s, unsigned *sig = nullptr, int sig_tile = -1,
+                   unsigned *wait_word = nullptr, unsigned *abort_word = nullptr);
 // like launch_update but the (i,k) and (j,k) operands come from a separate packed
 // panel buffer P (ldp rows, row index = global row), used by the sharded path.
 // (ptiles, world, rank): when world > 1 only tile columns tj with (tj / ptiles) % world == rank
 // are updated (block-cyclic panel ownership).
 void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
-                        int ptiles, int world, int rank, unsigned *sig = nullptr, int sig_tile = -1);
+                        int ptiles, int world, int rank, unsigned *sig = nullptr, int sig_tile = -1,
+                        unsigned *wait_word = nullptr, unsigned *abort_word = nullptr);
 
 // diagnostic (COCONS_UPD_STAMP=1): device counters {shader cycles, 100 MHz ticks, workgroups} summed over
 // every update workgroup since the last reset; nullptr when off
@@ -124,6 +130,7 @@ void launch_trmm_lower(const double *A, size_t lda, int n, const double *E, int 
 // fp64 MFMA issue-rate probe (TFLOP/s); dbuf must hold blocks*256 doubles
 double run_mfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf);
 double run_vfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf);
+void launch_dummy_resident(hipStream_t s, int threads, size_t lds, double ms, int mode, unsigned *word);
 int run_mfma_f64_probe_ex(int blocks, int nacc, int form, int iters, int gap_us, int reps, double *out);
 void run_corun_probe(int blocks_mfma, int blocks_vfma, int iters_mfma, int iters_vfma, double *dbuf, double *out);
 
