@@ -16,6 +16,11 @@ P_MAX = 32
 _lib = None
 
 c_dp = ctypes.POINTER(ctypes.c_double)
+UNIQUE_ID_BYTES = 128
+# int (*)(void *user, void *dev_ptr, long long bytes, int root, void *stream)
+BCAST_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p)
+# int (*)(void *user, double *host_inout, int count, int op)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int)
 c_int = ctypes.c_int
 c_vp = ctypes.c_void_p
 
@@ -56,6 +61,13 @@ SIGNATURES = {
     "cocons_mfma_f64_probe_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_dp]),
     "cocons_vfma_f64_probe": (c_int, [c_int, c_dp]),
     "cocons_debug_matern": (c_int, [c_int, c_dp, c_dp, c_dp]),
+    "cocons_comm_unique_id": (c_int, [c_vp]),
+    "cocons_fit_comm_init": (c_int, [c_vp, c_int, c_int, c_vp]),
+    "cocons_fit_set_collectives": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "cocons_fit_world": (c_int, [c_vp]),
+    "cocons_multi_create": (c_vp, [c_int, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_int, ctypes.POINTER(c_int)]),
+    "cocons_multi_destroy": (None, [c_vp]),
+    "cocons_multi_neg2loglik_dense": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
     "cocons_shard_begin": (c_int, [c_vp, c_dp, c_dp, c_int, c_int]),
     "cocons_shard_panel_factor": (c_int, [c_vp, c_int]),
     "cocons_shard_panel_buffer": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(ctypes.c_longlong)]),

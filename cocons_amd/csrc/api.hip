@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <string>
@@ -121,6 +123,88 @@ static ModeSel select_mode(const double *theta, int p, const double *smooth_limi
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ---------------------------------------------------------------------------
+// RCCL, loaded on first use (dlopen): the library itself has no load-time dependency on it, and a
+// process that never shards never touches it.
+struct RcclApi {
+    void *h;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*GroupStart)();
+    ncclResult_t (*GroupEnd)();
+    const char *(*GetErrorString)(ncclResult_t);
+};
+
+static RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static int state = 0;      // 0 untried, 1 ok, -1 failed
+    if (state == 0) {
+        state = -1;
+        // RCCL must sit on the SAME HIP / HSA runtime this library runs on.  A process may hold two ROCm
+        // stacks (PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 / librccl): a bare
+        // dlopen("librccl.so.1") then returns whichever was loaded first, possibly one whose HSA copy was
+        // never initialised ("no ROCm-capable device is detected").  So: look beside the libamdhip64 that
+        // hipGetDeviceCount resolves to, and only then fall back to the search path.
+        std::vector<std::string> names;
+        {
+            Dl_info di;
+            if (dladdr((void *)&hipGetDeviceCount, &di) && di.dli_fname) {
+                std::string dir(di.dli_fname);
+                size_t slash = dir.rfind('/');
+                if (slash != std::string::npos) {
+                    dir.resize(slash + 1);
+                    names.push_back(dir + "librccl.so.1");
+                    names.push_back(dir + "librccl.so");
+                }
+            }
+        }
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        void *h = nullptr;
+        for (const std::string &nm : names)
+            if ((h = dlopen(nm.c_str(), RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) { g_err = std::string("cannot load RCCL: ") + dlerror(); return nullptr; }
+        api.h = h;
+#define RSYM(field, name) *(void **)(&api.field) = dlsym(h, name); if (!api.field) { g_err = "RCCL symbol missing: " name; return nullptr; }
+        RSYM(GetUniqueId, "ncclGetUniqueId")
+        RSYM(CommInitRank, "ncclCommInitRank")
+        RSYM(CommInitAll, "ncclCommInitAll")
+        RSYM(CommDestroy, "ncclCommDestroy")
+        RSYM(Broadcast, "ncclBroadcast")
+        RSYM(AllReduce, "ncclAllReduce")
+        RSYM(GroupStart, "ncclGroupStart")
+        RSYM(GroupEnd, "ncclGroupEnd")
+        RSYM(GetErrorString, "ncclGetErrorString")
+#undef RSYM
+        state = 1;
+    }
+    return state == 1 ? &api : nullptr;
+}
+
+static void rccl_comm_destroy(ncclComm_t c)
+{
+    RcclApi *R = rccl_api();
+    if (R && c) R->CommDestroy(c);
+}
+
+#define NCCLCHK(expr)                                                             \
+    do {                                                                          \
+        ncclResult_t r__ = (expr);                                                \
+        if (r__ != ncclSuccess) {                                                 \
+            char b__[512];                                                        \
+            snprintf(b__, sizeof b__, "%s failed: %s (%s:%d)", #expr,             \
+                     rccl_api() ? rccl_api()->GetErrorString(r__) : "?", __FILE__, __LINE__); \
+            g_err = b__;                                                          \
+            return -200 - (int)r__;                                               \
+        }                                                                         \
+    } while (0)
+
+// ---------------------------------------------------------------------------
 struct cocons_fit {
     int n, p, r, q, device;
     pid_t pid;
@@ -154,6 +238,17 @@ struct cocons_fit {
     unsigned *dflags;             // 2 * flags_cap words: in[t], out[t] (see launch_potrf_engine)
     int flags_cap;
     bool engine_ok;               // false: plain schedule (batch slots; or after a hand-off timed out)
+    // collectives of the natively sharded evaluation (see "native sharded evaluation" below)
+    int coll_kind;                // 0 none, 1 RCCL communicator, 2 caller-provided transport
+    int coll_rank, coll_world;
+    ncclComm_t comm;
+    bool comm_own;                // the communicator was created by cocons_fit_comm_init (destroy it with the fit)
+    cocons_bcast_fn cb_bcast;
+    cocons_allreduce_fn cb_allreduce;
+    void *cb_user;
+    hipStream_t cstream;          // stream the panel broadcasts are issued on
+    hipEvent_t ev_main[2], ev_comm[2];   // per exchange buffer: pack / last reader done, broadcast done
+    double *dcoll;                // device staging of the final all-reduce (RCCL)
     double upd_flops;             // algorithmic flops of the event-timed trailing updates (profile runs)
     // host copies of the inputs + lazily created clones: the slots of cocons_neg2loglik_batch
     std::vector<double> *h_locs, *h_X, *h_z;
@@ -199,6 +294,11 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
         if (f->ev_eng) hipEventDestroy(f->ev_eng);
         hipFree(f->dflags);
+        if (f->cstream) { hipStreamSynchronize(f->cstream); hipStreamDestroy(f->cstream); }
+        for (auto &e : f->ev_main) if (e) hipEventDestroy(e);
+        for (auto &e : f->ev_comm) if (e) hipEventDestroy(e);
+        hipFree(f->dcoll);
+        if (f->comm && f->comm_own) rccl_comm_destroy(f->comm);
         if (f->slots) { for (auto c : *f->slots) cocons_fit_destroy(c); delete f->slots; f->slots = nullptr; }
         if (f->unsorted) { cocons_fit_destroy(f->unsorted); f->unsorted = nullptr; }
         if (f->stream2) hipStreamDestroy(f->stream2);
@@ -622,6 +722,7 @@ static bool engine_retry(cocons_fit *f, int st)
 
 static const double LOG_2PI = 1.8378770664093454835606594728112;
 static void dense_collect(cocons_fit *f, double *sum_logliks, double *parts);
+static int sharded_eval(cocons_fit *f, const double *theta, const double *mean, double *sum_logliks, double *parts);
 
 extern "C" int cocons_neg2loglik_dense(cocons_fit *f, const double *theta, const double *mean,
                                        double *sum_logliks, double *parts)
@@ -629,6 +730,7 @@ extern "C" int cocons_neg2loglik_dense(cocons_fit *f, const double *theta, const
     if (int rc = fit_check(f)) return rc;
     if (!theta || !mean || !sum_logliks) return fail(-1, "cocons_neg2loglik_dense: null argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_dense: fit has no z");
+    if (f->coll_kind) return sharded_eval(f, theta, mean, sum_logliks, parts);    // (also with one rank: the caller asked for it)
     for (;;) {
         if (int rc = enqueue_eval(f, theta, mean, true, nullptr, 0, nullptr, false)) return rc;
         HIPCHK(hipStreamSynchronize(f->stream));
@@ -1413,6 +1515,275 @@ extern "C" int cocons_shard_finish(cocons_fit *f, double *partial, int *info)
     for (int c = 0; c < cnt; ++c)
         for (int i = 0; i < len; ++i) partial[i] += f->hout[(size_t)c * len + i];
     if (info) *info = *f->hinfo;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// native sharded evaluation: the schedule of cocons_shard_* above, driven from inside the library, with
+// the panel broadcasts on a communication stream of their own.
+//
+// Per panel k (256 columns), exchange buffer b = k & 1:
+//   main stream M :  [owner] update + factor + pack panel k            -> record ev_main[b]
+//   comm stream C :  wait ev_main[b] ; broadcast buffer b from owner(k) -> record ev_comm[b]
+//   main stream M :  wait ev_comm[b] ; apply panel k to the own panels right of it
+// The owner of panel k+1 applies panel k to that panel FIRST, factors it and hands it to C before it applies
+// panel k to the rest, so the broadcast of k+1 travels while every rank is busy with the update of panel k
+// (two panels in flight; ev_main[b] also covers the last reader of buffer b, panel k-1's update).
+// Comm budget at n = 10^4: 40 panels, <= 20.7 MB each, 0.41 GB per evaluation.
+
+extern "C" int cocons_fit_world(cocons_fit *f) { return (f && f->coll_kind) ? f->coll_world : 1; }
+
+static int coll_prepare(cocons_fit *f)
+{
+    if (!f->cstream) HIPCHK(hipStreamCreateWithFlags(&f->cstream, hipStreamNonBlocking));
+    for (auto &e : f->ev_main) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : f->ev_comm) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!f->dcoll) HIPCHK(hipMalloc(&f->dcoll, (size_t)(2 + (COCONS_P_MAX + f->r) * (COCONS_P_MAX + f->r)) * sizeof(double)));
+    return 0;
+}
+
+extern "C" int cocons_comm_unique_id(void *id_out)
+{
+    if (!id_out) return fail(-1, "cocons_comm_unique_id: null argument");
+    RcclApi *R = rccl_api();
+    if (!R) return -1;
+    ncclUniqueId id;
+    NCCLCHK(R->GetUniqueId(&id));
+    static_assert(sizeof(ncclUniqueId) == COCONS_UNIQUE_ID_BYTES, "unique id size");
+    memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+extern "C" int cocons_fit_comm_init(cocons_fit *f, int nranks, int rank, const void *idp)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!idp || nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "cocons_fit_comm_init: bad argument");
+    if (f->coll_kind) return fail(-1, "cocons_fit_comm_init: the fit already has collectives");
+    RcclApi *R = rccl_api();
+    if (!R) return -1;
+    ncclUniqueId id;
+    memcpy(&id, idp, sizeof id);
+    // RCCL polls hipGetLastError() after its own launches: a stale (already handled) error code of this
+    // process must not be mistaken for a failure of the communicator set-up
+    (void)hipGetLastError();
+    NCCLCHK(R->CommInitRank(&f->comm, nranks, id, rank));
+    f->comm_own = true;
+    f->coll_kind = 1; f->coll_rank = rank; f->coll_world = nranks;
+    return coll_prepare(f);
+}
+
+extern "C" int cocons_fit_set_collectives(cocons_fit *f, int rank, int world, cocons_bcast_fn bcast,
+                                          cocons_allreduce_fn allreduce, void *user)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (world < 1 || rank < 0 || rank >= world || !bcast || !allreduce)
+        return fail(-1, "cocons_fit_set_collectives: bad argument");
+    if (f->coll_kind == 1) return fail(-1, "cocons_fit_set_collectives: the fit already has an RCCL communicator");
+    f->coll_kind = 2; f->coll_rank = rank; f->coll_world = world;
+    f->cb_bcast = bcast; f->cb_allreduce = allreduce; f->cb_user = user;
+    return coll_prepare(f);
+}
+
+static inline long long shard_panel_bytes(cocons_fit *f, int k)
+{
+    const int w = (f->nt - k * PT) < PT ? (f->nt - k * PT) : PT;
+    return (long long)(panel_rows(f, k) * (size_t)w * TILE * sizeof(double));
+}
+
+// hand panel k (already packed on the owner) to the communication stream
+static int coll_bcast_panel(cocons_fit *f, int k, bool in_group)
+{
+    const int b = k & 1, owner = k % f->coll_world;
+    const long long bytes = shard_panel_bytes(f, k);
+    HIPCHK(hipEventRecord(f->ev_main[b], f->stream));
+    HIPCHK(hipStreamWaitEvent(f->cstream, f->ev_main[b], 0));
+    if (f->coll_kind == 1) {
+        RcclApi *R = rccl_api();
+        NCCLCHK(R->Broadcast(f->xbuf[b], f->xbuf[b], (size_t)(bytes / 8), ncclDouble, owner, f->comm, f->cstream));
+        if (!in_group) HIPCHK(hipEventRecord(f->ev_comm[b], f->cstream));
+    } else {
+        if (f->cb_bcast(f->cb_user, f->xbuf[b], bytes, owner, (void *)f->cstream) != 0)
+            return fail(-6, "caller-provided broadcast failed");
+        HIPCHK(hipEventRecord(f->ev_comm[b], f->cstream));
+    }
+    return 0;
+}
+
+// one rank's part of schedule step k: everything between "panel k has arrived" and "panel k is applied"
+static int shard_step_pre(cocons_fit *f, int k, int np)
+{
+    HIPCHK(hipStreamWaitEvent(f->stream, f->ev_comm[k & 1], 0));
+    const int nxt = k + 1;
+    if (nxt < np && f->coll_rank == nxt % f->coll_world) {
+        if (int rc = shard_apply_range(f, k, nxt, nxt + 1)) return rc;      // only the columns of panel k+1 ...
+        if (int rc = cocons_shard_panel_factor(f, nxt)) return rc;          // ... factor and pack it
+    }
+    return 0;
+}
+
+static int shard_step_post(cocons_fit *f, int k, int np)
+{
+    const int nxt = k + 1;
+    if (nxt < np && f->coll_rank == nxt % f->coll_world) return shard_apply_range(f, k, nxt + 1, -1);
+    return shard_apply_range(f, k, k + 1, -1);
+}
+
+static int sharded_eval(cocons_fit *f, const double *theta, const double *mean, double *sum_logliks, double *parts)
+{
+    const int rank = f->coll_rank, world = f->coll_world;
+    if (int rc = cocons_shard_begin(f, theta, mean, rank, world)) return rc;
+    const int np = cocons_shard_num_panels(f);
+    if (rank == 0)
+        if (int rc = cocons_shard_panel_factor(f, 0)) return rc;
+    if (int rc = coll_bcast_panel(f, 0, false)) return rc;
+    for (int k = 0; k < np; ++k) {
+        if (int rc = shard_step_pre(f, k, np)) return rc;
+        if (k + 1 < np)
+            if (int rc = coll_bcast_panel(f, k + 1, false)) return rc;
+        if (int rc = shard_step_post(f, k, np)) return rc;
+    }
+    const int nr = f->r, len = 1 + nr * nr;
+    std::vector<double> part(len + 1);
+    int info = 0;
+    if (int rc = cocons_shard_finish(f, part.data(), &info)) return rc;
+    HIPCHK(hipStreamSynchronize(f->cstream));
+    double minfo = (double)info;                       // 0x7f7f7f7f = no failing minor (exact in a double)
+    if (world > 1) {
+        if (f->coll_kind == 1) {
+            RcclApi *R = rccl_api();
+            HIPCHK(hipMemcpyAsync(f->dcoll, part.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice, f->cstream));
+            HIPCHK(hipMemcpyAsync(f->dcoll + len, &minfo, sizeof(double), hipMemcpyHostToDevice, f->cstream));
+            NCCLCHK(R->AllReduce(f->dcoll, f->dcoll, (size_t)len, ncclDouble, ncclSum, f->comm, f->cstream));
+            NCCLCHK(R->AllReduce(f->dcoll + len, f->dcoll + len, 1, ncclDouble, ncclMin, f->comm, f->cstream));
+            HIPCHK(hipMemcpyAsync(part.data(), f->dcoll, (size_t)(len + 1) * sizeof(double), hipMemcpyDeviceToHost, f->cstream));
+            HIPCHK(hipStreamSynchronize(f->cstream));
+            minfo = part[len];
+        } else {
+            if (f->cb_allreduce(f->cb_user, part.data(), len, 0) != 0 || f->cb_allreduce(f->cb_user, &minfo, 1, 1) != 0)
+                return fail(-6, "caller-provided all-reduce failed");
+        }
+    }
+    if (minfo != (double)0x7f7f7f7f) {
+        int st = (int)minfo;
+        if (st > f->n) st = f->n;
+        g_err = "leading minor not positive";
+        return st;
+    }
+    double total = 0.0;
+    for (int c = 0; c < nr; ++c) {
+        const double quad = part[1 + c * nr + c];
+        total += f->n * LOG_2PI + 2 * part[0] + quad;
+        if (parts) parts[1 + c] = quad;
+    }
+    if (parts) parts[0] = part[0];
+    *sum_logliks = total;
+    return 0;
+}
+
+// ---- one process, several GPUs ---------------------------------------------------------------------
+struct cocons_multi {
+    int ndev;
+    std::vector<cocons_fit *> fits;
+    std::vector<ncclComm_t> comms;
+};
+
+extern "C" void cocons_multi_destroy(cocons_multi *m)
+{
+    if (!m) return;
+    for (auto f : m->fits) cocons_fit_destroy(f);          // (communicators are not owned by the fits)
+    for (auto c : m->comms) rccl_comm_destroy(c);
+    delete m;
+}
+
+extern "C" cocons_multi *cocons_multi_create(int n, int p, int r, const double *locs, const double *X, const double *z,
+                                             const double *smooth_limits, int ndev, const int *devices)
+{
+    if (ndev < 1 || !devices || r < 1) { fail(-1, "cocons_multi_create: bad argument"); return nullptr; }
+    RcclApi *R = rccl_api();
+    if (!R) return nullptr;
+    cocons_multi *m = new cocons_multi();
+    m->ndev = ndev;
+    for (int d = 0; d < ndev; ++d) {
+        cocons_fit *f = cocons_fit_create(n, p, r, 0, locs, X, z, nullptr, smooth_limits, devices[d]);
+        if (!f) { cocons_multi_destroy(m); return nullptr; }
+        m->fits.push_back(f);
+    }
+    m->comms.assign(ndev, nullptr);
+    (void)hipGetLastError();
+    ncclResult_t nr = R->CommInitAll(m->comms.data(), ndev, devices);
+    if (nr != ncclSuccess) {
+        fail(-200, "ncclCommInitAll: %s", R->GetErrorString(nr));
+        m->comms.clear();
+        cocons_multi_destroy(m);
+        return nullptr;
+    }
+    for (int d = 0; d < ndev; ++d) {
+        cocons_fit *f = m->fits[d];
+        f->comm = m->comms[d]; f->comm_own = false;
+        f->coll_kind = 1; f->coll_rank = d; f->coll_world = ndev;
+        if (fit_check(f) != 0 || coll_prepare(f) != 0) { cocons_multi_destroy(m); return nullptr; }
+    }
+    return m;
+}
+
+// The calling thread drives every device: each schedule step is enqueued on all devices in turn (all calls
+// are asynchronous), the per-panel broadcasts of the ranks are issued inside one RCCL group.
+extern "C" int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *theta, const double *mean,
+                                             double *sum_logliks, double *parts)
+{
+    if (!m || !theta || !mean || !sum_logliks) return fail(-1, "cocons_multi_neg2loglik_dense: null argument");
+    RcclApi *R = rccl_api();
+    if (!R) return -1;
+    const int W = m->ndev;
+    for (int d = 0; d < W; ++d)
+        if (int rc = cocons_shard_begin(m->fits[d], theta, mean, d, W)) return rc;
+    const int np = cocons_shard_num_panels(m->fits[0]);
+    auto group_bcast = [&](int k) -> int {
+        NCCLCHK(R->GroupStart());
+        for (int d = 0; d < W; ++d) {
+            if (int rc = fit_check(m->fits[d])) return rc;
+            if (int rc = coll_bcast_panel(m->fits[d], k, true)) return rc;
+        }
+        NCCLCHK(R->GroupEnd());
+        for (int d = 0; d < W; ++d) {
+            if (int rc = fit_check(m->fits[d])) return rc;
+            HIPCHK(hipEventRecord(m->fits[d]->ev_comm[k & 1], m->fits[d]->cstream));
+        }
+        return 0;
+    };
+    if (int rc = cocons_shard_panel_factor(m->fits[0], 0)) return rc;
+    if (int rc = group_bcast(0)) return rc;
+    for (int k = 0; k < np; ++k) {
+        for (int d = 0; d < W; ++d)
+            if (int rc = shard_step_pre(m->fits[d], k, np)) return rc;
+        if (k + 1 < np)
+            if (int rc = group_bcast(k + 1)) return rc;
+        for (int d = 0; d < W; ++d)
+            if (int rc = shard_step_post(m->fits[d], k, np)) return rc;
+    }
+    cocons_fit *f0 = m->fits[0];
+    const int nr = f0->r, len = 1 + nr * nr;
+    std::vector<double> tot(len, 0.0), part(len);
+    int info_min = 0x7f7f7f7f;
+    for (int d = 0; d < W; ++d) {
+        int info = 0;
+        if (int rc = cocons_shard_finish(m->fits[d], part.data(), &info)) return rc;
+        HIPCHK(hipStreamSynchronize(m->fits[d]->cstream));
+        for (int i = 0; i < len; ++i) tot[i] += part[i];
+        if (info < info_min) info_min = info;
+    }
+    if (info_min != 0x7f7f7f7f) {
+        g_err = "leading minor not positive";
+        return info_min > f0->n ? f0->n : info_min;
+    }
+    double total = 0.0;
+    for (int c = 0; c < nr; ++c) {
+        const double quad = tot[1 + c * nr + c];
+        total += f0->n * LOG_2PI + 2 * tot[0] + quad;
+        if (parts) parts[1 + c] = quad;
+    }
+    if (parts) parts[0] = tot[0];
+    *sum_logliks = total;
     return 0;
 }
 

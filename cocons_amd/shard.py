@@ -1,22 +1,33 @@
 """Column-panel sharded -2 log-likelihood across the GPUs of one node.
 
-One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI) as plumbing.
 The reference's `chol` (R/neg2loglikelihood.R:200) reads the upper triangle of Sigma row
 block by row block; those row blocks are the column panels of the lower factor kept on
-the device, so "Sigma row-block partitioned" = panels dealt block-cyclically over ranks:
+the device, so "Sigma row-block partitioned" = panels (256 columns) dealt block-cyclically
+over the ranks:
 
-    for each panel k (256 columns):
+    for each panel k:
         owner(k) = k mod world : factor the panel in place (potrf + panel solve), pack it
-        broadcast the packed panel (<= 20 MB at n = 10^4) from its owner      <- the only collective
-        every rank: update its OWN panels right of k with the received panel   (MFMA fp64)
-    all-reduce of {sum log diag, Gram of the rhs rows} partial sums           (1 + r^2 doubles)
+        broadcast the packed panel (<= 20.7 MB at n = 10^4) from its owner     <- the only collective
+        every rank: update its OWN panels right of k with the received panel    (MFMA fp64)
+    all-reduce of {sum log diag, Gram of the rhs rows} partial sums             (1 + r^2 doubles)
 
-Assembly needs no exchange: every rank builds the per-location vectors (O(n p)) and
-assembles only its own panels.  The right-hand sides ride along as extra rows of every
-panel, so no distributed triangular solve exists.
+The schedule, the RCCL broadcasts (on a communication stream of their own, two panels in
+flight) and the final all-reduce all live INSIDE the HIP library (`sharded_eval` in
+csrc/api.hip): once a fit has collectives, `cocons_neg2loglik_dense` on it is the sharded
+evaluation.  This module only wires a fit to its communicator:
 
-The schedule below is engine-agnostic: `engine` is a `ShardedFit` (HIP) in production; the
-CPU tests drive the same loop over gloo with a numpy engine that lives under tests/.
+  * `ShardedFit.init_rccl(dist)`    one process per GPU: rank 0 draws the RCCL unique id
+    (`cocons_comm_unique_id`), the 128 bytes travel over the host's process group
+    (torch.distributed here; R would use its own socket/MPI), every rank calls
+    `cocons_fit_comm_init`.  torch carries no panel, no reduction, no stream.
+  * `ShardedFit.init_host_transport(dist)`   tests: several ranks share ONE GPU, which RCCL refuses;
+    the library's broadcast / all-reduce hooks (`cocons_fit_set_collectives`) are served by
+    gloo through host memory.  Same native schedule, different wire.
+  * `MultiFit`   one process, several GPUs (`cocons_multi_*`, ncclCommInitAll).
+
+`sharded_neg2loglik_core(engine, ...)` further down is the same schedule in Python over an abstract
+engine: the CPU tests run it over gloo with a numpy engine (tests/np_shard_engine.py), which pins the
+schedule's logic (ownership, look-ahead order, buffer alternation) where no GPU exists.
 """
 from __future__ import annotations
 
@@ -32,74 +43,130 @@ INFO_OK = 0x7F7F7F7F
 LOG_2PI = math.log(2.0 * math.pi)
 
 
+def _hip_runtime():
+    """libamdhip64 through ctypes, for the host-transport hooks (device <-> host copies)."""
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            lib = ctypes.CDLL(name)
+            break
+        except OSError:
+            lib = None
+    if lib is None:
+        raise _lib.CoconsHipError("cannot load the HIP runtime")
+    lib.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    lib.hipMemcpy.restype = ctypes.c_int
+    lib.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    lib.hipStreamSynchronize.restype = ctypes.c_int
+    return lib
+
+
 class ShardedFit(CoconsFit):
-    """CoconsFit whose factorisation is split over the ranks of a process group.  The
-    exchange buffers are torch tensors so that torch.distributed can broadcast them in
-    place, and all kernels run on torch's current stream (collectives are ordered
-    against it by torch)."""
+    """CoconsFit whose evaluation is split over the ranks of a process group; see the module
+    docstring.  `neg2loglik_core` (inherited) returns the same value on every rank."""
 
     def __init__(self, locs, x_covariates, z, smooth_limits, device):
-        import torch
-        self.torch = torch
-        self.device = torch.device("cuda", device)
-        torch.cuda.set_device(self.device)
         super().__init__(locs, x_covariates, z, smooth_limits, device=device)
-        L = self._L
-        nbytes = int(L.cocons_shard_exchange_bytes(self._h))
-        self._xbuf = [torch.empty(nbytes // 8, dtype=torch.float64, device=self.device) for _ in range(2)]
-        self._pinned_stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(L.cocons_fit_set_stream(self._h, ctypes.c_void_p(self._pinned_stream)),
-                   "cocons_fit_set_stream")
-        _lib.check(L.cocons_shard_set_exchange(self._h, ctypes.c_void_p(self._xbuf[0].data_ptr()),
-                                               ctypes.c_void_p(self._xbuf[1].data_ptr()), nbytes),
-                   "cocons_shard_set_exchange")
+        self._keep = []          # ctypes callbacks must outlive the handle
 
-    # engine interface ------------------------------------------------------
-    def begin(self, theta_list, rank, world):
-        # (re)pin the handle to the stream that is current NOW: torch orders the collectives of this
-        # evaluation against its current stream, so the kernels must be on the same one
-        cur = self.torch.cuda.current_stream().cuda_stream
-        if cur != self._pinned_stream:
-            _lib.check(self._L.cocons_fit_set_stream(self._h, ctypes.c_void_p(cur)), "cocons_fit_set_stream")
-            self._pinned_stream = cur
+    def world(self):
+        return int(self._L.cocons_fit_world(self._h))
+
+    def init_rccl(self, dist, rank, world, group=None):
+        """One process per GPU: share the RCCL unique id over `dist` (any backend that moves 128 host
+        bytes) and create this rank's communicator inside the library."""
+        import torch
+        buf = (ctypes.c_ubyte * _lib.UNIQUE_ID_BYTES)()
+        if rank == 0:
+            _lib.check(self._L.cocons_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "cocons_comm_unique_id")
+        t = torch.tensor(list(buf), dtype=torch.uint8)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=0, group=group)
+        raw = bytes(t.cpu().tolist())
+        idb = (ctypes.c_ubyte * _lib.UNIQUE_ID_BYTES).from_buffer_copy(raw)
+        _lib.check(self._L.cocons_fit_comm_init(self._h, world, rank, ctypes.cast(idb, ctypes.c_void_p)),
+                   "cocons_fit_comm_init")
+
+    def init_host_transport(self, dist, rank, world, group=None):
+        """Tests: serve the library's broadcast / all-reduce hooks with `dist` (gloo) through host memory."""
+        import torch
+        hip = _hip_runtime()
+        D2H, H2D = 2, 1
+
+        def bcast(user, dev_ptr, nbytes, root, stream):
+            try:
+                if hip.hipStreamSynchronize(stream) != 0:
+                    return 1
+                host = np.empty(nbytes // 8, dtype=np.float64)
+                if rank == root and hip.hipMemcpy(host.ctypes.data, dev_ptr, nbytes, D2H) != 0:
+                    return 2
+                dist.broadcast(torch.from_numpy(host), src=root, group=group)
+                if rank != root and hip.hipMemcpy(dev_ptr, host.ctypes.data, nbytes, H2D) != 0:
+                    return 3
+                return 0
+            except Exception:                                   # noqa: BLE001
+                return 9
+
+        def allreduce(user, ptr, count, op):
+            try:
+                arr = np.ctypeslib.as_array(ptr, shape=(count,))
+                t = torch.from_numpy(arr.copy())
+                dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN, group=group)
+                arr[:] = t.numpy()
+                return 0
+            except Exception:                                   # noqa: BLE001
+                return 9
+
+        cb_b, cb_a = _lib.BCAST_FN(bcast), _lib.ALLREDUCE_FN(allreduce)
+        self._keep += [cb_b, cb_a]
+        _lib.check(self._L.cocons_fit_set_collectives(self._h, rank, world, ctypes.cast(cb_b, ctypes.c_void_p),
+                                                      ctypes.cast(cb_a, ctypes.c_void_p), None),
+                   "cocons_fit_set_collectives")
+
+
+class MultiFit:
+    """One process driving several GPUs (cocons_multi_*): what a single R session calls."""
+
+    def __init__(self, locs, x_covariates, z, smooth_limits, devices):
+        L = _lib.load()
+        self._L = L
+        locs = np.asfortranarray(np.asarray(locs, dtype=np.float64))
+        X = np.asfortranarray(np.asarray(x_covariates, dtype=np.float64))
+        self.n, self.p = X.shape
+        z = np.asfortranarray(np.asarray(z, dtype=np.float64).reshape(self.n, -1))
+        self.r = z.shape[1]
+        sl = np.asarray(smooth_limits, dtype=np.float64)
+        dev = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = L.cocons_multi_create(self.n, self.p, self.r, _p(locs), _p(X), _p(z), _p(sl), len(devices), dev)
+        if not self._h:
+            raise _lib.CoconsHipError("cocons_multi_create failed: " + _lib.last_error())
+
+    def neg2loglik_core(self, theta_list):
         T = theta_table(theta_list)
         mean = np.ascontiguousarray(np.asarray(theta_list["mean"], dtype=np.float64))
-        _lib.check(self._L.cocons_shard_begin(self._h, _p(T), _p(mean), rank, world), "cocons_shard_begin")
+        val = ctypes.c_double(0.0)
+        parts = np.zeros(1 + self.r)
+        _lib.check(self._L.cocons_multi_neg2loglik_dense(self._h, _p(T), _p(mean), ctypes.byref(val), _p(parts)),
+                   "cocons_multi_neg2loglik_dense")
+        return val.value, parts
 
-    def num_panels(self):
-        return int(self._L.cocons_shard_num_panels(self._h))
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cocons_multi_destroy(self._h)
+            self._h = None
 
-    def panel_factor(self, k):
-        _lib.check(self._L.cocons_shard_panel_factor(self._h, k), "cocons_shard_panel_factor")
-
-    def panel_tensor(self, k):
-        nbytes = ctypes.c_longlong(0)
-        ptr = ctypes.c_void_p()
-        _lib.check(self._L.cocons_shard_panel_buffer(self._h, k, ctypes.byref(ptr), ctypes.byref(nbytes)),
-                   "cocons_shard_panel_buffer")
-        buf = self._xbuf[k & 1]
-        assert ptr.value == buf.data_ptr()
-        return buf[: nbytes.value // 8]
-
-    def panel_apply(self, k, j0=None, j1=None):
-        """update own panels j in [j0, j1) (default: all right of k) with the received panel k"""
-        j0 = k + 1 if j0 is None else j0
-        j1 = -1 if j1 is None else j1
-        _lib.check(self._L.cocons_shard_panel_apply_range(self._h, k, j0, j1), "cocons_shard_panel_apply_range")
-
-    def finish(self):
-        part = np.zeros(1 + self.r * self.r)
-        info = ctypes.c_int(0)
-        _lib.check(self._L.cocons_shard_finish(self._h, _p(part), ctypes.byref(info)), "cocons_shard_finish")
-        return part, info.value
-
-    def make_tensor(self, arr):
-        return self.torch.as_tensor(arr, device=self.device)
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                       # noqa: BLE001
+            pass
 
 
 def sharded_neg2loglik_core(engine, theta_list, dist, rank, world, group=None, lookahead=True):
-    """One sharded evaluation.  Returns (sum_logliks, parts) like CoconsFit.neg2loglik_core,
-    identical on every rank; raises CholeskyError on every rank if any panel failed.
+    """The sharded schedule over an abstract engine (begin / panel_factor / panel_tensor / panel_apply /
+    finish): the Python twin of `sharded_eval` in csrc/api.hip, run by the CPU tests with a numpy engine.
+    Returns (sum_logliks, parts), identical on every rank; raises CholeskyError on every rank if any
+    panel failed.
 
     Look-ahead: the owner of panel k+1 updates and factors that panel FIRST and starts its
     broadcast asynchronously; every rank then applies panel k to the rest of its panels while
@@ -162,7 +229,8 @@ def sharded_predict_core(fit, theta_list, locs_pred, x_covariates_pred, dist, ra
     """Dense kriging (R/predict.R:136-183) with the m prediction locations split over the ranks
     (BASELINE config C5: the right-hand sides shard): every rank factors Sigma with
     its own m/world cross-covariance rows as border -- no exchange during the solve -- and the
-    (stochastic, quadratic-form) vectors are all-gathered.  `fit` is a plain CoconsFit per rank."""
+    (stochastic, quadratic-form) vectors are gathered at the end (O(m) doubles).  `fit` is a plain
+    CoconsFit per rank."""
     lp = np.asarray(locs_pred, dtype=np.float64)
     Xp = np.asarray(x_covariates_pred, dtype=np.float64)
     m = lp.shape[0]

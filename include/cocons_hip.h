@@ -169,7 +169,46 @@ int cocons_vfma_f64_probe(int blocks_per_cu, double *tflops);
  * tests/golden/besselk_grid.json (host arrays in, host array out).                    */
 int cocons_debug_matern(int n, const double *nu, const double *u, double *out);
 
-/* ---- column-panel sharded evaluation across GPUs (one process per GPU) ---------
+/* ---- natively sharded evaluation across the GPUs of one node ----------------------
+ * Sigma row blocks (= column panels of the lower factor kept here, 256 columns each) are dealt
+ * block-cyclically over the ranks; per panel the owner factors it and the library broadcasts it with
+ * RCCL over xGMI on a stream of its own (two panels in flight), every rank updates its own panels, and
+ * the 1 + r^2 partial sums (+ the failing minor) are all-reduced at the end.  No data-path call leaves
+ * the library: once a fit has collectives, cocons_neg2loglik_dense on it IS the sharded evaluation and
+ * returns the same value on every rank.
+ *
+ * (a) one process per GPU (torch.distributed.run, MPI, optimParallel workers ...): rank 0 calls
+ *     cocons_comm_unique_id, the 128 bytes reach the other ranks by whatever channel the host has, and
+ *     every rank calls cocons_fit_comm_init on its own fit (ncclCommInitRank).
+ * (b) one process, several GPUs (what a single R session needs, R/optim.R:117-121's single-caller model):
+ *     cocons_multi_create takes the device list (ncclCommInitAll), cocons_multi_neg2loglik_dense drives
+ *     all of them from the calling thread.
+ * (c) tests / other transports: cocons_fit_set_collectives installs caller-provided broadcast and
+ *     all-reduce functions (e.g. gloo when several ranks share one GPU, which RCCL refuses).           */
+#define COCONS_UNIQUE_ID_BYTES 128
+int cocons_comm_unique_id(void *id_out /* COCONS_UNIQUE_ID_BYTES */);
+int cocons_fit_comm_init(cocons_fit *fit, int nranks, int rank, const void *id /* COCONS_UNIQUE_ID_BYTES */);
+/* broadcast `bytes` at device pointer dev_ptr from rank `root` to every rank; `stream` (hipStream_t) is the
+ * library's communication stream: the function may enqueue on it or block.  Return 0 on success.        */
+typedef int (*cocons_bcast_fn)(void *user, void *dev_ptr, long long bytes, int root, void *stream);
+/* in-place all-reduce of `count` HOST doubles, op 0 = sum, 1 = min; blocking.                            */
+typedef int (*cocons_allreduce_fn)(void *user, double *host_inout, int count, int op);
+int cocons_fit_set_collectives(cocons_fit *fit, int rank, int world, cocons_bcast_fn bcast,
+                               cocons_allreduce_fn allreduce, void *user);
+/* number of ranks the fit is sharded over (1 = not sharded) */
+int cocons_fit_world(cocons_fit *fit);
+
+typedef struct cocons_multi cocons_multi;   /* one fit per device + their communicators */
+cocons_multi *cocons_multi_create(int n, int p, int r, const double *locs, const double *X, const double *z,
+                                  const double *smooth_limits, int ndev, const int *devices);
+void cocons_multi_destroy(cocons_multi *m);
+/* same outputs as cocons_neg2loglik_dense */
+int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *theta, const double *mean,
+                                  double *sum_logliks, double *parts);
+
+/* ---- column-panel sharded evaluation, step by step (the building blocks of the above; kept public for
+ * callers that bring their own schedule, and used by the CPU tests of the schedule) --------------------
+ * column-panel sharded evaluation across GPUs (one process per GPU) ---------
  * The reference's chol reads the UPPER triangle of Sigma row by row; its row
  * blocks are exactly the column panels of the lower factor kept here.  Panels
  * are dealt block-cyclically over `world` ranks; the caller (torch.distributed

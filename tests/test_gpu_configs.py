@@ -216,14 +216,14 @@ def _free_port():
     return p
 
 
-def _shard_worker(rank, world, port, g, out_dir):
+def _shard_worker(rank, world, port, g, out_dir, predict_first=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    import torch                      # noqa: F401  (before the HIP library, see cocons_amd/shard.py)
+    import torch                      # noqa: F401
     import torch.distributed as dist
     from cocons_amd import workloads as wl
-    from cocons_amd.shard import ShardedFit, sharded_neg2loglik_core
+    from cocons_amd.shard import ShardedFit
     dist.init_process_group("gloo", rank=rank, world_size=world)
     locs = wl.grid_locs(g)
     X = wl.design_from_locs(locs)["std.covs"]
@@ -231,22 +231,31 @@ def _shard_worker(rank, world, port, g, out_dir):
     th["mean"] = np.array([0.1, -0.2, 0.05])
     z = np.column_stack([wl.synthetic_z(g * g), wl.synthetic_z(g * g, seed=5)])
     fit = ShardedFit(locs, X, z, wl.SMOOTH_LIMITS, device=0)     # every rank on the one GPU of the box
-    val, parts = sharded_neg2loglik_core(fit, th, dist, rank, world)
+    if predict_first:
+        # grows the handle's border (leading dimension) before the sharded evaluation: the packed panels
+        # must still be sized by the rows in use (round-1 advisor finding)
+        fit.predict_core(th, locs[:300] + 1e-3, X[:300])
+    fit.init_host_transport(dist, rank, world)
+    assert fit.world() == world
+    val, parts = fit.neg2loglik_core(th)          # the library's own schedule; gloo is only the wire
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([[val], parts]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,g", [(2, 40), (3, 50), (4, 15), (2, 100)])
-def test_sharded_hip_engine_over_gloo(tmp_path, world, g):
-    """The production sharded path (HIP kernels + cocons_amd.shard schedule) with `world`
-    ranks sharing this box's single GPU and gloo carrying the panel broadcasts (RCCL refuses
-    several ranks on one device).  Must reproduce the single-GPU value.  (2, 100) is BASELINE
-    config C3 at its full size n = 10 000 in sharded form."""
+@pytest.mark.parametrize("world,g,predict_first", [(2, 40, False), (3, 50, False), (4, 15, False), (2, 40, True),
+                                                   (2, 100, False)])
+def test_native_sharded_evaluation_shared_gpu(tmp_path, world, g, predict_first):
+    """The production sharded path -- the schedule inside the HIP library (sharded_eval: panel ownership,
+    look-ahead, communication stream, double-buffered exchange, final all-reduce) -- with `world` ranks
+    sharing this box's single GPU.  RCCL refuses several ranks on one device, so the library's
+    broadcast / all-reduce hooks are served by gloo through host memory; everything else is the code the
+    RCCL build runs.  Must reproduce the single-GPU value.  (2, 100) is BASELINE config C3 at its full
+    size n = 10 000 in sharded form."""
     import torch.multiprocessing as mp
     import cocons_amd as ca
     from cocons_amd import workloads as wl
-    mp.spawn(_shard_worker, args=(world, _free_port(), g, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_shard_worker, args=(world, _free_port(), g, str(tmp_path), predict_first), nprocs=world, join=True)
     res = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r)) for r in range(world)]
     for r in res[1:]:
         assert np.array_equal(r, res[0])
@@ -258,6 +267,43 @@ def test_sharded_hip_engine_over_gloo(tmp_path, world, g):
     val, parts = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS).neg2loglik_core(th)
     assert abs(res[0][0] - val) < 1e-10 * abs(val)
     assert np.allclose(res[0][1:], parts, rtol=1e-10, atol=0)
+
+
+def test_native_sharded_rccl_one_rank_and_multi_handle():
+    """RCCL itself, as far as one GPU allows: a communicator of ONE rank created from a unique id
+    (cocons_comm_unique_id / cocons_fit_comm_init) and the one-process multi-GPU handle over the device
+    list [0] (cocons_multi_create -> ncclCommInitAll).  Both run the sharded schedule with ncclBroadcast /
+    ncclAllReduce on the library's communication stream and must reproduce the plain value."""
+    import ctypes
+    import cocons_amd as ca
+    from cocons_amd import _lib, workloads as wl
+    from cocons_amd.shard import MultiFit, ShardedFit
+    g = 36
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.1, -0.2, 0.05])
+    z = np.column_stack([wl.synthetic_z(g * g), wl.synthetic_z(g * g, seed=5)])
+    want, wparts = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS).neg2loglik_core(th)
+    fit = ShardedFit(locs, X, z, wl.SMOOTH_LIMITS, device=0)
+    L = _lib.load()
+    idb = (ctypes.c_ubyte * _lib.UNIQUE_ID_BYTES)()
+    _lib.check(L.cocons_comm_unique_id(ctypes.cast(idb, ctypes.c_void_p)), "cocons_comm_unique_id")
+    _lib.check(L.cocons_fit_comm_init(fit._h, 1, 0, ctypes.cast(idb, ctypes.c_void_p)), "cocons_fit_comm_init")
+    for _ in range(2):
+        got, parts = fit.neg2loglik_core(th)
+        assert abs(got - want) < 1e-10 * abs(want) and np.allclose(parts, wparts, rtol=1e-10, atol=0)
+    fit.close()
+    mf = MultiFit(locs, X, z, wl.SMOOTH_LIMITS, devices=[0])
+    got, parts = mf.neg2loglik_core(th)
+    assert abs(got - want) < 1e-10 * abs(want) and np.allclose(parts, wparts, rtol=1e-10, atol=0)
+    # a theta whose Sigma is not positive definite comes back as the failing minor on this path too
+    bad = {k: np.array(v, dtype=float) for k, v in th.items()}
+    bad["nugget"][0] = -800.0
+    bad["std.dev"][0], bad["scale"][0] = 0.0, 30.0
+    with pytest.raises(_lib.CholeskyError):
+        mf.neg2loglik_core(bad)
+    mf.close()
 
 
 def _predict_shard_worker(rank, world, port, out_dir):
