@@ -11,11 +11,16 @@ beside it (n^3/3 flop per evaluation).
   python bench.py [--gpus N] [--steps K] [--warmup W] [--n 10000] [--mode shard|replica]
 
 N = 1 : one GPU evaluates the whole thing.
-N > 1 : launched by torch.distributed.run, one rank per GPU (RCCL).  Default mode "shard":
-        Sigma's row blocks (= column panels of the factor) are dealt block-cyclically over
-        the ranks, panels are broadcast over xGMI (cocons_amd/shard.py); total work is fixed
-        -> "scaling": "strong".  Mode "replica": every rank evaluates its own theta (what
-        optimParallel's 1+2P finite-difference points are) -> "weak".
+N > 1 : one rank per GPU.  Started by torch.distributed.run (the ranks read RANK / LOCAL_RANK /
+        WORLD_SIZE) or bare (`python bench.py --gpus N`): then this process starts the N ranks itself
+        and never touches a GPU.  Default mode "shard": Sigma's row blocks (= column panels of the
+        factor) are dealt block-cyclically over the ranks and the evaluation is the library's native
+        sharded one (RCCL broadcasts on its own stream, csrc/api.hip `sharded_eval`); torch.distributed
+        only carries the 128-byte RCCL unique id, the barriers and the timing reduction (gloo).
+        Total work is fixed -> "scaling": "strong".  If the sharded path fails the run FAILS (non-zero
+        exit, no JSON value): a replica number is never reported in its place.
+        Mode "replica" (explicit): every rank evaluates its own theta (what optimParallel's 1+2P
+        finite-difference points are) -> "weak".
 
 Rank 0 prints ONE JSON line.
 """
@@ -38,8 +43,9 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (= fp64 vector peak): 256 CU x 4 SIMD
 #                                  x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 issues every 64 cycles
-MEASURED_MFMA_F64_TFLOPS = 49.0  # tools/probe_mfma.py on the GPU box: back-to-back v_mfma_f64_16x16x4_f64 on
-#                                  every SIMD, 8 waves/SIMD, operands in registers (32.6 / 43.9 / 47.4 / 49.0 at 1 / 2 / 4 / 8 waves per SIMD)
+MFMA_F64_16x16x4_TFLOPS = 48.7   # what the instruction the update kernel is built on sustains chip-wide (tools/
+#                                  probe_mfma_ex.py: one per ~102 cycles per SIMD at 2.37 GHz, no throttling)
+TRAFFIC_PROFILE = "r02_update_kernel_hbm_traffic.json"
 
 
 def chol_flops(n):
@@ -132,17 +138,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    ctl = None          # gloo control group: barriers / flags / timing, independent of the RCCL data path
+    ctl = None          # gloo group: rendezvous of the RCCL unique id, barriers, timing -- never a panel
     if world > 1:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
-                                    timeout=datetime.timedelta(seconds=300))
-        ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+        ctl = dist.group.WORLD
 
     g = int(round(math.sqrt(args.n)))
     n = g * g
@@ -166,27 +168,16 @@ def main():
         return float(t.item())
 
     shard_mode = world > 1 and args.mode == "shard"
-    shard_error = None
     if shard_mode:
-        # one sharded evaluation as a rehearsal: if the RCCL path fails on any rank, every rank
-        # falls back to replica mode (reported as such) instead of losing the whole run
-        from cocons_amd.shard import ShardedFit, sharded_neg2loglik_core
-        fit = None
-        try:
-            fit = ShardedFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
-            sharded_neg2loglik_core(fit, th, dist, rank, world)
-            torch.cuda.synchronize()
-        except Exception as e:                                  # noqa: BLE001
-            shard_error = "%s: %s" % (type(e).__name__, str(e)[:300])
-        if max_over_ranks(0.0 if shard_error is None else 1.0) > 0:
-            shard_mode = False
-            if shard_error is None:
-                shard_error = "sharded path failed on another rank"
-            if fit is not None:
-                fit.close()
-    if shard_mode:
+        from cocons_amd.shard import ShardedFit
+        fit = ShardedFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
+        if rehearsal:
+            fit.init_host_transport(dist, rank, world, group=ctl)     # ranks share one GPU: gloo is the wire
+        else:
+            fit.init_rccl(dist, rank, world, group=ctl)               # RCCL communicator inside the library
+
         def step():
-            return sharded_neg2loglik_core(fit, th, dist, rank, world)[0]
+            return fit.neg2loglik_core(th)[0]
     else:
         fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
         if world > 1:      # replica mode: every rank its own finite-difference point
@@ -292,55 +283,72 @@ def main():
 
     out = None
     if rank == 0:
-        stages = None
+        # stage timings and the dominant kernel's roofline come from THIS run: HIP events on the launch
+        # stream around every stage and every trailing-update launch (cocons_fit_profile).  For N > 1 they
+        # are taken on a plain single-GPU handle on rank 0 (the kernels are the same ones).
+        pfit = fit if not shard_mode else ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
+        st = pfit.profile_stages(th, reps=3)
+        stages = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()}
         roofline = None
-        if not shard_mode:
-            st = fit.profile_stages(th, reps=3)
-            stages = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()}
-            flops, launches = st["update_flops"], st["update_launches"]
-            if st["update_launches"] > 0 and st["update_sum_ms"] > 0:
-                achieved = flops / (st["update_sum_ms"] * 1e-3) / 1e12
-                roofline = {"bound": "mfma", "kernel": "cocons::update_kernel<64, 8, 0> (trailing SYRK/GEMM, v_mfma_f64_16x16x4_f64)",
-                            "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-                            "flops_per_launch": flops / max(launches, 1),
-                            "launch_ms": round(st["update_avg_ms"], 4), "launches_per_eval": st["update_launches"],
-                            "measured_mfma_f64_peak": MEASURED_MFMA_F64_TFLOPS,
-                            "traffic": None}
-                tr = os.path.join(ROOT, "profiles", "r01_update_kernel_hbm_traffic.json")
-                if n == 10000 and os.path.exists(tr):      # PMC pass of the same command (see file)
-                    with open(tr) as fh:
-                        roofline["traffic"] = json.load(fh)["hbm_bytes_per_launch_corrected"]
-                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        flops, launches = st["update_flops"], st["update_launches"]
+        if launches > 0 and st["update_sum_ms"] > 0:
+            achieved = flops / (st["update_sum_ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma",
+                        "kernel": "cocons::update_kernel<64, 8, 0> (trailing SYRK/GEMM, v_mfma_f64_16x16x4_f64)",
+                        "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                        "measured_in": "this run (HIP events around each launch on the launch stream)",
+                        "flops_per_launch": flops / max(launches, 1),
+                        "launch_ms": round(st["update_avg_ms"], 4), "launches_per_eval": launches,
+                        "instruction_ceiling_tflops": MFMA_F64_16x16x4_TFLOPS,
+                        "frac_of_instruction_ceiling": round(achieved / MFMA_F64_16x16x4_TFLOPS, 4),
+                        "instruction_ceiling_source": "tools/probe_mfma_ex.py on MI355X (profiles/r02_mfma_f64_probe.json): "
+                                                      "v_mfma_f64_16x16x4_f64 48.7 TFLOP/s, v_mfma_f64_4x4x4_4b_f64 76.2, "
+                                                      "both at an unthrottled 2.37 GHz",
+                        "traffic": None}
+            tr = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
+            if n == 10000 and os.path.exists(tr):
+                with open(tr) as fh:
+                    tj = json.load(fh)
+                roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+                roofline["traffic_source"] = "NOT measured in this run: profiles/%s (separate rocprofv3 --pmc passes of " \
+                                             "this command, commit %s); %s" % (TRAFFIC_PROFILE, tj.get("commit", "?"),
+                                                                               tj.get("note", ""))
+        chol_tf = chol_flops(n) / (stages["cholesky_ms"] * 1e-3) / 1e12
+        pairs = n * (n + 1) / 2.0
+        assembly = {"kernel": "cocons::pair_sym_kernel<0, false> (general-nu Bessel-K branch)", "bound": "fp64 valu",
+                    "ms": stages["assembly_ms"], "pairs_per_s": round(pairs / (stages["assembly_ms"] * 1e-3), 1),
+                    "hbm_write_GBps": round(8.0 * pairs / (stages["assembly_ms"] * 1e-3) / 1e9, 2),
+                    "note": "lower triangle only, written once into the factorisation buffer (8 B per pair)"}
         cpu = None
         parity = None
         if world == 1 and not args.no_cpu_baseline:
             cpu, cpu_val = cpu_baseline(n, locs, X, th, z)
             parity = abs(val - cpu_val) / abs(cpu_val)
-        chol_tf = None
-        if stages is not None:
-            chol_tf = chol_flops(n) / (stages["cholesky_ms"] * 1e-3) / 1e12
+        label = {10000: "C3", 4096: "C2"}.get(n, "grid")
         out = {
             "metric": "-2loglik evals/sec (dense cov_rns + Cholesky/solve/log-det, fp64) at n=%d" % n,
             "value": round(evals_per_s, 4), "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if (shard_mode or world == 1) else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C3: %dx%d grid n=%d, p=3, full nonstationary cov_rns (Bessel-K branch), r=1, "
-                                   "dense -2loglik" % (g, g, n),
-                       "parallelism": ("panel-sharded x%d (RCCL broadcast)" % world) if shard_mode else
-                                      ("replica x%d" % world if world > 1 else "single GPU"),
+            "config": {"workload": "%s: %dx%d grid n=%d, p=3, full nonstationary cov_rns (Bessel-K branch), r=1, "
+                                   "dense -2loglik" % (label, g, g, n),
+                       "parallelism": ("Sigma row blocks (column panels) sharded x%d, native RCCL broadcast%s"
+                                       % (world, " [rehearsal: gloo wire, one GPU]" if rehearsal else "")) if shard_mode
+                                      else ("replica x%d" % world if world > 1 else "single GPU"),
                        "target_8gpu_evals_per_s": 100},
-            "cholesky_tflops_fp64": None if chol_tf is None else round(chol_tf, 3),
-            "cholesky_frac_of_peak": None if chol_tf is None else round(chol_tf / (FP64_MFMA_PEAK_TFLOPS * world), 4),
+            "cholesky_tflops_fp64": round(chol_tf, 3),
+            "cholesky_frac": round(chol_tf / FP64_MFMA_PEAK_TFLOPS, 4),
+            "cholesky_note": "n^3/3 flop / cholesky_ms of ONE GPU (stages_ms); bordered factorisation incl. the solve",
             "stages_ms": stages,
             "neg2loglik": val,
             "throughput_inflight": inflight,
             "throughput_batch_api": batch,
             "replica_mode": replica,
-            "shard_error": shard_error,
             "parity_rel_err_vs_cpu": parity,
             "roofline": roofline,
+            "assembly": assembly,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
@@ -354,4 +362,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:                                       # noqa: BLE001
+        # a failing rank must fail the run (the launcher then stops the other ranks): no JSON line, non-zero exit
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

@@ -791,8 +791,12 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
     // several evaluations in flight already hide each other's panel chains; the resident engine is
     // for an evaluation that has the GPU to itself
     const bool engine_saved = f->engine_ok;
-    if (S > 1) f->engine_ok = false;
-    for (auto c : *f->slots) c->engine_ok = false;
+    static int batch_engine = -1;
+    if (batch_engine < 0) { const char *e = getenv("COCONS_BATCH_ENGINE"); batch_engine = e ? atoi(e) : 0; }
+    if (!batch_engine) {
+        if (S > 1) f->engine_ok = false;
+        for (auto c : *f->slots) c->engine_ok = false;
+    }
     if (S > (int)f->slots->size() + 1) S = (int)f->slots->size() + 1;
     for (int i = 0; i < nb; ++i) { values[i] = NAN; status[i] = -1; }   // never left unwritten
     std::vector<int> pending(S, -1);
