@@ -17,6 +17,8 @@ from .host import (  # noqa: F401
     cov_rns,
     cov_rns_classic,
     cov_rns_pred,
+    cov_rns_taper,
+    cov_rns_taper_pred,
     getBetas_profile,
     getHessian_dense,
     getModelLists,

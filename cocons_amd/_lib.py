@@ -45,6 +45,10 @@ SIGNATURES = {
     "cocons_cov_rns": (c_int, [c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "cocons_cov_rns_classic": (c_int, [c_int, c_int, c_dp, c_dp, c_dp, c_dp]),
     "cocons_cov_rns_pred": (c_int, [c_int, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "cocons_cov_rns_taper": (c_int, [c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_dp]),
+    "cocons_cov_rns_taper_pred": (c_int, [c_int, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_int,
+                                          ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_dp]),
+    "cocons_cov_rows": (c_int, [c_vp, c_dp, c_int, c_int, ctypes.POINTER(c_int), c_int, c_dp]),
     "cocons_sumsmoothlone": (ctypes.c_double, [c_dp, c_int, ctypes.c_double, ctypes.c_double]),
     "cocons_fit_create": (c_vp, [c_int, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_int]),
     "cocons_fit_destroy": (None, [c_vp]),

@@ -1058,6 +1058,141 @@ extern "C" int cocons_cov_rns_pred(int n, int m, int p, const double *theta, con
 }
 
 // ---------------------------------------------------------------------------
+// sparse/taper covariance entries (first slice): the assembly only -- the spam
+// Cholesky behind R/neg2loglikelihood.R:20-108 stays with the caller.
+static int taper_common(bool pred, int n, int m, int p, const double *theta, const double *locs,
+                        const double *locs_pred, const double *X, const double *X_pred, const double *smooth_limits,
+                        int nnz, const int *colindices, const int *rowpointers, double *out)
+{
+    if (n <= 0 || p <= 0 || p > COCONS_P_MAX || !theta || !locs || !X || !smooth_limits || nnz < 0 || !colindices ||
+        !rowpointers || (nnz > 0 && !out) || (pred && (m <= 0 || !locs_pred || !X_pred)))
+        return fail(-1, "cov_rns_taper*: bad argument");
+    const int nrows = pred ? m : n;
+    if (rowpointers[0] != 1 || rowpointers[nrows] != nnz + 1) return fail(-1, "cov_rns_taper*: rowpointers do not match nnz (1-based CSR expected)");
+    for (int w = 0; w < nnz; ++w)
+        if (colindices[w] < 1 || colindices[w] > n) return fail(-1, "cov_rns_taper*: column index out of range");
+    ThetaVecs tv;
+    make_theta_vecs(theta, p, tv);
+    for (int i = 0; i < p; ++i) tv.two_scale_je[i] = 2 * theta[TH_SCALE * p + i];   // FULL scale vector (cocons_taper.cpp:207)
+    // smoothness dispatch of cov_rns_taper (:183-201); the prediction variant always takes the Bessel branch
+    ModeSel ms = select_mode(theta, p, smooth_limits, pred ? 2 : 0);
+    hipStream_t s = nullptr;
+    double *dX = nullptr, *dl = nullptr, *dloc = nullptr, *dXp = nullptr, *dlp = nullptr, *dlocp = nullptr, *dout = nullptr;
+    int *dci = nullptr, *drp = nullptr;
+    int rc = 0;
+#define CKT(expr)                                                                 \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess) {                                                  \
+            rc = fail(-100 - (int)e__, "cov_rns_taper*: %s", hipGetErrorString(e__)); \
+            goto done;                                                            \
+        }                                                                         \
+    } while (0)
+    CKT(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    CKT(hipMalloc(&dX, (size_t)n * p * sizeof(double)));
+    CKT(hipMalloc(&dl, (size_t)n * 2 * sizeof(double)));
+    CKT(hipMalloc(&dloc, (size_t)LOCP_FIELDS * n * sizeof(double)));
+    CKT(hipMalloc(&dout, (size_t)(nnz > 0 ? nnz : 1) * sizeof(double)));
+    CKT(hipMalloc(&dci, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int)));
+    CKT(hipMalloc(&drp, (size_t)(nrows + 1) * sizeof(int)));
+    CKT(hipMemcpyAsync(dX, X, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice, s));
+    CKT(hipMemcpyAsync(dl, locs, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    CKT(hipMemcpyAsync(dci, colindices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, s));
+    CKT(hipMemcpyAsync(drp, rowpointers, (size_t)(nrows + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    {
+        LocArgs la;
+        la.n = n; la.p = p; la.X = dX; la.ldx = n; la.locs = dl; la.ldl = n;
+        la.out = dloc; la.stride = n; la.smooth_kind = ms.smooth_kind;
+        la.smooth_min = smooth_limits[0]; la.smooth_max = smooth_limits[1]; la.th = tv;
+        launch_loc_params(la, s);
+        if (pred) {
+            CKT(hipMalloc(&dXp, (size_t)m * p * sizeof(double)));
+            CKT(hipMalloc(&dlp, (size_t)m * 2 * sizeof(double)));
+            CKT(hipMalloc(&dlocp, (size_t)LOCP_FIELDS * m * sizeof(double)));
+            CKT(hipMemcpyAsync(dXp, X_pred, (size_t)m * p * sizeof(double), hipMemcpyHostToDevice, s));
+            CKT(hipMemcpyAsync(dlp, locs_pred, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+            LocArgs lp = la;
+            lp.n = m; lp.X = dXp; lp.ldx = m; lp.locs = dlp; lp.ldl = m; lp.out = dlocp; lp.stride = m;
+            launch_loc_params(lp, s);
+            launch_taper(MODE_GEOM, true, m, nnz, dci, drp, dlocp, m, dloc, n, 0.0, dout, s);
+        } else {
+            launch_taper(ms.mode, false, n, nnz, dci, drp, dloc, n, dloc, n, ms.nu_fixed, dout, s);
+        }
+    }
+    CKT(hipGetLastError());
+    if (nnz > 0) CKT(hipMemcpyAsync(out, dout, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+    CKT(hipStreamSynchronize(s));
+done:
+    if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); }
+    hipFree(dX); hipFree(dl); hipFree(dloc); hipFree(dXp); hipFree(dlp); hipFree(dlocp); hipFree(dout);
+    hipFree(dci); hipFree(drp);
+#undef CKT
+    return rc;
+}
+
+extern "C" int cocons_cov_rns_taper(int n, int p, const double *theta, const double *locs, const double *X,
+                                    const double *smooth_limits, int nnz, const int *colindices,
+                                    const int *rowpointers, double *entries)
+{
+    return taper_common(false, n, 0, p, theta, locs, nullptr, X, nullptr, smooth_limits, nnz, colindices, rowpointers, entries);
+}
+
+extern "C" int cocons_cov_rns_taper_pred(int n, int m, int p, const double *theta, const double *locs,
+                                         const double *locs_pred, const double *X, const double *X_pred,
+                                         const double *smooth_limits, int nnz, const int *colindices,
+                                         const int *rowpointers, double *entries)
+{
+    return taper_common(true, n, m, p, theta, locs, locs_pred, X, X_pred, smooth_limits, nnz, colindices, rowpointers, entries);
+}
+
+// ---------------------------------------------------------------------------
+// Rows of the dense covariance / correlation matrix of a fit, without the n x n matrix.
+// Works on the fit's ORIGINAL observation order (the reference's orientation rule "ii = the smaller index"
+// and its u <= eps rule depend on it), from the host copies the handle keeps: O(n p) bytes go down,
+// nidx * n doubles come back.
+extern "C" int cocons_cov_rows(cocons_fit *f, const double *theta, int classic, int nidx, const int *idx, int cor,
+                               double *out)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!theta || nidx <= 0 || !idx || !out) return fail(-1, "cocons_cov_rows: bad argument");
+    const int n = f->n, p = f->p;
+    for (int b = 0; b < nidx; ++b)
+        if (idx[b] < 0 || idx[b] >= n) return fail(-1, "cocons_cov_rows: row index out of range (0-based)");
+    ThetaVecs tv;
+    make_theta_vecs(theta, p, tv);
+    ModeSel ms = select_mode(theta, p, f->smooth_limits, classic ? 1 : 0);
+    hipStream_t s = f->stream;
+    double *dX = nullptr, *dl = nullptr, *dloc = nullptr, *dout = nullptr;
+    int *didx = nullptr;
+    int rc = 0;
+    do {
+        hipError_t e;
+#define CKR(expr) if ((e = (expr)) != hipSuccess) { rc = fail(-100 - (int)e, "cocons_cov_rows: %s", hipGetErrorString(e)); break; }
+        CKR(hipMalloc(&dX, (size_t)n * p * sizeof(double)));
+        CKR(hipMalloc(&dl, (size_t)n * 2 * sizeof(double)));
+        CKR(hipMalloc(&dloc, (size_t)LOCP_FIELDS * n * sizeof(double)));
+        CKR(hipMalloc(&dout, (size_t)nidx * n * sizeof(double)));
+        CKR(hipMalloc(&didx, (size_t)nidx * sizeof(int)));
+        CKR(hipMemcpyAsync(dX, f->h_X->data(), (size_t)n * p * sizeof(double), hipMemcpyHostToDevice, s));
+        CKR(hipMemcpyAsync(dl, f->h_locs->data(), (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+        CKR(hipMemcpyAsync(didx, idx, (size_t)nidx * sizeof(int), hipMemcpyHostToDevice, s));
+        LocArgs la;
+        la.n = n; la.p = p; la.X = dX; la.ldx = n; la.locs = dl; la.ldl = n;
+        la.out = dloc; la.stride = n; la.smooth_kind = ms.smooth_kind;
+        la.smooth_min = f->smooth_limits[0]; la.smooth_max = f->smooth_limits[1]; la.th = tv;
+        launch_loc_params(la, s);
+        launch_cov_rows(ms.mode, n, nidx, didx, dloc, n, ms.gr, ms.nu_fixed, cor, dout, s);
+        CKR(hipGetLastError());
+        CKR(hipMemcpyAsync(out, dout, (size_t)nidx * n * sizeof(double), hipMemcpyDeviceToHost, s));
+        CKR(hipStreamSynchronize(s));
+#undef CKR
+    } while (0);
+    hipStreamSynchronize(s);
+    hipFree(dX); hipFree(dl); hipFree(dloc); hipFree(dout); hipFree(didx);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
 // kriging core: rows under the matrix = [ (z - X mean)' ; cov_rns_pred (m x n) ]
 extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const double *mean, int z_col,
                                     int m, const double *locs_pred, const double *X_pred,

@@ -69,6 +69,7 @@ loc_params_kernel(LocArgs a)
     o[w + 9 * s] = sigma;
     o[w + 10 * s] = snu;
     o[w + 11 * s] = (1 / exp(-1 * t_sd)) + ng;          // :111
+    o[w + 12 * s] = ng;
 }
 
 constexpr int TS = 64;   // pair tile edge
@@ -202,6 +203,101 @@ rhs_rows_kernel(RhsArgs a)
     }
     for (int k = a.nrows; k < a.nrows + a.nrows_zero; ++k)
         a.out[(size_t)(a.row0 + k) + (size_t)c * a.ld] = 0.0;
+}
+
+// Sparse/taper covariance entries (src/cocons_taper.cpp): one thread per stored entry of the CSR pattern
+// (colindices / rowpointers 1-based as spam stores them, read-only here -- the reference shifts them
+// in place, :73-74, :211-212).  The row of entry w is found by bisection in rowpointers.
+struct TaperArgs {
+    int nrows, nnz;
+    const int *ci, *rp;
+    const double *rows; size_t stride_rows;   // SoA of the row side (prediction locations for PRED)
+    const double *cols; size_t stride;        // SoA of the column side (observations)
+    double nu_fixed;
+    double *out;
+};
+
+template <int MODE, bool PRED>
+__global__ void __launch_bounds__(256, PAIR_MIN_WAVES)
+taper_kernel(TaperArgs a)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.nnz) return;
+    int lo = 0, hi = a.nrows - 1;             // largest ii with rp[ii] - 1 <= w
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.rp[mid] - 1 <= w) lo = mid; else hi = mid - 1;
+    }
+    const int ii = lo, jj = a.ci[w] - 1;
+    double v;
+    if (!PRED && ii == jj) v = a.rows[ii + 11 * a.stride_rows];
+    else v = taper_value_idx<MODE, PRED>(a.rows, a.stride_rows, ii, a.cols, a.stride, jj, a.nu_fixed);
+    a.out[w] = v;
+}
+
+void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const int *rp, const double *rows,
+                  size_t stride_rows, const double *cols, size_t stride, double nu_fixed, double *out, hipStream_t s)
+{
+    if (nnz <= 0) return;
+    TaperArgs a;
+    a.nrows = nrows; a.nnz = nnz; a.ci = ci; a.rp = rp; a.rows = rows; a.stride_rows = stride_rows;
+    a.cols = cols; a.stride = stride; a.nu_fixed = nu_fixed; a.out = out;
+    dim3 g((nnz + 255) / 256), b(256);
+    if (pred) { hipLaunchKernelGGL((taper_kernel<MODE_GEOM, true>), g, b, 0, s, a); return; }
+    switch (mode) {
+    case MODE_HALF: hipLaunchKernelGGL((taper_kernel<MODE_HALF, false>), g, b, 0, s, a); break;
+    case MODE_THREEHALF: hipLaunchKernelGGL((taper_kernel<MODE_THREEHALF, false>), g, b, 0, s, a); break;
+    case MODE_FIVEHALF: hipLaunchKernelGGL((taper_kernel<MODE_FIVEHALF, false>), g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL((taper_kernel<MODE_GEOM, false>), g, b, 0, s, a); break;
+    }
+}
+
+// Selected rows of the dense covariance (or of cov2cor of it) without ever forming the n x n matrix: what
+// plot(type = "correlations") uses of cov_rns (R/methods.R:161-165: tmp_cov[ww, ]).  Entry (i, j) with the
+// reference's orientation (ii = the smaller index, src/cocons_full.cpp:119-120); cov2cor as stats::cov2cor:
+// (Is[i] * V[i,j]) * Is[j] with Is = 1 / sqrt(diag), diagonal set to exactly 1.
+struct RowsArgs {
+    int n, nidx;
+    const int *idx;
+    const double *loc; size_t stride;
+    double gr, nu_fixed;
+    int cor;
+    double *out;            // nidx rows of n, row b at out + b * n
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256, PAIR_MIN_WAVES)
+cov_rows_kernel(RowsArgs a)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.n) return;
+    const int i = a.idx[blockIdx.y];
+    double v;
+    if (i == j) v = a.loc[i + 11 * a.stride];
+    else if (i < j) v = pair_value_idx<MODE>(a.loc, a.stride, i, a.loc, a.stride, j, a.gr, a.nu_fixed, false);
+    else v = pair_value_idx<MODE>(a.loc, a.stride, j, a.loc, a.stride, i, a.gr, a.nu_fixed, false);
+    if (a.cor) {
+        const double isi = 1 / sqrt(a.loc[i + 11 * a.stride]), isj = 1 / sqrt(a.loc[j + 11 * a.stride]);
+        v = (i == j) ? 1.0 : (isi * v) * isj;
+    }
+    a.out[(size_t)blockIdx.y * a.n + j] = v;
+}
+
+void launch_cov_rows(int mode, int n, int nidx, const int *idx, const double *loc, size_t stride, double gr,
+                     double nu_fixed, int cor, double *out, hipStream_t s)
+{
+    if (n <= 0 || nidx <= 0) return;
+    RowsArgs a;
+    a.n = n; a.nidx = nidx; a.idx = idx; a.loc = loc; a.stride = stride; a.gr = gr; a.nu_fixed = nu_fixed;
+    a.cor = cor; a.out = out;
+    dim3 g((n + 255) / 256, nidx), b(256);
+    switch (mode) {
+    case MODE_HALF: hipLaunchKernelGGL((cov_rows_kernel<MODE_HALF>), g, b, 0, s, a); break;
+    case MODE_THREEHALF: hipLaunchKernelGGL((cov_rows_kernel<MODE_THREEHALF>), g, b, 0, s, a); break;
+    case MODE_FIVEHALF: hipLaunchKernelGGL((cov_rows_kernel<MODE_FIVEHALF>), g, b, 0, s, a); break;
+    case MODE_MEAN: hipLaunchKernelGGL((cov_rows_kernel<MODE_MEAN>), g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL((cov_rows_kernel<MODE_GEOM>), g, b, 0, s, a); break;
+    }
 }
 
 // Diagnostic: the device Matern/Bessel routine evaluated pointwise, so that it can be pinned

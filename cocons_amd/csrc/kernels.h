@@ -68,6 +68,12 @@ void launch_loc_params(const LocArgs &a, hipStream_t s);
 void launch_pair_sym(int mode, bool mirror, const PairArgs &a, hipStream_t s);
 void launch_pair_rect(int mode, const PairArgs &a, hipStream_t s);
 void launch_rhs_rows(const RhsArgs &a, hipStream_t s);
+// entries of the sparse/taper covariance for a CSR pattern (1-based indices, device arrays)
+void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const int *rp, const double *rows,
+                  size_t stride_rows, const double *cols, size_t stride, double nu_fixed, double *out, hipStream_t s);
+// rows idx[0..nidx) of the dense covariance (cor != 0: of cov2cor of it); out row b at out + b * n
+void launch_cov_rows(int mode, int n, int nidx, const int *idx, const double *loc, size_t stride, double gr,
+                     double nu_fixed, int cor, double *out, hipStream_t s);
 // out[i] = 2^(1-nu)/Gamma(nu) u^nu K_nu(u) by the device routine of the pair kernels (diagnostic)
 void launch_matern_points(int n, const double *nu, const double *x, double *out, hipStream_t s);
 

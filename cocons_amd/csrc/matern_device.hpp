@@ -39,7 +39,8 @@ enum PairMode : int {
 //   9 sigma             Pexp(0.5*std.dev)
 //  10 snu               sqrt(nu_w) (GEOM) or nu_w (MEAN)
 //  11 diag              Pexp(std.dev) + nugget
-constexpr int LOCP_FIELDS = 12;
+//  12 ng                Pexp(nugget)   (taper prediction variant: sigma^2 + ng, src/cocons_taper.cpp:88)
+constexpr int LOCP_FIELDS = 13;
 
 // src/cocons_types.h:49-54
 __device__ __forceinline__ double kahan(double a, double b, double c, double d)
@@ -205,6 +206,36 @@ __device__ __forceinline__ double pair_value_idx(const double *base_a, size_t sa
     pb = base_b + ib;
     double amp = sqrt(pa[8 * sa] * pb[7 * sb] * pb[6 * sb]);
     return m * pa[9 * sa] * pb[9 * sb] * amp / sqrt(det);
+}
+
+// One entry of the sparse/taper covariance (src/cocons_taper.cpp:229-262 and its copies, :86-129):
+// isotropic, local range r = Pexp(2 scale) (field 2 -- the caller passes the FULL scale vector here),
+// sigma = Pexp(0.5 std.dev) (field 9), sqrt(nu) (field 10).  ia = row ("ii") location, ib = column.
+// PRED: exact coordinate match or u <= eps -> sigma_ii * sigma_ii + Pexp(nugget)_ii (:88, :106),
+// otherwise (cov_rns_taper) u <= eps -> the diagonal value of ii (:248); ii == jj is the caller's case.
+template <int MODE, bool PRED>
+__device__ __forceinline__ double taper_value_idx(const double *base_a, size_t sa, int ia,
+                                                  const double *base_b, size_t sb, int ib, double nu_fixed)
+{
+    const double epsilon = 2.220446049250313e-16;
+    const double *pa = base_a + ia, *pb = base_b + ib;
+    const double ax = pa[0], ay = pa[sa], bx = pb[0], by = pb[sb];
+    const double si = pa[9 * sa];
+    const double own = PRED ? si * si + pa[12 * sa] : pa[11 * sa];
+    if (PRED && ax == bx && ay == by) return own;
+    const double ri = pa[2 * sa], rj = pb[2 * sb];
+    const double smtns = (MODE == MODE_GEOM) ? pa[10 * sa] * pb[10 * sb] : nu_fixed;
+    const double prefactor = (2 * sqrt(ri) * sqrt(rj)) / (ri + rj);
+    const double global_range = (ri + rj) / 2;
+    const double dx = ax - bx, dy = ay - by;
+    const double u = sqrt(8 * smtns) * sqrt(dx * dx + dy * dy) / sqrt(global_range);
+    if (u <= epsilon) return own;
+    double m;
+    if (MODE == MODE_HALF) m = exp(-u);
+    else if (MODE == MODE_THREEHALF) m = (1 + u) * exp(-u);
+    else if (MODE == MODE_FIVEHALF) m = (1 + u + u * u / 3) * exp(-u);
+    else m = (u < 706.0) ? matern_bessel(smtns, u) : matern_asymptotic(smtns, u);
+    return prefactor * m * si * pb[9 * sb];
 }
 
 }  // namespace cocons

@@ -89,6 +89,44 @@ def cov_rns_pred(theta, locs, locs_pred, x_covariates, x_covariates_pred, smooth
     return out
 
 
+def _ip(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+
+
+def cov_rns_taper(theta, locs, x_covariates, colindices, rowpointers, smooth_limits) -> np.ndarray:
+    """Sparse covariance function: the entries of the spam pattern (colindices / rowpointers 1-based, as
+    spam stores them); R/RcppExports.R:63-65 -> src/cocons_taper.cpp:151-433."""
+    L = _lib.load()
+    locs, X = _f(locs), _f(x_covariates)
+    n, p = X.shape
+    T = theta_table(theta)
+    sl = np.asarray(smooth_limits, dtype=np.float64)
+    ci = np.ascontiguousarray(colindices, dtype=np.int32)
+    rp = np.ascontiguousarray(rowpointers, dtype=np.int32)
+    out = np.empty(ci.size)
+    _lib.check(L.cocons_cov_rns_taper(n, p, _p(T), _p(locs), _p(X), _p(sl), ci.size, _ip(ci), _ip(rp), _p(out)),
+               "cov_rns_taper")
+    return out
+
+
+def cov_rns_taper_pred(theta, locs, locs_pred, x_covariates, x_covariates_pred, colindices, rowpointers,
+                       smooth_limits) -> np.ndarray:
+    """Sparse cross-covariance entries (rows = prediction locations); R/RcppExports.R:52-54 ->
+    src/cocons_taper.cpp:17-139."""
+    L = _lib.load()
+    locs, lp, X, Xp = _f(locs), _f(locs_pred), _f(x_covariates), _f(x_covariates_pred)
+    n, p = X.shape
+    m = Xp.shape[0]
+    T = theta_table(theta)
+    sl = np.asarray(smooth_limits, dtype=np.float64)
+    ci = np.ascontiguousarray(colindices, dtype=np.int32)
+    rp = np.ascontiguousarray(rowpointers, dtype=np.int32)
+    out = np.empty(ci.size)
+    _lib.check(L.cocons_cov_rns_taper_pred(n, m, p, _p(T), _p(locs), _p(lp), _p(X), _p(Xp), _p(sl), ci.size,
+                                           _ip(ci), _ip(rp), _p(out)), "cov_rns_taper_pred")
+    return out
+
+
 def sumsmoothlone(x, lam: float, alpha: float = 1e6) -> float:
     """Smoothed-L1 penalty; R/RcppExports.R:10-12 (host arithmetic, O(p))."""
     L = _lib.load()
@@ -251,6 +289,16 @@ class CoconsFit:
         _lib.check(self._L.cocons_predict_dense(self._h, _p(T), _p(mean), int(z_col), m, _p(lp), _p(Xp),
                                                 _p(st), _p(qf)), "cocons_predict_dense")
         return st, qf
+
+    def cov_rows(self, theta_list, index, cor=False, classic=False):
+        """Rows `index` (0-based) of cov_rns / cov_rns_classic at the fit's locations, or of cov2cor of it,
+        without the n x n matrix (what plot(type = "correlations") reads, R/methods.R:161-165)."""
+        T = theta_table(theta_list)
+        idx = np.ascontiguousarray(np.atleast_1d(index), dtype=np.int32)
+        out = np.empty((idx.size, self.n))
+        _lib.check(self._L.cocons_cov_rows(self._h, _p(T), int(bool(classic)), idx.size, _ip(idx), int(bool(cor)), _p(out)),
+                   "cocons_cov_rows")
+        return out
 
     def sim_core(self, theta_list, iiderrors, classic=False):
         E = _f(np.asarray(iiderrors, dtype=np.float64).reshape(self.n, -1))

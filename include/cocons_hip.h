@@ -56,6 +56,25 @@ int cocons_cov_rns_pred(int n, int m, int p, const double *theta, const double *
  *   src/RcppExports.cpp:16-26 -> sumsmoothlone, src/cocons_full.cpp:12-30 (host, O(p)) */
 double cocons_sumsmoothlone(const double *x, int len, double lambda, double alpha);
 
+/* ---- sparse/taper covariance entries (first slice) ---------------
+ * replaces .Call("_cocons_cov_rns_taper", theta, locs, x_covariates, colindices, rowpointers, smooth_limits)
+ *   src/RcppExports.cpp:88-101 -> cov_rns_taper, src/cocons_taper.cpp:151-433
+ * and .Call("_cocons_cov_rns_taper_pred", theta, locs, locs_pred, x_covariates, x_covariates_pred,
+ *           colindices, rowpointers, smooth_limits)
+ *   src/RcppExports.cpp:72-87 -> cov_rns_taper_pred, src/cocons_taper.cpp:17-139.
+ * colindices (nnz) / rowpointers (rows + 1) are the spam CSR pattern, 1-BASED as spam stores them, and are
+ * only read: the reference shifts its (coerced copies of the) index vectors by -1 in place (:73-74, :211-212),
+ * which a caller never sees because spam's integer slots are copied on coercion to NumericVector.
+ * entries[w] receives the covariance of stored entry w (row-wise order).  The tapering itself and the
+ * sparse Cholesky (R/neg2loglikelihood.R:20-108) stay with the caller.                              */
+int cocons_cov_rns_taper(int n, int p, const double *theta, const double *locs, const double *X,
+                         const double *smooth_limits, int nnz, const int *colindices, const int *rowpointers,
+                         double *entries);
+int cocons_cov_rns_taper_pred(int n, int m, int p, const double *theta, const double *locs,
+                              const double *locs_pred, const double *X, const double *X_pred,
+                              const double *smooth_limits, int nnz, const int *colindices,
+                              const int *rowpointers, double *entries);
+
 /* ---- fit handle: everything that is constant over an optimisation -------------
  * Created once per cocoOptim / getHessian call from the arguments the reference
  * passes unchanged to every GetNeg2loglikelihood* evaluation
@@ -113,6 +132,15 @@ int cocons_neg2loglik_reml(cocons_fit *fit, const double *theta, int rank,
 int cocons_predict_dense(cocons_fit *fit, const double *theta, const double *mean,
                          int z_col, int m, const double *locs_pred, const double *X_pred,
                          double *stochastic, double *quadform);
+
+/* Rows of the covariance (cor = 0) or correlation (cor != 0, stats::cov2cor) matrix of the fit's
+ * locations without forming the n x n matrix: what getCovMatrix's consumers read of it --
+ * plot(type = "correlations") uses tmp_cov[ww, ] only (R/methods.R:161-165, :210-214; cov_rns at
+ * R/getFunctions.R:44-52).  idx: nidx 0-based row indices in the caller's (original) observation order;
+ * classic != 0 selects cov_rns_classic; out: nidx rows of n doubles (row b at out + b * n).
+ * O(n p) bytes go down and nidx * n doubles come back instead of the 8 n^2-byte matrix.               */
+int cocons_cov_rows(cocons_fit *fit, const double *theta, int classic, int nidx, const int *idx, int cor,
+                    double *out);
 
 /* Marginal simulation core: replaces R/sim.R:147-172
  *   covmat <- cov_rns(...) | cov_rns_classic(...); cholS <- chol(covmat);

@@ -407,6 +407,144 @@ int oracle_cov_rns_pred(int n, int m, int p, const double *theta, const double *
     return 0;
 }
 
+/* ---- src/cocons_taper.cpp:151-433  cov_rns_taper -------------------------
+ * CSR-indexed isotropic nonstationary Matern (the sparse/taper path's covariance entries).  colindices
+ * and rowpointers are 1-based as spam stores them (the reference shifts them by -1 in place, :211-212);
+ * entry w of row ii (0-based) pairs ii with jj = colindices[w] - 1.  Per entry, operation for operation:
+ *   ii == jj          -> Pexp(std.dev, x_ii) + Pexp(nugget, x_ii)                             (:229-231)
+ *   prefactor = (2 * pow(r_ii, 0.5) * pow(r_jj, 0.5)) / (r_ii + r_jj), r = Pexp(2 * scale)   (:236, :207)
+ *   global_range = (r_ii + r_jj) / 2                                                          (:238)
+ *   u = sqrt(8 nu) * sqrt(pow(dx, 2) + pow(dy, 2)) / sqrt(global_range)                       (:242-243)
+ *   u <= eps          -> the diagonal value of ii                                             (:246-249)
+ *   value = prefactor * M_nu(u) * sigma_ii * sigma_jj, sigma = Pexp(0.5 * std.dev)            (:253, ...)
+ * with the same fixed-smoothness dispatch and quirk as cov_rns (a fixed nu outside {0.5, 1.5, 2.5} leaves
+ * smooth_vector at zero, :173, :189-201 -> u = 0 -> every off-diagonal entry = diagonal value of ii).   */
+int oracle_cov_rns_taper(int n, int p, const double *theta, const double *locs, const double *X,
+                         const double *smooth_limits, int nnz, const int *colindices,
+                         const int *rowpointers, double *out)
+{
+    const double epsilon = DBL_EPSILON;
+    double *range_v = (double *)calloc((size_t)n * 3, sizeof(double));
+    if (!range_v) return -1;
+    double *sigma_v = range_v + n, *smooth_v = range_v + 2 * (size_t)n;
+    double two_scale[64], half_sd[64];
+    if (p > 64) { free(range_v); return -1; }
+    for (int i = 0; i < p; ++i) {
+        two_scale[i] = 2 * theta[TH_SCALE * p + i];
+        half_sd[i] = 0.5 * theta[TH_SD * p + i];
+    }
+    const double *smooth = theta + TH_SMOOTH * p, *sd = theta + TH_SD * p, *ng = theta + TH_NUGGET * p;
+    int smooth_switch = 0;
+    double smooth_value = 0.0;
+    if (all_zero_from_second(smooth, p) && smooth_limits[0] == smooth_limits[1]) {
+        smooth_value = smooth_limits[0];
+        smooth_switch = map_smooth_value(smooth_value);
+    } else {
+        for (int w = 0; w < n; ++w)
+            smooth_v[w] = sqrt(pexpfma_smooth(smooth, X, n, p, w, smooth_limits[0], smooth_limits[1]));
+    }
+    for (int w = 0; w < n; ++w) {
+        range_v[w] = pexpfma(two_scale, X, n, p, w);
+        sigma_v[w] = pexpfma(half_sd, X, n, p, w);
+    }
+    int acc = 0;
+    for (int ii = 0; ii < n; ++ii) {
+        for (int w = rowpointers[ii] - 1; w < rowpointers[ii + 1] - 1; ++w) {
+            const int jj = colindices[w] - 1;
+            if (acc >= nnz) { free(range_v); return -2; }
+            if (ii == jj) {
+                out[acc++] = pexpfma(sd, X, n, p, ii) + pexpfma(ng, X, n, p, ii);
+                continue;
+            }
+            const double smtns = (smooth_switch == 0) ? smooth_v[ii] * smooth_v[jj] : smooth_value;
+            const double prefactor = (2 * pow(range_v[ii], 0.5) * pow(range_v[jj], 0.5)) / (range_v[ii] + range_v[jj]);
+            const double global_range = (range_v[ii] + range_v[jj]) / 2;
+            const double d0 = locs[ii] - locs[jj], d1 = locs[ii + (size_t)n] - locs[jj + (size_t)n];
+            const double u = sqrt(8 * smtns) * sqrt(pow(d0, 2) + pow(d1, 2)) / sqrt(global_range);
+            if (u <= epsilon) {
+                out[acc++] = pexpfma(sd, X, n, p, ii) + pexpfma(ng, X, n, p, ii);
+                continue;
+            }
+            double v;
+            switch (smooth_switch) {
+            case 1: v = prefactor * exp(-u) * sigma_v[ii] * sigma_v[jj]; break;
+            case 2: v = prefactor * (1 + u) * exp(-u) * sigma_v[ii] * sigma_v[jj]; break;
+            case 3: v = prefactor * (1 + u + u * u / 3) * exp(-u) * sigma_v[ii] * sigma_v[jj]; break;
+            default:
+                if (u < 706.0)
+                    v = prefactor * pow(2.0, -(smtns - 1)) / tgamma(smtns) * pow(u, smtns) * oracle_besselk(smtns, u) *
+                        sigma_v[ii] * sigma_v[jj];
+                else
+                    v = prefactor * pow(2.0, -(smtns - 1)) / tgamma(smtns) * pow(u, smtns) * sqrt(M_PI / (2.0 * u)) *
+                        exp(-u) * sigma_v[ii] * sigma_v[jj];
+            }
+            out[acc++] = v;
+        }
+    }
+    free(range_v);
+    return acc == nnz ? 0 : -3;
+}
+
+/* ---- src/cocons_taper.cpp:17-139  cov_rns_taper_pred ----------------------
+ * rows = prediction locations (rowpointers has m + 1 entries), columns = observation locations.  Always
+ * the Bessel branch; coincident coordinates or u <= eps -> sigma_pred_ii * sigma_pred_ii +
+ * Pexp(nugget, x_pred_ii) (:86-88, :104-107).                                                        */
+int oracle_cov_rns_taper_pred(int n, int m, int p, const double *theta, const double *locs,
+                              const double *locs_pred, const double *X, const double *X_pred,
+                              const double *smooth_limits, int nnz, const int *colindices,
+                              const int *rowpointers, double *out)
+{
+    const double epsilon = DBL_EPSILON;
+    double *buf = (double *)calloc((size_t)(n + m) * 3, sizeof(double));
+    if (!buf || p > 64) { free(buf); return -1; }
+    double *scale_v = buf, *sigma_v = buf + n, *smooth_v = buf + 2 * (size_t)n;
+    double *scale_p = buf + 3 * (size_t)n, *sigma_p = scale_p + m, *smooth_p = scale_p + 2 * (size_t)m;
+    double two_scale[64], half_sd[64];
+    for (int i = 0; i < p; ++i) {
+        two_scale[i] = 2 * theta[TH_SCALE * p + i];
+        half_sd[i] = 0.5 * theta[TH_SD * p + i];
+    }
+    const double *smooth = theta + TH_SMOOTH * p, *ng = theta + TH_NUGGET * p;
+    for (int w = 0; w < n; ++w) {
+        scale_v[w] = pexpfma(two_scale, X, n, p, w);
+        sigma_v[w] = pexpfma(half_sd, X, n, p, w);
+        smooth_v[w] = sqrt(pexpfma_smooth(smooth, X, n, p, w, smooth_limits[0], smooth_limits[1]));
+    }
+    for (int w = 0; w < m; ++w) {
+        scale_p[w] = pexpfma(two_scale, X_pred, m, p, w);
+        sigma_p[w] = pexpfma(half_sd, X_pred, m, p, w);
+        smooth_p[w] = sqrt(pexpfma_smooth(smooth, X_pred, m, p, w, smooth_limits[0], smooth_limits[1]));
+    }
+    int acc = 0;
+    for (int ii = 0; ii < m; ++ii) {
+        for (int w = rowpointers[ii] - 1; w < rowpointers[ii + 1] - 1; ++w) {
+            const int jj = colindices[w] - 1;
+            if (acc >= nnz) { free(buf); return -2; }
+            if (locs_pred[ii] == locs[jj] && locs_pred[ii + (size_t)m] == locs[jj + (size_t)n]) {
+                out[acc++] = sigma_p[ii] * sigma_p[ii] + pexpfma(ng, X_pred, m, p, ii);
+                continue;
+            }
+            const double smtns = smooth_p[ii] * smooth_v[jj];
+            const double prefactor = (2 * pow(scale_p[ii], 0.5) * pow(scale_v[jj], 0.5)) / (scale_p[ii] + scale_v[jj]);
+            const double global_range = (scale_p[ii] + scale_v[jj]) / 2;
+            const double d0 = locs_pred[ii] - locs[jj], d1 = locs_pred[ii + (size_t)m] - locs[jj + (size_t)n];
+            const double u = sqrt(8 * smtns) * sqrt(pow(d0, 2) + pow(d1, 2)) / sqrt(global_range);
+            if (u <= epsilon) {
+                out[acc++] = sigma_p[ii] * sigma_p[ii] + pexpfma(ng, X_pred, m, p, ii);
+                continue;
+            }
+            if (u < 706.0)
+                out[acc++] = prefactor * pow(2.0, -(smtns - 1)) / tgamma(smtns) * pow(u, smtns) * oracle_besselk(smtns, u) *
+                             sigma_p[ii] * sigma_v[jj];
+            else
+                out[acc++] = prefactor * pow(2.0, -(smtns - 1)) / tgamma(smtns) * pow(u, smtns) * sqrt(M_PI / (2.0 * u)) *
+                             exp(-u) * sigma_p[ii] * sigma_v[jj];
+        }
+    }
+    free(buf);
+    return acc == nnz ? 0 : -3;
+}
+
 /* ---- sumsmoothlone: src/cocons_full.cpp:12-30 ------------------------------- */
 double oracle_sumsmoothlone(const double *x, int len, double lambda, double alpha)
 {

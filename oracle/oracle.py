@@ -51,6 +51,9 @@ def lib():
         L.oracle_sumsmoothlone.restype = ctypes.c_double
         L.oracle_sumsmoothlone.argtypes = [dp, ci, ctypes.c_double, ctypes.c_double]
         L.oracle_chol_ld.argtypes = [ci, dp, ci, dp, dp, dp, dp]
+        ip = ctypes.POINTER(ctypes.c_int)
+        L.oracle_cov_rns_taper.argtypes = [ci, ci, dp, dp, dp, dp, ci, ip, ip, dp]
+        L.oracle_cov_rns_taper_pred.argtypes = [ci, ci, ci, dp, dp, dp, dp, dp, dp, ci, ip, ip, dp]
         _LIB = L
     return _LIB
 
@@ -109,6 +112,42 @@ def cov_rns_pred(theta, locs, locs_pred, x_covariates, x_covariates_pred, smooth
     out = np.empty((m, n), order="F")
     rc = lib().oracle_cov_rns_pred(n, m, p, _p(T), _p(locs), _p(lp), _p(X), _p(Xp), _p(sl), _p(out))
     assert rc == 0
+    return out
+
+
+def _ip(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+
+
+def cov_rns_taper(theta, locs, x_covariates, colindices, rowpointers, smooth_limits) -> np.ndarray:
+    """src/cocons_taper.cpp:151-433 -- the entries of the CSR pattern (colindices / rowpointers 1-based,
+    as spam stores them; not modified)."""
+    locs, X = _f(locs), _f(x_covariates)
+    n, p = X.shape
+    T = theta_table(theta)
+    sl = np.asarray(smooth_limits, dtype=np.float64)
+    ci = np.ascontiguousarray(colindices, dtype=np.int32)
+    rp = np.ascontiguousarray(rowpointers, dtype=np.int32)
+    out = np.empty(ci.size)
+    rc = lib().oracle_cov_rns_taper(n, p, _p(T), _p(locs), _p(X), _p(sl), ci.size, _ip(ci), _ip(rp), _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def cov_rns_taper_pred(theta, locs, locs_pred, x_covariates, x_covariates_pred, colindices, rowpointers,
+                       smooth_limits) -> np.ndarray:
+    """src/cocons_taper.cpp:17-139 -- rows = prediction locations."""
+    locs, lp, X, Xp = _f(locs), _f(locs_pred), _f(x_covariates), _f(x_covariates_pred)
+    n, p = X.shape
+    m = Xp.shape[0]
+    T = theta_table(theta)
+    sl = np.asarray(smooth_limits, dtype=np.float64)
+    ci = np.ascontiguousarray(colindices, dtype=np.int32)
+    rp = np.ascontiguousarray(rowpointers, dtype=np.int32)
+    out = np.empty(ci.size)
+    rc = lib().oracle_cov_rns_taper_pred(n, m, p, _p(T), _p(locs), _p(lp), _p(X), _p(Xp), _p(sl), ci.size,
+                                         _ip(ci), _ip(rp), _p(out))
+    assert rc == 0, rc
     return out
 
 

@@ -486,3 +486,83 @@ def test_device_matern_against_mpmath_grid(golden_dir):
     rel = np.abs(out[ok] - want[ok]) / want[ok]
     assert rel.max() < 1e-13, (rel.max(), nu[ok][rel.argmax()], x[ok][rel.argmax()])
     assert np.all(np.abs(out[~ok] - want[~ok]) < 1e-290)
+
+
+def _csr_within(rows, cols, delta):
+    ci, rp = [], [1]
+    for a in rows:
+        d = np.hypot(cols[:, 0] - a[0], cols[:, 1] - a[1])
+        ci.extend((np.nonzero(d <= delta)[0] + 1).tolist())
+        rp.append(len(ci) + 1)
+    return np.array(ci, dtype=np.int32), np.array(rp, dtype=np.int32)
+
+
+def test_taper_entries_vs_oracle_and_golden(oracle, golden_dir):
+    """cov_rns_taper / cov_rns_taper_pred (assembly slice): mpmath golden entries at
+    n = 24 and the CPU restatement entry by entry on a 3000-point pattern (~90 neighbours per row),
+    every smoothness branch, the fixed-nu quirk, an empty row and a coincident prediction location."""
+    import cocons_amd as ca
+    g = json.load(open(os.path.join(golden_dir, "taper_n24.json")))
+    th = {k: np.array(v) for k, v in g["theta"].items()}
+    locs, X = np.array(g["locs"]), np.array(g["X"])
+    a = ca.cov_rns_taper(th, locs, X, g["colindices"], g["rowpointers"], g["smooth_limits"])
+    assert _relerr(a, g["entries_general"]) < 1e-13
+    c = ca.cov_rns_taper_pred(th, locs, np.array(g["locs_pred"]), X, np.array(g["X_pred"]),
+                              g["colindices_pred"], g["rowpointers_pred"], g["smooth_limits"])
+    assert _relerr(c, g["entries_pred"]) < 1e-13
+    n = 3000
+    locs, X, th, rng = _problem(n, seed=31)
+    ci, rp = _csr_within(locs, locs, 0.1)
+    assert ci.size > 50 * n
+    got = ca.cov_rns_taper(th, locs, X, ci, rp, wl_limits())
+    want = oracle.cov_rns_taper(th, locs, X, ci, rp, wl_limits())
+    assert _relerr(got, want) < ENTRY_RTOL
+    for nu in (0.5, 1.5, 2.5, 1.0):                      # closed forms and the degenerate fixed-nu quirk
+        t2 = {k: np.array(v, dtype=float) for k, v in th.items()}
+        t2["smooth"] = np.zeros(3)
+        got = ca.cov_rns_taper(t2, locs, X, ci, rp, (nu, nu))
+        want = oracle.cov_rns_taper(t2, locs, X, ci, rp, (nu, nu))
+        assert _relerr(got, want) < ENTRY_RTOL
+    m = 500
+    lp = rng.uniform(0, 1, size=(m, 2))
+    lp[10] = locs[77]
+    lp[11] = np.array([5.0, 5.0])                        # no neighbour: an empty row
+    Xp = np.column_stack([np.ones(m), rng.standard_normal(m), rng.standard_normal(m)])
+    cip, rpp = _csr_within(lp, locs, 0.1)
+    assert rpp[12] == rpp[11]
+    got = ca.cov_rns_taper_pred(th, locs, lp, X, Xp, cip, rpp, wl_limits())
+    want = oracle.cov_rns_taper_pred(th, locs, lp, X, Xp, cip, rpp, wl_limits())
+    assert _relerr(got, want) < ENTRY_RTOL
+
+
+def wl_limits():
+    from cocons_amd import workloads as wl
+    return wl.SMOOTH_LIMITS
+
+
+def test_cov_rows_and_cor_rows(oracle):
+    """Rows of Sigma / cov2cor(Sigma) straight from the fit (cocons_cov_rows), the consumers of
+    getCovMatrix (R/getFunctions.R:44-52, R/methods.R:161-165), against the full CPU matrix: both
+    orientations around the requested index, the duplicate-location rule, classic and fixed-nu modes,
+    on scattered (internally Morton-sorted) data."""
+    import cocons_amd as ca
+    n = 700
+    locs, X, th, rng = _problem(n, seed=41)
+    locs[5] = locs[400]                                     # u <= eps pair
+    fit = ca.CoconsFit(locs, X, rng.standard_normal(n), wl_limits())
+    idx = np.array([0, 5, 399, 400, n - 1])
+    S = oracle.cov_rns(th, locs, X, wl_limits())
+    rows = fit.cov_rows(th, idx)
+    assert _relerr(rows, S[idx]) < ENTRY_RTOL
+    d = 1 / np.sqrt(np.diag(S))
+    R = (d[:, None] * S) * d[None, :]
+    np.fill_diagonal(R, 1.0)
+    cor = fit.cov_rows(th, idx, cor=True)
+    assert _relerr(cor, R[idx]) < ENTRY_RTOL
+    assert all(cor[b, i] == 1.0 for b, i in enumerate(idx))
+    Sc = oracle.cov_rns_classic(th, locs, X)
+    assert _relerr(fit.cov_rows(th, idx, classic=True), Sc[idx]) < ENTRY_RTOL
+    t2 = {k: np.array(v, dtype=float) for k, v in th.items()}
+    t2["smooth"] = np.zeros(3)
+    fit2 = ca.CoconsFit(locs, X, rng.standard_normal(n), (1.5, 1.5))
+    assert _relerr(fit2.cov_rows(t2, idx), oracle.cov_rns(t2, locs, X, (1.5, 1.5))[idx]) < ENTRY_RTOL

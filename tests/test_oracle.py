@@ -168,3 +168,33 @@ def test_penalty_and_theta_plumbing(oracle):
     s = oracle.getScale(X)
     assert np.all(s["std.covs"][:, 0] == 1)
     assert abs(s["std.covs"][:, 1].mean()) < 1e-15 and s["std.covs"][:, 1].std(ddof=1) == pytest.approx(1.0)
+
+
+def test_taper_golden_n24(oracle, golden_dir):
+    """cov_rns_taper / cov_rns_taper_pred restatement against the 40-digit mpmath entries
+    (tests/golden/make_golden_taper.py): general nu, fixed nu = 1.5, prediction variant incl. a
+    coincident location."""
+    g = json.load(open(os.path.join(golden_dir, "taper_n24.json")))
+    th = {k: np.array(v) for k, v in g["theta"].items()}
+    locs, X = np.array(g["locs"]), np.array(g["X"])
+    a = oracle.cov_rns_taper(th, locs, X, g["colindices"], g["rowpointers"], g["smooth_limits"])
+    assert _relerr(a, g["entries_general"]) < 5e-14
+    th15 = dict(th)
+    th15["smooth"] = np.zeros(3)
+    b = oracle.cov_rns_taper(th15, locs, X, g["colindices"], g["rowpointers"], [1.5, 1.5])
+    assert _relerr(b, g["entries_fixed_1p5"]) < 5e-14
+    c = oracle.cov_rns_taper_pred(th, locs, np.array(g["locs_pred"]), X, np.array(g["X_pred"]),
+                                  g["colindices_pred"], g["rowpointers_pred"], g["smooth_limits"])
+    assert _relerr(c, g["entries_pred"]) < 5e-14
+    # the dense and the taper functions agree where they model the same thing: no anisotropy, p = 1
+    n = 12
+    rng = np.random.default_rng(2)
+    l2 = rng.uniform(0, 1, size=(n, 2))
+    X1 = np.ones((n, 1))
+    t1 = {"std.dev": np.array([0.3]), "scale": np.array([math.log(0.25)]), "aniso": np.zeros(1), "tilt": np.zeros(1),
+          "smooth": np.zeros(1), "nugget": np.array([math.log(0.05)])}
+    ci = np.tile(np.arange(1, n + 1), n)
+    rp = np.arange(0, n + 1) * n + 1
+    dense = oracle.cov_rns(t1, l2, X1, (1.5, 1.5))
+    sparse = oracle.cov_rns_taper(t1, l2, X1, ci, rp, (1.5, 1.5)).reshape(n, n)
+    assert _relerr(sparse, dense) < 1e-13
