@@ -1,0 +1,104 @@
+# glue/R/cocons_hip.R -- R side of the HIP drop-in: replaces the BODIES of the reference's objective
+# closures (R/neg2loglikelihood.R:127-291); names, arguments and return values are unchanged, so
+# cocoOptim / getHessian / cocoPredict / cocoSim call them as before.  The thin wrappers of
+# R/RcppExports.R (cov_rns, cov_rns_classic, cov_rns_pred, cov_rns_taper*, sumsmoothlone) stay as they
+# are: only the native symbols behind them change (glue/cocons_hip_glue.c).
+#
+# The device-resident data of a fit live in an explicit handle (external pointer).  Callers that hold
+# one pass it as `fit = `; otherwise one handle per (process, data) is created on first use and kept in
+# an environment keyed on the ADDRESS-INDEPENDENT content hash of everything the handle depends on
+# (all of locs, x_covariates, z, x_betas, smooth.limits) -- two datasets can no longer alias.
+
+.cocons.hip <- new.env(parent = emptyenv())
+
+cocons_hip_fit <- function(locs, x_covariates, z, smooth.limits, x_betas = NULL, device = NULL) {
+  if (is.null(device)) {
+    ndev <- max(1L, .Call(`_cocons_hip_device_count`))
+    device <- as.integer(Sys.getenv("COCONS_HIP_DEVICE", Sys.getpid() %% ndev))   # worker -> GPU map
+  }
+  z <- as.matrix(z)
+  storage.mode(locs) <- storage.mode(x_covariates) <- storage.mode(z) <- "double"
+  if (!is.null(x_betas)) { x_betas <- as.matrix(x_betas); storage.mode(x_betas) <- "double" }
+  .Call(`_cocons_hip_fit_create`, locs, x_covariates, z, x_betas, as.double(smooth.limits), as.integer(device))
+}
+
+.cocons.hip.cached <- function(locs, x_covariates, z, smooth.limits, x_betas = NULL) {
+  key <- paste(Sys.getpid(), rlang::hash(list(locs, x_covariates, z, x_betas, smooth.limits)))
+  fit <- .cocons.hip[[key]]
+  if (is.null(fit)) {
+    fit <- cocons_hip_fit(locs, x_covariates, z, smooth.limits, x_betas)
+    assign(key, fit, envir = .cocons.hip)
+  }
+  fit
+}
+
+.cocons.hip.result <- function(res, safe) {       # the reference's tryCatch contract, :200-206
+  if (res[[1]] > 0L) {
+    if (safe) return(NULL) else stop("Cholesky error")
+  }
+  res[[2]]
+}
+
+GetNeg2loglikelihood <- function(theta, par.pos, locs, x_covariates, smooth.limits, z, n, lambda,
+                                 safe = TRUE, fit = NULL) {
+  theta_list <- cocons::getModelLists(theta = theta, par.pos = par.pos, type = "diff")     # :193
+  if (is.null(fit)) fit <- .cocons.hip.cached(locs, x_covariates, z, smooth.limits)
+  val <- .cocons.hip.result(.Call(`_cocons_hip_neg2loglik`, fit, theta_list[-1], theta_list$mean), safe)
+  if (is.null(val)) return(1e+06)
+  val + .cocons.getPen(n * dim(as.matrix(z))[2], lambda, theta_list, smooth.limits)          # :220
+}
+
+# the 1 + 2P points of one finite-difference gradient, or getHessian's 3P(P+1)/2 (R/getFunctions.R:979-1016)
+GetNeg2loglikelihoodBatch <- function(thetas, par.pos, locs, x_covariates, smooth.limits, z, n, lambda,
+                                      safe = TRUE, fit = NULL) {
+  tl <- lapply(thetas, function(t) cocons::getModelLists(theta = t, par.pos = par.pos, type = "diff"))
+  if (is.null(fit)) fit <- .cocons.hip.cached(locs, x_covariates, z, smooth.limits)
+  res <- .Call(`_cocons_hip_neg2loglik_batch`, fit, lapply(tl, function(x) x[-1]), lapply(tl, function(x) x$mean))
+  out <- res[[2]]
+  for (i in seq_along(tl)) {
+    if (res[[1]][i] > 0L) { if (safe) out[i] <- 1e+06 else stop("Cholesky error") }
+    else out[i] <- out[i] + .cocons.getPen(n * dim(as.matrix(z))[2], lambda, tl[[i]], smooth.limits)
+  }
+  out
+}
+
+GetNeg2loglikelihoodProfile <- function(theta, par.pos, locs, x_covariates, smooth.limits, z, n, x_betas,
+                                        lambda, safe = TRUE, fit = NULL) {
+  theta_list <- cocons::getModelLists(theta = theta, par.pos = par.pos, type = "diff")
+  if (is.null(fit)) fit <- .cocons.hip.cached(locs, x_covariates, z, smooth.limits, x_betas)
+  v <- .cocons.hip.result(.Call(`_cocons_hip_neg2loglik_profile`, fit, theta_list[-1]), safe)
+  if (is.null(v)) return(1e+06)
+  v[1] + .cocons.getPen(n * dim(as.matrix(z))[2], lambda, theta_list, smooth.limits)
+}
+
+GetNeg2loglikelihoodREML <- function(theta, par.pos, locs, x_covariates, x_betas, smooth.limits, z, n,
+                                     lambda, safe = TRUE, fit = NULL) {
+  theta_list <- cocons::getModelLists(theta = theta, par.pos = par.pos, type = "diff")
+  if (is.null(fit)) fit <- .cocons.hip.cached(locs, x_covariates, z, smooth.limits)
+  v <- .cocons.hip.result(.Call(`_cocons_hip_neg2loglik_reml`, fit, theta_list[-1],
+                                as.integer(qr(x_covariates)$rank)), safe)                  # :270
+  if (is.null(v)) return(1e+06)
+  v[1] + .cocons.getPen(n * dim(as.matrix(z))[2], lambda, theta_list, smooth.limits)
+}
+
+# GLS coefficients after a pml / reml fit (R/optim.R:329-341) without a second chol:
+# v = c(sum_logliks, logdet, logdet_W, quad_1..r, beta_1..) as returned by the cores above
+.cocons.hip.betas <- function(v, r) v[-seq_len(3 + r)]
+
+# dense kriging core for cocoPredict (R/predict.R:136-183): the four lines cov_rns / cov_rns_pred /
+# solve / rowSums become
+#   kr <- .cocons.hip.predict(fit, theta_list, newlocs, X_pred_std)
+#   stochastic <- kr[, 1];  quadform <- kr[, 2]      # c_i' Sigma^-1 resid,  c_i' Sigma^-1 c_i
+.cocons.hip.predict <- function(fit, theta_list, newlocs, X_pred, z_col = 1L) {
+  res <- .Call(`_cocons_hip_predict`, fit, theta_list[-1], theta_list$mean, as.integer(z_col), newlocs, X_pred)
+  if (res[[1]] > 0L) stop("Cholesky error")
+  res[[2]]
+}
+
+# rows of cov2cor(cov_rns(...)) for plot(type = "correlations") (R/methods.R:161-165): tmp_cov[ww, ]
+.cocons.hip.cor.rows <- function(fit, theta_list, index, classic = FALSE)
+  .Call(`_cocons_hip_cov_rows`, fit, theta_list[-1], classic, as.integer(index), TRUE)
+
+# one R process, several GPUs: Sigma row blocks sharded over `devices`, RCCL inside the library
+cocons_hip_multi <- function(locs, x_covariates, z, smooth.limits, devices)
+  .Call(`_cocons_hip_multi_create`, locs, x_covariates, as.matrix(z), as.double(smooth.limits), as.integer(devices))

@@ -1,0 +1,396 @@
+/*
+ * glue/cocons_hip_glue.c -- the complete `.Call` layer over libcocons_hip.so (include/cocons_hip.h).
+ *
+ * Drop into the reference package's src/ IN PLACE OF src/RcppExports.cpp (plain C against R's C API; no
+ * Rcpp, no Boost).  It defines every native symbol the reference registers
+ * (src/RcppExports.cpp:105-113: _cocons_sumsmoothlone, _cocons_cov_rns, _cocons_cov_rns_pred,
+ * _cocons_cov_rns_classic, _cocons_cov_rns_taper_pred, _cocons_cov_rns_taper) with the same arity, plus
+ * the fused entries of the fit handle, and registers them all in R_init_cocons.
+ *
+ * R is not installed in the build image of this repository, so this file is NOT compiled there; every
+ * cocons_* function it calls is exercised through the same C ABI by tests/ (ctypes, cocons_amd/_lib.py).
+ * Makevars:  PKG_CPPFLAGS = -I$(COCONS_HIP)/include
+ *            PKG_LIBS     = -L$(COCONS_HIP)/cocons_amd/csrc -lcocons_hip -Wl,-rpath,$(COCONS_HIP)/cocons_amd/csrc
+ *
+ * Conventions: a Cholesky failure is NOT an R error here -- the fused entries return list(status, ...)
+ * with status k > 0 and the R closures map it to 1e+06 / stop("Cholesky error") exactly as
+ * R/neg2loglikelihood.R:200-206 does; status < 0 (bad argument, HIP, RCCL) raises an R error with the
+ * library's message.  No HIP call happens at load time (R_init_cocons): cocoOptim forks its workers
+ * (R/optim.R:117-121) and a HIP context does not survive fork; a handle refuses use in another process.
+ */
+#include <string.h>
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+#include "cocons_hip.h"
+
+/* ---- helpers ---------------------------------------------------------------------------------- */
+static SEXP list_get(SEXP lst, const char *nm)
+{
+    SEXP names = Rf_getAttrib(lst, R_NamesSymbol);
+    for (R_xlen_t i = 0; i < XLENGTH(lst); ++i)
+        if (strcmp(CHAR(STRING_ELT(names, i)), nm) == 0) return VECTOR_ELT(lst, i);
+    Rf_error("theta has no element '%s'", nm);
+    return R_NilValue;
+}
+
+/* theta: named list -> 6 x p row-major table, looked up BY NAME like src/cocons_full.cpp:47-54, so both
+ * theta_list and theta_list[-1] work */
+static void theta_table(SEXP theta, int p, double *T)
+{
+    static const char *asp[6] = {"std.dev", "scale", "aniso", "tilt", "smooth", "nugget"};
+    if (p < 1 || p > COCONS_P_MAX) Rf_error("the design matrix has %d columns; the HIP path supports 1..%d", p, COCONS_P_MAX);
+    for (int a = 0; a < 6; ++a) {
+        SEXP v = list_get(theta, asp[a]);
+        if (!Rf_isReal(v) || XLENGTH(v) != p) Rf_error("theta$%s must be a double vector of length %d", asp[a], p);
+        memcpy(T + a * p, REAL(v), (size_t)p * sizeof(double));
+    }
+}
+
+static void hip_check(int rc, const char *what)
+{
+    if (rc < 0) Rf_error("%s: %s", what, cocons_last_error());
+}
+
+static cocons_fit *fit_of(SEXP ptr)
+{
+    cocons_fit *f = (cocons_fit *)R_ExternalPtrAddr(ptr);
+    if (!f) Rf_error("cocons HIP handle is NULL (closed, or restored from a saved workspace)");
+    return f;
+}
+
+static SEXP status_value(int rc, SEXP value)     /* list(status, value) */
+{
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 2));
+    SET_VECTOR_ELT(out, 0, Rf_ScalarInteger(rc));
+    SET_VECTOR_ELT(out, 1, value);
+    UNPROTECT(1);
+    return out;
+}
+
+/* spam index vectors arrive as integer (spam's slots) or double (after arithmetic): copy to int */
+static int *as_int_copy(SEXP v, R_xlen_t *len)
+{
+    R_xlen_t n = XLENGTH(v);
+    int *out = (int *)R_alloc((size_t)(n > 0 ? n : 1), sizeof(int));
+    if (Rf_isInteger(v)) memcpy(out, INTEGER(v), (size_t)n * sizeof(int));
+    else if (Rf_isReal(v)) for (R_xlen_t i = 0; i < n; ++i) out[i] = (int)REAL(v)[i];
+    else Rf_error("index vector must be integer or double");
+    *len = n;
+    return out;
+}
+
+/* ---- the reference's registered symbols (same names, same arity) ------------------------------ */
+/* src/RcppExports.cpp:16-26 */
+SEXP _cocons_sumsmoothlone(SEXP x, SEXP lambda, SEXP alpha)
+{
+    return Rf_ScalarReal(cocons_sumsmoothlone(REAL(x), (int)XLENGTH(x), Rf_asReal(lambda), Rf_asReal(alpha)));
+}
+
+/* src/RcppExports.cpp:29-40 */
+SEXP _cocons_cov_rns(SEXP theta, SEXP locs, SEXP X, SEXP smooth_limits)
+{
+    const int n = Rf_nrows(X), p = Rf_ncols(X);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    SEXP ans = PROTECT(Rf_allocMatrix(REALSXP, n, n));     /* same ownership as NumericMatrix(m_dim, m_dim) */
+    hip_check(cocons_cov_rns(n, p, T, REAL(locs), REAL(X), REAL(smooth_limits), REAL(ans)), "cov_rns");
+    UNPROTECT(1);
+    return ans;
+}
+
+/* src/RcppExports.cpp:43-56 */
+SEXP _cocons_cov_rns_pred(SEXP theta, SEXP locs, SEXP locs_pred, SEXP X, SEXP X_pred, SEXP smooth_limits)
+{
+    const int n = Rf_nrows(X), p = Rf_ncols(X), m = Rf_nrows(X_pred);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    SEXP ans = PROTECT(Rf_allocMatrix(REALSXP, m, n));
+    hip_check(cocons_cov_rns_pred(n, m, p, T, REAL(locs), REAL(locs_pred), REAL(X), REAL(X_pred),
+                                  REAL(smooth_limits), REAL(ans)), "cov_rns_pred");
+    UNPROTECT(1);
+    return ans;
+}
+
+/* src/RcppExports.cpp:59-69 */
+SEXP _cocons_cov_rns_classic(SEXP theta, SEXP locs, SEXP X)
+{
+    const int n = Rf_nrows(X), p = Rf_ncols(X);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    SEXP ans = PROTECT(Rf_allocMatrix(REALSXP, n, n));
+    hip_check(cocons_cov_rns_classic(n, p, T, REAL(locs), REAL(X), REAL(ans)), "cov_rns_classic");
+    UNPROTECT(1);
+    return ans;
+}
+
+/* src/RcppExports.cpp:72-87; colindices / rowpointers are read, never modified */
+SEXP _cocons_cov_rns_taper_pred(SEXP theta, SEXP locs, SEXP locs_pred, SEXP X, SEXP X_pred, SEXP colindices,
+                                SEXP rowpointers, SEXP smooth_limits)
+{
+    const int n = Rf_nrows(X), p = Rf_ncols(X), m = Rf_nrows(X_pred);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    R_xlen_t nnz, nrp;
+    int *ci = as_int_copy(colindices, &nnz), *rp = as_int_copy(rowpointers, &nrp);
+    if (nrp != (R_xlen_t)m + 1) Rf_error("rowpointers must have nrow(locs_pred) + 1 entries");
+    SEXP ans = PROTECT(Rf_allocVector(REALSXP, nnz));
+    hip_check(cocons_cov_rns_taper_pred(n, m, p, T, REAL(locs), REAL(locs_pred), REAL(X), REAL(X_pred),
+                                        REAL(smooth_limits), (int)nnz, ci, rp, REAL(ans)), "cov_rns_taper_pred");
+    UNPROTECT(1);
+    return ans;
+}
+
+/* src/RcppExports.cpp:88-101 */
+SEXP _cocons_cov_rns_taper(SEXP theta, SEXP locs, SEXP X, SEXP colindices, SEXP rowpointers, SEXP smooth_limits)
+{
+    const int n = Rf_nrows(X), p = Rf_ncols(X);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    R_xlen_t nnz, nrp;
+    int *ci = as_int_copy(colindices, &nnz), *rp = as_int_copy(rowpointers, &nrp);
+    if (nrp != (R_xlen_t)n + 1) Rf_error("rowpointers must have nrow(locs) + 1 entries");
+    SEXP ans = PROTECT(Rf_allocVector(REALSXP, nnz));
+    hip_check(cocons_cov_rns_taper(n, p, T, REAL(locs), REAL(X), REAL(smooth_limits), (int)nnz, ci, rp, REAL(ans)),
+              "cov_rns_taper");
+    UNPROTECT(1);
+    return ans;
+}
+
+/* ---- fit handle: explicit external pointer owned by the caller (no hidden cache key) ------------ */
+SEXP _cocons_hip_device_count(void)
+{
+    int n = cocons_device_count();
+    if (n < 0) Rf_error("cocons_device_count: %s", cocons_last_error());
+    return Rf_ScalarInteger(n);
+}
+
+static void fit_finalizer(SEXP ptr)
+{
+    cocons_fit *f = (cocons_fit *)R_ExternalPtrAddr(ptr);
+    if (f) { cocons_fit_destroy(f); R_ClearExternalPtr(ptr); }
+}
+
+/* x_betas may be NULL; device < 0 = default */
+SEXP _cocons_hip_fit_create(SEXP locs, SEXP X, SEXP z, SEXP x_betas, SEXP smooth_limits, SEXP device)
+{
+    const int n = Rf_nrows(X), p = Rf_ncols(X);
+    const int r = Rf_isMatrix(z) ? Rf_ncols(z) : 1;
+    const int q = Rf_isNull(x_betas) ? 0 : (Rf_isMatrix(x_betas) ? Rf_ncols(x_betas) : 1);
+    if (Rf_nrows(locs) != n || Rf_ncols(locs) != 2) Rf_error("locs must be n x 2");
+    cocons_fit *f = cocons_fit_create(n, p, r, q, REAL(locs), REAL(X), REAL(z), q ? REAL(x_betas) : NULL,
+                                      REAL(smooth_limits), Rf_asInteger(device));
+    if (!f) Rf_error("cocons_fit_create: %s", cocons_last_error());
+    SEXP tag = PROTECT(Rf_allocVector(INTSXP, 4));         /* n, p, r, q: lets the R side validate its arguments */
+    INTEGER(tag)[0] = n; INTEGER(tag)[1] = p; INTEGER(tag)[2] = r; INTEGER(tag)[3] = q;
+    SEXP ptr = PROTECT(R_MakeExternalPtr(f, tag, R_NilValue));
+    R_RegisterCFinalizerEx(ptr, fit_finalizer, TRUE);
+    UNPROTECT(2);
+    return ptr;
+}
+
+SEXP _cocons_hip_fit_close(SEXP ptr)
+{
+    fit_finalizer(ptr);
+    return R_NilValue;
+}
+
+static int fit_p(SEXP ptr) { return INTEGER(R_ExternalPtrTag(ptr))[1]; }
+static int fit_r(SEXP ptr) { return INTEGER(R_ExternalPtrTag(ptr))[2]; }
+static int fit_q(SEXP ptr) { return INTEGER(R_ExternalPtrTag(ptr))[3]; }
+static int fit_n(SEXP ptr) { return INTEGER(R_ExternalPtrTag(ptr))[0]; }
+
+/* GetNeg2loglikelihood core (R/neg2loglikelihood.R:195-218): list(status, sum_logliks) */
+SEXP _cocons_hip_neg2loglik(SEXP fitp, SEXP theta, SEXP mean)
+{
+    cocons_fit *f = fit_of(fitp);
+    double T[6 * COCONS_P_MAX], val = NA_REAL;
+    theta_table(theta, fit_p(fitp), T);
+    if (XLENGTH(mean) != fit_p(fitp)) Rf_error("theta$mean must have length %d", fit_p(fitp));
+    int rc = cocons_neg2loglik_dense(f, T, REAL(mean), &val, NULL);
+    hip_check(rc, "GetNeg2loglikelihood");
+    return status_value(rc, Rf_ScalarReal(val));
+}
+
+/* nb evaluations at once: thetas = list of theta lists, means = list of mean vectors (or a p x nb matrix);
+ * returns list(status = integer(nb), value = double(nb)) */
+SEXP _cocons_hip_neg2loglik_batch(SEXP fitp, SEXP thetas, SEXP means)
+{
+    cocons_fit *f = fit_of(fitp);
+    const int p = fit_p(fitp), nb = (int)XLENGTH(thetas);
+    double *T = (double *)R_alloc((size_t)(nb > 0 ? nb : 1) * 6 * p, sizeof(double));
+    double *M = (double *)R_alloc((size_t)(nb > 0 ? nb : 1) * p, sizeof(double));
+    for (int i = 0; i < nb; ++i) {
+        theta_table(VECTOR_ELT(thetas, i), p, T + (size_t)i * 6 * p);
+        memcpy(M + (size_t)i * p, Rf_isMatrix(means) ? REAL(means) + (size_t)i * p : REAL(VECTOR_ELT(means, i)),
+               (size_t)p * sizeof(double));
+    }
+    SEXP st = PROTECT(Rf_allocVector(INTSXP, nb)), val = PROTECT(Rf_allocVector(REALSXP, nb));
+    hip_check(cocons_neg2loglik_batch(f, nb, T, M, REAL(val), INTEGER(st)), "GetNeg2loglikelihood (batch)");
+    SEXP out = status_value(0, val);
+    SET_VECTOR_ELT(out, 0, st);
+    UNPROTECT(2);
+    return out;
+}
+
+/* Profile core (R/neg2loglikelihood.R:132-160): list(status, c(sum_logliks, parts...)); parts as in the header */
+SEXP _cocons_hip_neg2loglik_profile(SEXP fitp, SEXP theta)
+{
+    cocons_fit *f = fit_of(fitp);
+    const int p = fit_p(fitp), r = fit_r(fitp), q = fit_q(fitp);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    SEXP v = PROTECT(Rf_allocVector(REALSXP, 1 + 2 + r + q));
+    int rc = cocons_neg2loglik_profile(f, T, REAL(v), REAL(v) + 1);
+    hip_check(rc, "GetNeg2loglikelihoodProfile");
+    SEXP out = status_value(rc, v);
+    UNPROTECT(1);
+    return out;
+}
+
+/* REML core (R/neg2loglikelihood.R:254-287); rank = qr(x_covariates)$rank (:270) */
+SEXP _cocons_hip_neg2loglik_reml(SEXP fitp, SEXP theta, SEXP rank)
+{
+    cocons_fit *f = fit_of(fitp);
+    const int p = fit_p(fitp), r = fit_r(fitp);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    SEXP v = PROTECT(Rf_allocVector(REALSXP, 1 + 2 + r + p));
+    int rc = cocons_neg2loglik_reml(f, T, Rf_asInteger(rank), REAL(v), REAL(v) + 1);
+    hip_check(rc, "GetNeg2loglikelihoodREML");
+    SEXP out = status_value(rc, v);
+    UNPROTECT(1);
+    return out;
+}
+
+/* dense kriging core (R/predict.R:136-183): list(status, cbind(stochastic, quadform)) */
+SEXP _cocons_hip_predict(SEXP fitp, SEXP theta, SEXP mean, SEXP z_col, SEXP locs_pred, SEXP X_pred)
+{
+    cocons_fit *f = fit_of(fitp);
+    const int p = fit_p(fitp), m = Rf_nrows(X_pred);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    SEXP v = PROTECT(Rf_allocMatrix(REALSXP, m, 2));
+    int rc = cocons_predict_dense(f, T, REAL(mean), Rf_asInteger(z_col) - 1, m, REAL(locs_pred), REAL(X_pred),
+                                  REAL(v), REAL(v) + m);
+    hip_check(rc, "cocoPredict");
+    SEXP out = status_value(rc, v);
+    UNPROTECT(1);
+    return out;
+}
+
+/* marginal simulation core (R/sim.R:147-172): iiderrors n x nsim -> list(status, n x nsim fields) */
+SEXP _cocons_hip_sim(SEXP fitp, SEXP theta, SEXP mean, SEXP classic, SEXP iiderrors)
+{
+    cocons_fit *f = fit_of(fitp);
+    const int p = fit_p(fitp), n = fit_n(fitp), nsim = Rf_ncols(iiderrors);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    if (Rf_nrows(iiderrors) != n) Rf_error("iiderrors must have n rows");
+    SEXP v = PROTECT(Rf_allocMatrix(REALSXP, n, nsim));
+    int rc = cocons_sim_dense(f, T, REAL(mean), Rf_asLogical(classic), nsim, REAL(iiderrors), REAL(v));
+    hip_check(rc, "cocoSim");
+    SEXP out = status_value(rc, v);
+    UNPROTECT(1);
+    return out;
+}
+
+/* conditional simulation core (R/sim.R:84-127): iiderrors m x nsim -> list(status, m x nsim fields) */
+SEXP _cocons_hip_sim_cond(SEXP fitp, SEXP theta, SEXP mean, SEXP z_col, SEXP locs_pred, SEXP X_pred,
+                          SEXP locs_unobs, SEXP iiderrors)
+{
+    cocons_fit *f = fit_of(fitp);
+    const int p = fit_p(fitp), m = Rf_nrows(X_pred), nsim = Rf_ncols(iiderrors);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    SEXP v = PROTECT(Rf_allocMatrix(REALSXP, m, nsim));
+    int rc = cocons_sim_cond_dense(f, T, REAL(mean), Rf_asInteger(z_col) - 1, m, REAL(locs_pred), REAL(X_pred),
+                                   REAL(locs_unobs), nsim, REAL(iiderrors), REAL(v));
+    hip_check(rc, "cocoSim (conditional)");
+    SEXP out = status_value(rc, v);
+    UNPROTECT(1);
+    return out;
+}
+
+/* rows of cov_rns / cov2cor(cov_rns) without the n x n matrix (R/methods.R:161-165); index is 1-based;
+ * returns a length(index) x n matrix */
+SEXP _cocons_hip_cov_rows(SEXP fitp, SEXP theta, SEXP classic, SEXP index, SEXP cor)
+{
+    cocons_fit *f = fit_of(fitp);
+    const int p = fit_p(fitp), n = fit_n(fitp);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    R_xlen_t k;
+    int *idx = as_int_copy(index, &k);
+    for (R_xlen_t i = 0; i < k; ++i) idx[i] -= 1;
+    double *tmp = (double *)R_alloc((size_t)k * n, sizeof(double));
+    hip_check(cocons_cov_rows(f, T, Rf_asLogical(classic), (int)k, idx, Rf_asLogical(cor), tmp), "cov rows");
+    SEXP ans = PROTECT(Rf_allocMatrix(REALSXP, (int)k, n));
+    for (R_xlen_t b = 0; b < k; ++b)
+        for (int j = 0; j < n; ++j) REAL(ans)[b + (size_t)j * k] = tmp[(size_t)b * n + j];
+    UNPROTECT(1);
+    return ans;
+}
+
+/* ---- several GPUs from ONE R process (cocons_multi_*: RCCL inside the library) ----------------- */
+static void multi_finalizer(SEXP ptr)
+{
+    cocons_multi *m = (cocons_multi *)R_ExternalPtrAddr(ptr);
+    if (m) { cocons_multi_destroy(m); R_ClearExternalPtr(ptr); }
+}
+
+SEXP _cocons_hip_multi_create(SEXP locs, SEXP X, SEXP z, SEXP smooth_limits, SEXP devices)
+{
+    const int n = Rf_nrows(X), p = Rf_ncols(X), r = Rf_isMatrix(z) ? Rf_ncols(z) : 1;
+    R_xlen_t nd;
+    int *dev = as_int_copy(devices, &nd);
+    cocons_multi *m = cocons_multi_create(n, p, r, REAL(locs), REAL(X), REAL(z), REAL(smooth_limits), (int)nd, dev);
+    if (!m) Rf_error("cocons_multi_create: %s", cocons_last_error());
+    SEXP tag = PROTECT(Rf_allocVector(INTSXP, 4));
+    INTEGER(tag)[0] = n; INTEGER(tag)[1] = p; INTEGER(tag)[2] = r; INTEGER(tag)[3] = 0;
+    SEXP ptr = PROTECT(R_MakeExternalPtr(m, tag, R_NilValue));
+    R_RegisterCFinalizerEx(ptr, multi_finalizer, TRUE);
+    UNPROTECT(2);
+    return ptr;
+}
+
+SEXP _cocons_hip_multi_neg2loglik(SEXP mp, SEXP theta, SEXP mean)
+{
+    cocons_multi *m = (cocons_multi *)R_ExternalPtrAddr(mp);
+    if (!m) Rf_error("cocons multi-GPU handle is NULL");
+    double T[6 * COCONS_P_MAX], val = NA_REAL;
+    theta_table(theta, fit_p(mp), T);
+    int rc = cocons_multi_neg2loglik_dense(m, T, REAL(mean), &val, NULL);
+    hip_check(rc, "GetNeg2loglikelihood (multi-GPU)");
+    return status_value(rc, Rf_ScalarReal(val));
+}
+
+/* ---- registration (replaces src/RcppExports.cpp:105-118) --------------------------------------- */
+static const R_CallMethodDef CallEntries[] = {
+    {"_cocons_sumsmoothlone", (DL_FUNC)&_cocons_sumsmoothlone, 3},
+    {"_cocons_cov_rns", (DL_FUNC)&_cocons_cov_rns, 4},
+    {"_cocons_cov_rns_pred", (DL_FUNC)&_cocons_cov_rns_pred, 6},
+    {"_cocons_cov_rns_classic", (DL_FUNC)&_cocons_cov_rns_classic, 3},
+    {"_cocons_cov_rns_taper_pred", (DL_FUNC)&_cocons_cov_rns_taper_pred, 8},
+    {"_cocons_cov_rns_taper", (DL_FUNC)&_cocons_cov_rns_taper, 6},
+    {"_cocons_hip_device_count", (DL_FUNC)&_cocons_hip_device_count, 0},
+    {"_cocons_hip_fit_create", (DL_FUNC)&_cocons_hip_fit_create, 6},
+    {"_cocons_hip_fit_close", (DL_FUNC)&_cocons_hip_fit_close, 1},
+    {"_cocons_hip_neg2loglik", (DL_FUNC)&_cocons_hip_neg2loglik, 3},
+    {"_cocons_hip_neg2loglik_batch", (DL_FUNC)&_cocons_hip_neg2loglik_batch, 3},
+    {"_cocons_hip_neg2loglik_profile", (DL_FUNC)&_cocons_hip_neg2loglik_profile, 2},
+    {"_cocons_hip_neg2loglik_reml", (DL_FUNC)&_cocons_hip_neg2loglik_reml, 3},
+    {"_cocons_hip_predict", (DL_FUNC)&_cocons_hip_predict, 6},
+    {"_cocons_hip_sim", (DL_FUNC)&_cocons_hip_sim, 5},
+    {"_cocons_hip_sim_cond", (DL_FUNC)&_cocons_hip_sim_cond, 8},
+    {"_cocons_hip_cov_rows", (DL_FUNC)&_cocons_hip_cov_rows, 5},
+    {"_cocons_hip_multi_create", (DL_FUNC)&_cocons_hip_multi_create, 5},
+    {"_cocons_hip_multi_neg2loglik", (DL_FUNC)&_cocons_hip_multi_neg2loglik, 3},
+    {NULL, NULL, 0}
+};
+
+void R_init_cocons(DllInfo *dll)
+{
+    R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);   /* no HIP call here (fork safety) */
+    R_useDynamicSymbols(dll, FALSE);
+}

@@ -63,3 +63,29 @@ def test_bad_arguments_return_error_codes_without_touching_the_gpu():
     assert not lib.cocons_fit_create(0, 1, 1, 0, p, p, p, None, p, 0)
     assert lib.cocons_neg2loglik_dense(None, p, p, p, None) < 0
     assert "null fit handle" in _lib.last_error()
+
+
+def test_glue_covers_the_reference_call_surface():
+    """glue/cocons_hip_glue.c (the `.Call` layer a maintainer drops into src/) defines and registers every
+    native symbol of the reference's table (src/RcppExports.cpp:105-113) with the same arity, and only calls
+    functions include/cocons_hip.h declares."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    glue = open(os.path.join(root, "glue", "cocons_hip_glue.c")).read()
+    header = open(os.path.join(root, "include", "cocons_hip.h")).read()
+    table = dict(re.findall(r'\{"(_cocons_[a-z_0-9]+)",\s*\(DL_FUNC\)&\1,\s*(\d+)\}', glue))
+    reference = {"_cocons_sumsmoothlone": 3, "_cocons_cov_rns": 4, "_cocons_cov_rns_pred": 6,
+                 "_cocons_cov_rns_classic": 3, "_cocons_cov_rns_taper_pred": 8, "_cocons_cov_rns_taper": 6}
+    for name, arity in reference.items():
+        assert int(table[name]) == arity
+    for name, arity in table.items():                       # every registered symbol is defined with that arity
+        m = re.search(r"^SEXP %s\(([^)]*)\)" % name, glue, re.M)
+        assert m, name
+        args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        assert len(args) == int(arity), name
+    declared = set(re.findall(r"\b(cocons_[a-z0-9_]+)\s*\(", header))
+    used = set(re.findall(r"\b(cocons_[a-z0-9_]+)\s*\(", glue)) - {"cocons_hip_glue"}
+    assert used <= declared, used - declared
+    rfile = open(os.path.join(root, "glue", "R", "cocons_hip.R")).read()
+    for sym in re.findall(r"`(_cocons_hip_[a-z_0-9]+)`", rfile):
+        assert sym in table, sym
