@@ -621,12 +621,6 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     const int nt = v.nt, mt = v.mt;
     hipStream_t M = f->stream;
     if (!engine_enabled() || !f->engine_ok || nt <= 4) {
-        {   // diagnostic: COCONS_DUMMY_RESIDENT="threads,lds_bytes,ms,mode"
-            const char *e = getenv("COCONS_DUMMY_RESIDENT");
-            int th = 0, mode = 0; long lds = 0; double ms = 0;
-            if (e && sscanf(e, "%d,%ld,%lf,%d", &th, &lds, &ms, &mode) == 4 && nt > 4)
-                launch_dummy_resident(f->stream2, th, (size_t)lds, ms, mode, (unsigned *)(f->dinfo + 1));
-        }
         for (int k = 0; k < nt; k += 2) {
             panel_ops(f, v, k, M);
             if (k + 2 < nt) {
@@ -1990,7 +1984,7 @@ extern "C" int cocons_debug_upd_clock(double *out3)
 // extended probe: see run_mfma_f64_probe_ex (chol.hip) for the meaning of out[0..3]
 extern "C" int cocons_mfma_f64_probe_ex(int blocks_per_cu, int nacc, int form, int iters, int gap_us, int reps, double *out4)
 {
-    if (!out4 || blocks_per_cu < 1 || blocks_per_cu > 8 || (nacc != 4 && nacc != 8 && nacc != 16) || form < 0 || form > 3 ||
+    if (!out4 || blocks_per_cu < 1 || blocks_per_cu > 8 || (nacc != 4 && nacc != 8 && nacc != 16) || form < 0 || form > 3 || form == 2 ||
         iters < 1 || reps < 1 || gap_us < 0)
         return fail(-1, "cocons_mfma_f64_probe_ex: bad argument");
     hipDeviceProp_t prop;

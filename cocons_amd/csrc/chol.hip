@@ -588,7 +588,6 @@ struct UpdArgs {
     unsigned *sig; int sig_tile;   // engine hand-off: workgroups inside the diagonal block (tiles sig_tile, sig_tile+1)
                                    // add 1 to sig[sig_tile] (tile (t,t)) or sig[sig_tile+1] (tiles (t+1,t), (t+1,t+1))
     unsigned *wait_word, *abort_word;  // engine hand-off: every workgroup first waits for *wait_word >= 1
-    int dbg;                       // diagnostic timing knob (COCONS_UPD_DBG): 1 = no operand staging after chunk 0, 2 = also no C read-modify-write
     unsigned long long *stamp;     // diagnostic (COCONS_UPD_STAMP=1): += {shader cycles, 100 MHz ticks, 1} per workgroup
     int ptiles, world, rank;       // sharded path: only 128-tile columns whose panel (tj128 / ptiles) is owned
 };
@@ -761,18 +760,37 @@ update_kernel(UpdArgs a)
 //   C(row = 16 x + 4 ((b + s) & 3) + j,  col = 16 y + 4 ((b + 2 t) & 3) + i)   of the wave's 32x32 tile.
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
-template <int KC, int ROLE>
-__global__ void __launch_bounds__(256, (KC <= 8 ? 4 : 2))
+#define DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+// wait until at most N LDS operations are outstanding; ties the wait to the registers it guards
+#define WAIT_LGKM(N, P)                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                             \
+                 : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(P[5]), "+v"(P[6]), "+v"(P[7]))
+// P = { rows x=0 rot 0, rows x=0 rot 1, cols y=0 rot 0, cols y=0 rot 2, then the same for x = y = 1 }
+#define MFMA_STEP(P)                                                                     \
+    do {                                                                                 \
+        _Pragma("unroll") for (int x = 0; x < 2; ++x)                                    \
+        _Pragma("unroll") for (int y = 0; y < 2; ++y)                                    \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                    \
+            acc[x][y][s][t] = MFMA4(P[4 * y + 2 + t], P[4 * x + s], acc[x][y][s][t]);   \
+    } while (0)
+
+// The kernel: operand chunks go global -> LDS directly (global_load_lds_dwordx4, 1 KB per wave-instruction,
+// no staging registers, no ds_write) into a ring of NS stages that runs NS-1 chunks ahead; one raw
+// s_barrier per chunk, counted vmcnt waits (never 0 inside the loop).  The operand slices are read with
+// hand-placed ds_read_b64 (left to itself the compiler fuses neighbouring reads into ds_read2_b64 /
+// ds_read2st64_b64, which run at half the LDS rate) and explicit lgkmcnt waits: the eight reads of the
+// second k-step of a chunk are in flight while the sixteen instructions of the first issue.  LDS image of one operand side per stage: 8 columns x 64 rows, 512 B
+// per column, UNPADDED (a DMA instruction's 1 KB must be contiguous) and made conflict-free by an XOR
+// swizzle of bit 7 of the row byte for odd columns; the DMA realises it through its per-lane SOURCE address.
+template <int ROLE>
+__global__ void __launch_bounds__(256, 5)
 update4_kernel(UpdArgs a)
 {
-    constexpr int TM = 64;
-    constexpr int LDT = TM + 16;   // lanes l and l+16 land 128 B apart mod 256 -> conflict-free b64 reads
-    constexpr int TPC = 256 / KC;  // threads per panel column
-    constexpr int RPT = TM / TPC;  // rows staged per thread and side
+    constexpr int TM = 64, KC = 8, NS = 4;
+    constexpr unsigned SIDE_B = KC * 64 * 8, STAGE_B = 2 * SIDE_B;     // 4 KB per side, 8 KB per stage
     int ti, tj;
     if (a.lower_only) {
-        // 1-D grid over the tiles (ti >= tj) of the trapezoid, column by column: column j (0-based
-        // from tj0) holds H - j tiles and starts at j H - j (j-1)/2.  No empty workgroups.
         long long L = blockIdx.x;
         const double hh = 2.0 * a.H + 1.0;
         int j = (int)((hh - sqrt(hh * hh - 8.0 * (double)L)) * 0.5);
@@ -786,13 +804,11 @@ update4_kernel(UpdArgs a)
         tj = a.tj0 + blockIdx.y;
     }
     if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;
-    // does this workgroup's tile lie inside the diagonal block the engine is waiting for?
     const int sig_Ti = (ti * TM) / TILE - a.sig_tile, sig_Tj = (tj * TM) / TILE - a.sig_tile;
     const bool sig_wg = a.sig != nullptr && sig_Ti >= 0 && sig_Ti <= 1 && sig_Tj >= 0 && sig_Tj <= sig_Ti;
-    extern __shared__ double upd4_smem[];      // 4 * KC * LDT doubles (dynamic: KC = 32 needs 80 KB)
-    double (*sI)[KC * LDT] = (double (*)[KC * LDT])upd4_smem;
-    double (*sJ)[KC * LDT] = (double (*)[KC * LDT])(upd4_smem + 2 * KC * LDT);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ double upd4_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave & 1, wj = wave >> 1;
     if (a.wait_word) {     // operand tile comes from the engine
         int *wait_ok = (int *)upd4_smem;
@@ -805,16 +821,28 @@ update4_kernel(UpdArgs a)
     }
     unsigned long long st_c = 0, st_r = 0;
     if (a.stamp) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)upd4_smem;
 
-    // staging map: thread -> (panel column kc, RPT consecutive rows)
-    const int kc = tid / TPC, rg = (tid % TPC) * RPT;
-    const double *gI = a.P + (size_t)(ti * TM + rg) + (size_t)kc * a.ldp;
-    const double *gJ = a.P + (size_t)(tj * TM + rg) + (size_t)kc * a.ldp;
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    // two register stages: chunk c+1 (loaded one iteration ago, stored to LDS at the end of this one) and
-    // chunk c+2 (loaded now) -- the operand panels come from L2 / Infinity Cache under full load, where a
-    // load takes far longer than one chunk of MFMAs
-    d2 stI[2][RPT / 2], stJ[2][RPT / 2];
+    // DMA source: lane l of wave w fills bytes [1024 w + 16 l, +16) of a side image = column k = 2 w + (l >> 5),
+    // physical row bytes 16 (l & 31); with the swizzle that slot holds rows r, r+1, r = 2 (l & 31) ^ (16 (k & 1))
+    const int kd = 2 * wave + (lane >> 5);
+    const int rd = (2 * (lane & 31)) ^ ((lane >> 5) << 4);
+    const double *gI = a.P + (size_t)(ti * TM + rd) + (size_t)kd * a.ldp;
+    const double *gJ = a.P + (size_t)(tj * TM + rd) + (size_t)kd * a.ldp;
+    const size_t cstride = (size_t)KC * a.ldp;
+    const unsigned dma_dst = lds0 + 1024u * (unsigned)wave;
+#define GLDS16(gsrc, ldsdst)                                                                          \
+    do {                                                                                              \
+        unsigned keep_;                                                                               \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(gsrc), "s"(ldsdst) : "memory");                             \
+    } while (0)
+#define ISSUE_CHUNK(c, stage)                                                                         \
+    do {                                                                                              \
+        const double *pi_ = gI + (size_t)(c) * cstride, *pj_ = gJ + (size_t)(c) * cstride;            \
+        GLDS16(pi_, dma_dst + (unsigned)(stage) * STAGE_B);                                           \
+        GLDS16(pj_, dma_dst + (unsigned)(stage) * STAGE_B + SIDE_B);                                  \
+    } while (0)
 
     double acc[2][2][2][2];
 #pragma unroll
@@ -826,113 +854,50 @@ update4_kernel(UpdArgs a)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[x][y][s][t] = 0.0;
 
-    const int nch = a.K / KC;
+    const int nch = a.K / KC;          // a multiple of NS (K is a multiple of 128)
 #pragma unroll
-    for (int v = 0; v < RPT / 2; ++v) {
-        stI[0][v] = *(const d2 *)(gI + 2 * v);
-        stJ[0][v] = *(const d2 *)(gJ + 2 * v);
-    }
-    if (nch > 1) {
-#pragma unroll
-        for (int v = 0; v < RPT / 2; ++v) {
-            stI[1][v] = *(const d2 *)(gI + (size_t)KC * a.ldp + 2 * v);
-            stJ[1][v] = *(const d2 *)(gJ + (size_t)KC * a.ldp + 2 * v);
-        }
-    }
-#pragma unroll
-    for (int v = 0; v < RPT / 2; ++v) {
-        *(d2 *)(&sI[0][kc * LDT + rg + 2 * v]) = stI[0][v];
-        *(d2 *)(&sJ[0][kc * LDT + rg + 2 * v]) = stJ[0][v];
-    }
-    __syncthreads();
+    for (int c = 0; c < NS - 1; ++c) ISSUE_CHUNK(c, c);
 
+    // operand read addresses (bytes, stage 0): physical (row, k) = 512 k + ((8 row) ^ (128 (k & 1))), k = kq here
     const int kq = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
-    // Operand slices are read with hand-placed ds_read_b64 (the compiler fuses neighbouring reads into
-    // ds_read2_b64 / ds_read2st64_b64, which run at half the LDS rate) and explicit lgkmcnt waits: the
-    // eight reads of k-step s+1 are in flight while the sixteen instructions of k-step s issue.
-    // LDS byte addresses of this lane's element in the row / column operand images, rotation 0:
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)upd4_smem;
-    const unsigned aR0 = lds0 + 8u * (unsigned)(kq * LDT + 4 * bq + jq + (TM / 2) * wi);
-    const unsigned aR1 = lds0 + 8u * (unsigned)(kq * LDT + 4 * ((bq + 1) & 3) + jq + (TM / 2) * wi);
-    const unsigned aC0 = lds0 + 8u * (unsigned)(2 * KC * LDT + kq * LDT + 4 * bq + jq + (TM / 2) * wj);
-    const unsigned aC2 = lds0 + 8u * (unsigned)(2 * KC * LDT + kq * LDT + 4 * ((bq + 2) & 3) + jq + (TM / 2) * wj);
-#define DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-    // issue the eight operand reads of k-step S4 of buffer half `bo` (byte offset of the buffer)
-#define ISSUE_STEP(P, bo, S4)                                                            \
-    do {                                                                                 \
-        const unsigned o_ = (bo);                                                        \
-        DSR64(P[0], aR0 + o_, (S4) * 4 * LDT * 8);                                       \
-        DSR64(P[1], aR1 + o_, (S4) * 4 * LDT * 8);                                       \
-        DSR64(P[2], aC0 + o_, (S4) * 4 * LDT * 8);                                       \
-        DSR64(P[3], aC2 + o_, (S4) * 4 * LDT * 8);                                       \
-        DSR64(P[4], aR0 + o_, (S4) * 4 * LDT * 8 + 128);                                 \
-        DSR64(P[5], aR1 + o_, (S4) * 4 * LDT * 8 + 128);                                 \
-        DSR64(P[6], aC0 + o_, (S4) * 4 * LDT * 8 + 128);                                 \
-        DSR64(P[7], aC2 + o_, (S4) * 4 * LDT * 8 + 128);                                 \
-    } while (0)
-    // wait until at most N LDS operations are outstanding; ties the wait to the registers it guards
-#define WAIT_LGKM(N, P)                                                                  \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                             \
-                 : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(P[5]), "+v"(P[6]), "+v"(P[7]))
+    const unsigned sw = (unsigned)(kq & 1) << 7;
+    unsigned aP[8];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        aP[4 * x + 0] = lds0 + 512u * kq + ((8u * (unsigned)(32 * wi + 16 * x + 4 * bq + jq)) ^ sw);
+        aP[4 * x + 1] = lds0 + 512u * kq + ((8u * (unsigned)(32 * wi + 16 * x + 4 * ((bq + 1) & 3) + jq)) ^ sw);
+        aP[4 * x + 2] = lds0 + SIDE_B + 512u * kq + ((8u * (unsigned)(32 * wj + 16 * x + 4 * bq + jq)) ^ sw);
+        aP[4 * x + 3] = lds0 + SIDE_B + 512u * kq + ((8u * (unsigned)(32 * wj + 16 * x + 4 * ((bq + 2) & 3) + jq)) ^ sw);
+    }
     // P = { rows x=0 rot 0, rows x=0 rot 1, cols y=0 rot 0, cols y=0 rot 2, then the same for x = y = 1 }
-#define MFMA_STEP(P)                                                                     \
-    do {                                                                                 \
-        _Pragma("unroll") for (int x = 0; x < 2; ++x)                                    \
-        _Pragma("unroll") for (int y = 0; y < 2; ++y)                                    \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                    \
-            acc[x][y][s][t] = MFMA4(P[4 * y + 2 + t], P[4 * x + s], acc[x][y][s][t]);   \
+#define ISSUE_STEP_D(P, stage, S4)                                                                    \
+    do {                                                                                              \
+        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                              \
+            DSR64(P[q_], aP[q_], (stage) * STAGE_B + (S4) * 2048);                                    \
     } while (0)
-    // the loop body handles two chunks so that the register stages have static indices
-    auto chunk = [&](int ch, d2 (&nI)[RPT / 2], d2 (&nJ)[RPT / 2], d2 (&fI)[RPT / 2], d2 (&fJ)[RPT / 2]) {
-        // nI/nJ: chunk ch+1, already in flight; fI/fJ: receives chunk ch+2
-        const int cur = ch & 1;
-        const unsigned bo = (unsigned)cur * (unsigned)(KC * LDT * 8);
-        double PA[8], PB[8];
-        ISSUE_STEP(PA, bo, 0);
-        if (ch + 2 < nch && !(a.dbg & 3)) {
-            const double *pI = gI + (size_t)(ch + 2) * KC * a.ldp;
-            const double *pJ = gJ + (size_t)(ch + 2) * KC * a.ldp;
+    for (int c0 = 0; c0 < nch; c0 += NS) {
 #pragma unroll
-            for (int v = 0; v < RPT / 2; ++v) {
-                fI[v] = *(const d2 *)(pI + 2 * v);
-                fJ[v] = *(const d2 *)(pJ + 2 * v);
-            }
-        }
-#pragma unroll
-        for (int s4 = 0; s4 < KC / 4; s4 += 2) {
-            ISSUE_STEP(PB, bo, s4 + 1);
+        for (int st = 0; st < NS; ++st) {
+            const int c = c0 + st;
+            // chunk c has landed once at most 2 * min(chunks issued after it, NS - 2) DMA instructions are outstanding
+            const int rem = nch - 1 - c;
+            if (rem >= NS - 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c + NS - 1 < nch) ISSUE_CHUNK(c + NS - 1, (st + NS - 1) % NS);
+            double PA[8], PB[8];
+            ISSUE_STEP_D(PA, st, 0);
+            ISSUE_STEP_D(PB, st, 1);
             WAIT_LGKM(8, PA);
             MFMA_STEP(PA);
-            // (the last accumulator of the step above is tied in so that the compiler keeps this wait
-            // behind all sixteen instructions of that step)
-            if (s4 + 2 < KC / 4) {
-                ISSUE_STEP(PA, bo, s4 + 2);
-                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(PB[0]), "+v"(PB[1]), "+v"(PB[2]), "+v"(PB[3]), "+v"(PB[4]),
-                             "+v"(PB[5]), "+v"(PB[6]), "+v"(PB[7]), "+v"(acc[1][1][1][1]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(PB[0]), "+v"(PB[1]), "+v"(PB[2]), "+v"(PB[3]), "+v"(PB[4]),
-                             "+v"(PB[5]), "+v"(PB[6]), "+v"(PB[7]), "+v"(acc[1][1][1][1]));
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(PB[0]), "+v"(PB[1]), "+v"(PB[2]), "+v"(PB[3]), "+v"(PB[4]),
+                         "+v"(PB[5]), "+v"(PB[6]), "+v"(PB[7]), "+v"(acc[1][1][1][1]));
             MFMA_STEP(PB);
         }
-        if (ch + 1 < nch && !(a.dbg & 3)) {
-#pragma unroll
-            for (int v = 0; v < RPT / 2; ++v) {
-                *(d2 *)(&sI[cur ^ 1][kc * LDT + rg + 2 * v]) = nI[v];
-                *(d2 *)(&sJ[cur ^ 1][kc * LDT + rg + 2 * v]) = nJ[v];
-            }
-        }
-        __syncthreads();
-    };
-    for (int ch = 0; ch < nch; ch += 2) {
-        chunk(ch, stI[1], stJ[1], stI[0], stJ[0]);
-        if (ch + 1 < nch) chunk(ch + 1, stI[0], stJ[0], stI[1], stJ[1]);
     }
-    // C -= acc: all sixteen loads first, then the stores (written as `*p -= acc` the compiler must assume
-    // that a store aliases the next load and serialises sixteen memory round trips)
+    // C -= acc: all sixteen loads first, then the stores
     double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi + jq) + (size_t)(tj * TM + (TM / 2) * wj + kq) * a.ldc;
-    if ((a.dbg & 2) && acc[0][0][0][0] != 12345.678) return;
     double cv[2][2][2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -950,8 +915,7 @@ update4_kernel(UpdArgs a)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-                {
+                for (int t = 0; t < 2; ++t) {
                     double *p = Cb + (16 * x + 4 * ((bq + s) & 3)) + (size_t)(16 * y + 4 * ((bq + 2 * t) & 3)) * a.ldc;
                     if (sig_wg) store_wt(p, cv[x][y][s][t] - acc[x][y][s][t]); else *p = cv[x][y][s][t] - acc[x][y][s][t];
                 }
@@ -1144,7 +1108,6 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     a.sig = sig; a.sig_tile = sig_tile;
     a.wait_word = wait_word; a.abort_word = abort_word;
     a.stamp = upd_stamp_buffer();
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("COCONS_UPD_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     static int swz = -1;
     if (swz < 0) { const char *e = getenv("COCONS_XCD_SWIZZLE"); swz = e ? atoi(e) : 0; }
     a.xcd_swizzle = swz;
@@ -1164,23 +1127,17 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     }
     const bool trailing = (K >= 2 * TILE) && world == 1;
     // default: the 16x16x4 kernel (8 waves per SIMD, pipe-bound at the instruction's 48.7 TFLOP/s).
-    // COCONS_UPD_MFMA4=1 selects the 4x4x4 kernel: its instruction peaks at 76 TFLOP/s but the kernel
-    // around it (LDS feed, staging, 5 waves per SIMD) does not beat the default yet
+    // COCONS_UPD_MFMA4=1 selects the 4x4x4 kernel: its instruction peaks at 76 TFLOP/s, but at a 32x32
+    // tile per wave, one barrier per 32 instructions and 5 waves per SIMD the kernel around it lands
+    // where the default does (what it needs next)
     static int form4 = -1;
     if (form4 < 0) { const char *e = getenv("COCONS_UPD_MFMA4"); form4 = e ? atoi(e) : 0; }
     if (!form4) {
         if (trailing) hipLaunchKernelGGL((update_kernel<64, 8, 0>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((update_kernel<64, 8, 1>), grid, dim3(256), 0, s, a);
     } else {
-        static int kc = -1;     // COCONS_UPD_KC: K-chunk of the 4x4x4 kernel (8, 16, 32)
-        if (kc < 0) { const char *e = getenv("COCONS_UPD_KC"); kc = e ? atoi(e) : 8; }
-        const size_t shm8 = 4 * 8 * 80 * sizeof(double);
-        if (!trailing) hipLaunchKernelGGL((update4_kernel<8, 1>), grid, dim3(256), shm8, s, a);
-        else if (kc == 32) {
-            (void)hipFuncSetAttribute((const void *)update4_kernel<32, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * shm8));
-            hipLaunchKernelGGL((update4_kernel<32, 0>), grid, dim3(256), 4 * shm8, s, a);
-        } else if (kc == 16) hipLaunchKernelGGL((update4_kernel<16, 0>), grid, dim3(256), 2 * shm8, s, a);
-        else hipLaunchKernelGGL((update4_kernel<8, 0>), grid, dim3(256), shm8, s, a);
+        if (trailing) hipLaunchKernelGGL((update4_kernel<0>), grid, dim3(256), 4 * 8192, s, a);
+        else hipLaunchKernelGGL((update4_kernel<1>), grid, dim3(256), 4 * 8192, s, a);
     }
 }
 
@@ -1297,68 +1254,6 @@ mfma_f64_probe_ex_kernel(double *out, unsigned long long *stamp, int iters, doub
     if (threadIdx.x == 0) { stamp[2 * blockIdx.x] = c1 - c0; stamp[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-// FORM 2: the inner loop of update4_kernel without its global traffic and barriers: per k-step of 4,
-// eight ds_read_b64 operand slices feed sixteen 4x4x4 instructions (operands re-read from an LDS image)
-__global__ void __launch_bounds__(256)
-mfma4_lds_probe_kernel(double *out, unsigned long long *stamp, int iters, double seed)
-{
-    constexpr int LDT = 80, KC = 8;
-    __shared__ double sI[KC * LDT], sJ[KC * LDT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < KC * LDT; e += 256) { sI[e] = seed + e * 1e-4; sJ[e] = seed - e * 1e-4; }
-    __syncthreads();
-    const int wi = wave & 1, wj = wave >> 1;
-    const int kq = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
-    const int roR0 = kq * LDT + 4 * bq + jq + 32 * wi, roR1 = kq * LDT + 4 * ((bq + 1) & 3) + jq + 32 * wi;
-    const int roC0 = kq * LDT + 4 * bq + jq + 32 * wj, roC2 = kq * LDT + 4 * ((bq + 2) & 3) + jq + 32 * wj;
-    double acc[2][2][2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc[x][y][s][t] = 0.0;
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int it = 0; it < iters; ++it) {
-        const double *bI = sI, *bJ = sJ;
-        asm volatile("" : "+v"(bI), "+v"(bJ));      // keep the reads inside the loop
-#pragma unroll
-        for (int s4 = 0; s4 < KC / 4; ++s4) {
-            double pr[2][2], pc[2][2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                pr[x][0] = bI[s4 * 4 * LDT + 16 * x + roR0];
-                pr[x][1] = bI[s4 * 4 * LDT + 16 * x + roR1];
-                pc[x][0] = bJ[s4 * 4 * LDT + 16 * x + roC0];
-                pc[x][1] = bJ[s4 * 4 * LDT + 16 * x + roC2];
-            }
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            acc[x][y][s][t] = MFMA4(pc[y][t], pr[x][s], acc[x][y][s][t]);
-        }
-    }
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    double res = 0.0;
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) res += acc[x][y][s][t];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = res;
-    if (threadIdx.x == 0) { stamp[2 * blockIdx.x] = c1 - c0; stamp[2 * blockIdx.x + 1] = r1 - r0; }
-}
-
 // FORM 3: sixteen accumulators fed from four + four DISTINCT operand registers (no LDS traffic): tells
 // operand-register switching apart from the LDS feed
 __global__ void __launch_bounds__(256)
@@ -1415,28 +1310,6 @@ __global__ void idle_kernel(unsigned long long ticks)
     while (__builtin_amdgcn_s_memrealtime() - r0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
-// diagnostic: a resident do-nothing workgroup of the engine's shape (does mere residency of a second
-// kernel slow the trailing update?)
-__global__ void __launch_bounds__(512) dummy_resident_kernel(unsigned long long ticks, int mode, unsigned *word)
-{
-    extern __shared__ double smem[];
-    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) {
-        while (__builtin_amdgcn_s_memrealtime() - r0 < ticks) {
-            if (mode == 1) (void)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_s_sleep(16);
-        }
-        smem[0] = 1.0;
-    }
-    __syncthreads();
-}
-
-void launch_dummy_resident(hipStream_t s, int threads, size_t lds, double ms, int mode, unsigned *word)
-{
-    (void)hipFuncSetAttribute((const void *)dummy_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dummy_resident_kernel, dim3(1), dim3(threads), lds, s, (unsigned long long)(ms * 1e5), mode, word);
-}
-
 template <int NACC, int FORM>
 static void launch_probe_ex(int blocks, double *dbuf, unsigned long long *stamp, int iters, hipStream_t s)
 {
@@ -1456,9 +1329,7 @@ int run_mfma_f64_probe_ex(int blocks, int nacc, int form, int iters, int gap_us,
     hipMalloc(&dbuf, (size_t)blocks * 256 * sizeof(double));
     hipMalloc(&dst, (size_t)blocks * 2 * sizeof(unsigned long long));
     auto burst = [&]() {
-        if (form == 2) {     // nacc is fixed at 16, iters counts k-steps of 8 (32 instructions)
-            hipLaunchKernelGGL(mfma4_lds_probe_kernel, dim3(blocks), dim3(256), 0, s, dbuf, dst, iters, 1.0);
-        } else if (form == 3) {
+        if (form == 3) {     // nacc is fixed at 16, iters counts groups of 32 instructions
             hipLaunchKernelGGL(mfma4_regs_probe_kernel, dim3(blocks), dim3(256), 0, s, dbuf, dst, iters, 1.0);
         } else if (form == 0) {
             if (nacc == 4) launch_probe_ex<4, 0>(blocks, dbuf, dst, iters, s);
@@ -1492,12 +1363,12 @@ int run_mfma_f64_probe_ex(int blocks, int nacc, int form, int iters, int gap_us,
     std::vector<double> clk(blocks), cyc(blocks);
     for (int b = 0; b < blocks; ++b) {
         clk[b] = (double)st[2 * b] / (double)st[2 * b + 1] * 0.1;      // cycles per 10 ns -> GHz
-        cyc[b] = (double)st[2 * b] / ((double)iters * (form >= 2 ? 32 : nacc));
+        cyc[b] = (double)st[2 * b] / ((double)iters * (form == 3 ? 32 : nacc));
     }
     std::sort(clk.begin(), clk.end());
     std::sort(cyc.begin(), cyc.end());
     const double flop_per = form == 0 ? 2048.0 : 512.0;
-    const double flops = (double)blocks * 4.0 * (double)iters * (form >= 2 ? 32 : nacc) * flop_per;
+    const double flops = (double)blocks * 4.0 * (double)iters * (form == 3 ? 32 : nacc) * flop_per;
     out[0] = flops / (ms_sum / reps * 1e-3) / 1e12;
     out[1] = clk[blocks / 2];
     out[2] = cyc[blocks / 2];

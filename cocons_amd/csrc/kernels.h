@@ -136,7 +136,6 @@ void launch_trmm_lower(const double *A, size_t lda, int n, const double *E, int 
 // fp64 MFMA issue-rate probe (TFLOP/s); dbuf must hold blocks*256 doubles
 double run_mfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf);
 double run_vfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf);
-void launch_dummy_resident(hipStream_t s, int threads, size_t lds, double ms, int mode, unsigned *word);
 int run_mfma_f64_probe_ex(int blocks, int nacc, int form, int iters, int gap_us, int reps, double *out);
 void run_corun_probe(int blocks_mfma, int blocks_vfma, int iters_mfma, int iters_vfma, double *dbuf, double *out);
 

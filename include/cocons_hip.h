@@ -183,7 +183,8 @@ int cocons_fit_profile(cocons_fit *fit, const double *theta, const double *mean,
  * for the roofline peak the update kernel is priced against. */
 int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops);
 /* Extended probe: nacc (4 / 8 / 16) independent accumulators per wave, form 0 = v_mfma_f64_16x16x4_f64,
- * 1 = v_mfma_f64_4x4x4_4b_f64; `reps` bursts of `iters` loop iterations separated by idle gaps of gap_us
+ * 1 = v_mfma_f64_4x4x4_4b_f64, 3 = the 4x4x4 form with sixteen accumulators fed from eight DISTINCT operand
+ * registers (nacc ignored); `reps` bursts of `iters` loop iterations separated by idle gaps of gap_us
  * (0 = back to back).  out4[0] = TFLOP/s inside the bursts, [1] = clock the chip held inside the kernel
  * in GHz (s_memtime / s_memrealtime), [2] = shader cycles per MFMA instruction per wave, [3] = mean
  * burst duration in ms.  Tells issue rate per clock apart from the clock the chip sustains under load. */
