@@ -566,3 +566,24 @@ def test_cov_rows_and_cor_rows(oracle):
     t2["smooth"] = np.zeros(3)
     fit2 = ca.CoconsFit(locs, X, rng.standard_normal(n), (1.5, 1.5))
     assert _relerr(fit2.cov_rows(t2, idx), oracle.cov_rns(t2, locs, X, (1.5, 1.5))[idx]) < ENTRY_RTOL
+
+
+def test_device_matern_large_argument_branch_vs_mpmath():
+    """The device routine's large-argument branch (Hankel series, u >= 20) and the CF2 branch next to it
+    against 40-digit mpmath at 1500 random (nu, u), u in [15, 60] and [60, 700], nu in [0.25, 3.5]."""
+    import mpmath as mp
+    from cocons_amd import _lib
+    mp.mp.dps = 40
+    rng = np.random.default_rng(77)
+    nu = rng.uniform(0.25, 3.5, 1500)
+    u = np.concatenate([rng.uniform(15.0, 60.0, 1000), rng.uniform(60.0, 700.0, 500)])
+    u[:6] = [19.999999, 20.0, 20.000001, 20.5, 24.0, 32.0]
+    want = np.array([float(mp.power(2, 1 - mp.mpf(a)) / mp.gamma(mp.mpf(a)) * mp.power(mp.mpf(b), mp.mpf(a)) *
+                           mp.besselk(mp.mpf(a), mp.mpf(b))) for a, b in zip(nu, u)])
+    out = np.empty_like(u)
+    L = _lib.load()
+    _lib.check(L.cocons_debug_matern(u.size, nu.ctypes.data_as(_lib.c_dp), u.ctypes.data_as(_lib.c_dp),
+                                     out.ctypes.data_as(_lib.c_dp)), "cocons_debug_matern")
+    ok = want > 1e-290
+    rel = np.abs(out[ok] - want[ok]) / want[ok]
+    assert rel.max() < 1e-13, (rel.max(), nu[ok][rel.argmax()], u[ok][rel.argmax()])
