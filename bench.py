@@ -43,8 +43,8 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (= fp64 vector peak): 256 CU x 4 SIMD
 #                                  x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 issues every 64 cycles
-MFMA_F64_16x16x4_TFLOPS = 48.7   # what the instruction the update kernel is built on sustains chip-wide (tools/
-#                                  probe_mfma_ex.py: one per ~102 cycles per SIMD at 2.37 GHz, no throttling)
+PIPE_BUSY_PMC = 0.714            # matrix pipe busy fraction of the update kernel over one evaluation (rocprofv3 --pmc,
+#                                  profiles/r02_update_kernel_mfma_util.json); the rest of achieved/peak is the clock
 TRAFFIC_PROFILE = "r02_update_kernel_hbm_traffic.json"
 
 
@@ -300,11 +300,10 @@ def main():
                         "measured_in": "this run (HIP events around each launch on the launch stream)",
                         "flops_per_launch": flops / max(launches, 1),
                         "launch_ms": round(st["update_avg_ms"], 4), "launches_per_eval": launches,
-                        "instruction_ceiling_tflops": MFMA_F64_16x16x4_TFLOPS,
-                        "frac_of_instruction_ceiling": round(achieved / MFMA_F64_16x16x4_TFLOPS, 4),
-                        "instruction_ceiling_source": "tools/probe_mfma_ex.py on MI355X (profiles/r02_mfma_f64_probe.json): "
-                                                      "v_mfma_f64_16x16x4_f64 48.7 TFLOP/s, v_mfma_f64_4x4x4_4b_f64 76.2, "
-                                                      "both at an unthrottled 2.37 GHz",
+                        "pipe_busy_frac_pmc": PIPE_BUSY_PMC,
+                        "pipe_busy_source": "NOT measured in this run: profiles/r02_update_kernel_mfma_util.json "
+                                            "(SQ_VALU_MFMA_BUSY_CYCLES over SIMD cycles, all 39 launches, plain schedule); "
+                                            "bare-instruction probes in profiles/r02_mfma_f64_probe.json",
                         "traffic": None}
             tr = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
             if n == 10000 and os.path.exists(tr):

@@ -743,10 +743,12 @@ update_kernel(UpdArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// Trailing update on v_mfma_f64_4x4x4_4b_f64.  Measured on MI355X (tools/probe_mfma_ex.py): the
-// 16x16x4 fp64 form sustains one instruction per ~102 cycles per SIMD (48.7 TFLOP/s chip-wide, 62 % of
-// the 78.6 peak, at an unthrottled 2.37 GHz), the 4x4x4 four-block form one per 16 cycles
-// (76.2 TFLOP/s, 97 %).  The four-block form multiplies, per block b, a 4x4 slice of each operand:
+// Trailing update on v_mfma_f64_4x4x4_4b_f64 -- an ALTERNATIVE to update_kernel kept for comparison
+// (COCONS_UPD_MFMA4=1).  Both fp64 MFMA forms have the same nominal rate (2048 flop / 64 pipe cycles =
+// 512 / 16); issued back to back the 16x16x4 form sustains only 48.7 TFLOP/s chip-wide and the 4x4x4 form
+// 76.2 (tools/probe_mfma_ex.py), but inside a real kernel, interleaved across 8 waves per SIMD, the 16x16x4
+// form keeps the pipe as busy (72 %) as this kernel does (71 %): the instruction is not what limits either
+// (DESIGN.md section 8).  The four-block form multiplies, per block b, a 4x4 slice of each operand:
 //   D[lane 16 i + 4 b + j] += sum_k A[lane 16 k + 4 b + i] * B[lane 16 k + 4 b + j]
 // (mapping determined with one-hot operands, tools/diag/mfma4_layout.hip), i.e. of the 16 x 16 outer
 // product of two 16-row operand slices it delivers only the four diagonal 4x4 blocks.  The other twelve
