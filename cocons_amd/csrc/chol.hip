@@ -584,7 +584,6 @@ struct UpdArgs {
     int K;
     int ti0, tj0, lower_only;      // tile indices in units of TM
     int H;                         // lower_only: rows of the trapezoid (ti1 - tj0), 1-D grid over its tiles
-    int xcd_swizzle;
     unsigned *sig; int sig_tile;   // engine hand-off: workgroups inside the diagonal block (tiles sig_tile, sig_tile+1)
                                    // add 1 to sig[sig_tile] (tile (t,t)) or sig[sig_tile+1] (tiles (t+1,t), (t+1,t+1))
     unsigned *wait_word, *abort_word;  // engine hand-off: every workgroup first waits for *wait_word >= 1
@@ -607,14 +606,6 @@ update_kernel(UpdArgs a)
         // 1-D grid over the tiles (ti >= tj) of the trapezoid, column by column: column j (0-based
         // from tj0) holds H - j tiles and starts at j H - j (j-1)/2.  No empty workgroups.
         long long L = blockIdx.x;
-        if (a.xcd_swizzle) {
-            // workgroups b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous
-            // run of the tile order so that neighbouring tiles (same operand panels) share an L2
-            const long long G = gridDim.x, per = G / 8, rem = G % 8;
-            const long long x = L % 8, q = L / 8;
-            // XCD x owns [start_x, start_x + per + (x < rem)) of the tile order
-            L = x * per + (x < rem ? x : rem) + q;
-        }
         const double hh = 2.0 * a.H + 1.0;
         int j = (int)((hh - sqrt(hh * hh - 8.0 * (double)L)) * 0.5);
         while (j > 0 && (long long)j * a.H - (long long)j * (j - 1) / 2 > L) --j;
@@ -1110,9 +1101,6 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     a.sig = sig; a.sig_tile = sig_tile;
     a.wait_word = wait_word; a.abort_word = abort_word;
     a.stamp = upd_stamp_buffer();
-    static int swz = -1;
-    if (swz < 0) { const char *e = getenv("COCONS_XCD_SWIZZLE"); swz = e ? atoi(e) : 0; }
-    a.xcd_swizzle = swz;
     a.H = 0;
     // 64 x 64 tiles throughout (the 128 x 128 shape measured 31 TFLOP/s against 50): tile indices in
     // units of 64 from here on

@@ -587,3 +587,18 @@ def test_device_matern_large_argument_branch_vs_mpmath():
     ok = want > 1e-290
     rel = np.abs(out[ok] - want[ok]) / want[ok]
     assert rel.max() < 1e-13, (rel.max(), nu[ok][rel.argmax()], u[ok][rel.argmax()])
+
+
+def test_alternative_update_kernel_in_subprocess():
+    """The 4x4x4-MFMA trailing-update kernel (COCONS_UPD_MFMA4=1, an alternative kept beside the default)
+    through the same parity checks as the default: Cholesky vs long-double truth and -2 loglik vs the CPU
+    path, in a fresh process (the selector is read once per process)."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env["COCONS_UPD_MFMA4"] = "1"
+    here = os.path.abspath(__file__)
+    rc = subprocess.call([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-k",
+                          "chol_solve_vs_long_double or neg2loglik_vs_cpu or ragged_sizes"], env=env,
+                         cwd=os.path.dirname(os.path.dirname(here)))
+    assert rc == 0
