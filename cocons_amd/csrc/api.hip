@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -1841,6 +1842,13 @@ extern "C" cocons_multi *cocons_multi_create(int n, int p, int r, const double *
         if (!f) { cocons_multi_destroy(m); return nullptr; }
         m->fits.push_back(f);
     }
+    // a device listed twice (tests on a one-GPU box) cannot carry an RCCL communicator: such a handle serves
+    // the entry points that need no collective (cocons_multi_predict_dense) and refuses the sharded objective
+    bool distinct = true;
+    for (int a = 0; a < ndev; ++a)
+        for (int b = a + 1; b < ndev; ++b)
+            if (devices[a] == devices[b]) distinct = false;
+    if (!distinct) return m;
     m->comms.assign(ndev, nullptr);
     (void)hipGetLastError();
     ncclResult_t nr = R->CommInitAll(m->comms.data(), ndev, devices);
@@ -1865,6 +1873,7 @@ extern "C" int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *thet
                                              double *sum_logliks, double *parts)
 {
     if (!m || !theta || !mean || !sum_logliks) return fail(-1, "cocons_multi_neg2loglik_dense: null argument");
+    if (m->comms.empty()) return fail(-1, "cocons_multi_neg2loglik_dense: this handle has no communicator (a device is listed twice)");
     RcclApi *R = rccl_api();
     if (!R) return -1;
     const int W = m->ndev;
@@ -1917,6 +1926,40 @@ extern "C" int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *thet
     }
     if (parts) parts[0] = tot[0];
     *sum_logliks = total;
+    return 0;
+}
+
+// Dense kriging with the m prediction locations split over the devices of the handle (BASELINE config C5:
+// the right-hand sides shard): every device factors Sigma with its own slice of the
+// cross-covariance rows as border -- no exchange at all -- and the slices are concatenated on the host.
+// Outputs as cocons_predict_dense.  One host thread per device issues that device's call.
+extern "C" int cocons_multi_predict_dense(cocons_multi *m, const double *theta, const double *mean, int z_col,
+                                          int mp, const double *locs_pred, const double *X_pred,
+                                          double *stochastic, double *quadform)
+{
+    if (!m || !theta || !mean || mp <= 0 || !locs_pred || !X_pred || !stochastic || !quadform)
+        return fail(-1, "cocons_multi_predict_dense: bad argument");
+    const int W = m->ndev, p = m->fits[0]->p;
+    std::vector<int> rcs(W, 0);
+    std::vector<std::string> errs(W);
+    std::vector<std::thread> th;
+    for (int d = 0; d < W; ++d) {
+        const int lo = (int)((long long)mp * d / W), hi = (int)((long long)mp * (d + 1) / W);
+        if (hi <= lo) continue;
+        th.emplace_back([=, &rcs, &errs]() {
+            const int k = hi - lo;
+            std::vector<double> lp((size_t)2 * k), Xp((size_t)p * k);       // column-major slices
+            for (int c = 0; c < 2; ++c)
+                for (int i = 0; i < k; ++i) lp[(size_t)i + (size_t)c * k] = locs_pred[(size_t)(lo + i) + (size_t)c * mp];
+            for (int c = 0; c < p; ++c)
+                for (int i = 0; i < k; ++i) Xp[(size_t)i + (size_t)c * k] = X_pred[(size_t)(lo + i) + (size_t)c * mp];
+            rcs[d] = cocons_predict_dense(m->fits[d], theta, mean, z_col, k, lp.data(), Xp.data(), stochastic + lo, quadform + lo);
+            if (rcs[d] != 0) errs[d] = g_err;          // g_err is thread-local
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int d = 0; d < W; ++d)
+        if (rcs[d] != 0) { g_err = errs[d]; return rcs[d]; }
     return 0;
 }
 

@@ -150,6 +150,18 @@ class MultiFit:
                    "cocons_multi_neg2loglik_dense")
         return val.value, parts
 
+    def predict_core(self, theta_list, locs_pred, x_covariates_pred, z_col=0):
+        """(stochastic, quadform) of cocoPredict's dense core, the prediction locations split over the devices."""
+        T = theta_table(theta_list)
+        mean = np.ascontiguousarray(np.asarray(theta_list["mean"], dtype=np.float64))
+        lp = np.asfortranarray(np.asarray(locs_pred, dtype=np.float64))
+        Xp = np.asfortranarray(np.asarray(x_covariates_pred, dtype=np.float64))
+        m = Xp.shape[0]
+        st, qf = np.empty(m), np.empty(m)
+        _lib.check(self._L.cocons_multi_predict_dense(self._h, _p(T), _p(mean), int(z_col), m, _p(lp), _p(Xp),
+                                                      _p(st), _p(qf)), "cocons_multi_predict_dense")
+        return st, qf
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.cocons_multi_destroy(self._h)

@@ -102,3 +102,10 @@ GetNeg2loglikelihoodREML <- function(theta, par.pos, locs, x_covariates, x_betas
 # one R process, several GPUs: Sigma row blocks sharded over `devices`, RCCL inside the library
 cocons_hip_multi <- function(locs, x_covariates, z, smooth.limits, devices)
   .Call(`_cocons_hip_multi_create`, locs, x_covariates, as.matrix(z), as.double(smooth.limits), as.integer(devices))
+
+# cocoPredict's dense core with the prediction locations split over the GPUs of a multi handle (config C5)
+cocons_hip_multi_predict <- function(m, theta_list, newlocs, X_pred, z_col = 1L) {
+  res <- .Call(`_cocons_hip_multi_predict`, m, theta_list[-1], theta_list$mean, as.integer(z_col), newlocs, X_pred)
+  if (res[[1]] > 0L) stop("Cholesky error")
+  res[[2]]
+}

@@ -365,6 +365,23 @@ SEXP _cocons_hip_multi_neg2loglik(SEXP mp, SEXP theta, SEXP mean)
     return status_value(rc, Rf_ScalarReal(val));
 }
 
+/* dense kriging core with the prediction locations split over the handle's GPUs: list(status, cbind(stochastic, quadform)) */
+SEXP _cocons_hip_multi_predict(SEXP mp, SEXP theta, SEXP mean, SEXP z_col, SEXP locs_pred, SEXP X_pred)
+{
+    cocons_multi *m = (cocons_multi *)R_ExternalPtrAddr(mp);
+    if (!m) Rf_error("cocons multi-GPU handle is NULL");
+    const int k = Rf_nrows(X_pred);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, fit_p(mp), T);
+    SEXP v = PROTECT(Rf_allocMatrix(REALSXP, k, 2));
+    int rc = cocons_multi_predict_dense(m, T, REAL(mean), Rf_asInteger(z_col) - 1, k, REAL(locs_pred), REAL(X_pred),
+                                        REAL(v), REAL(v) + k);
+    hip_check(rc, "cocoPredict (multi-GPU)");
+    SEXP out = status_value(rc, v);
+    UNPROTECT(1);
+    return out;
+}
+
 /* ---- registration (replaces src/RcppExports.cpp:105-118) --------------------------------------- */
 static const R_CallMethodDef CallEntries[] = {
     {"_cocons_sumsmoothlone", (DL_FUNC)&_cocons_sumsmoothlone, 3},
@@ -386,6 +403,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_cocons_hip_cov_rows", (DL_FUNC)&_cocons_hip_cov_rows, 5},
     {"_cocons_hip_multi_create", (DL_FUNC)&_cocons_hip_multi_create, 5},
     {"_cocons_hip_multi_neg2loglik", (DL_FUNC)&_cocons_hip_multi_neg2loglik, 3},
+    {"_cocons_hip_multi_predict", (DL_FUNC)&_cocons_hip_multi_predict, 6},
     {NULL, NULL, 0}
 };
 

@@ -235,6 +235,12 @@ void cocons_multi_destroy(cocons_multi *m);
 int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *theta, const double *mean,
                                   double *sum_logliks, double *parts);
 
+/* cocoPredict's dense core (cocons_predict_dense) with the m prediction locations split over the devices of
+ * the handle: no exchange, slices concatenated on the host (BASELINE config C5).                         */
+int cocons_multi_predict_dense(cocons_multi *m, const double *theta, const double *mean, int z_col,
+                               int m_pred, const double *locs_pred, const double *X_pred,
+                               double *stochastic, double *quadform);
+
 /* ---- column-panel sharded evaluation, step by step (the building blocks of the above; kept public for
  * callers that bring their own schedule, and used by the CPU tests of the schedule) --------------------
  * column-panel sharded evaluation across GPUs (one process per GPU) ---------

@@ -353,3 +353,21 @@ def test_c5_predict_split_two_ranks(tmp_path):
     st, qf = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS).predict_core(th, lp, Xp)
     assert np.max(np.abs(res[0][0] - st)) <= 1e-10 * np.max(np.abs(st))
     assert np.max(np.abs(res[0][1] - qf)) <= 1e-10 * np.max(np.abs(qf))
+
+
+def test_c5_predict_split_native_multi_handle():
+    """C5 through the one-process multi-device handle (cocons_multi_predict_dense): the device list [0, 0]
+    splits the 8192 prediction locations over two fit handles driven by two host threads (no communicator is
+    needed for this entry point); must equal the unsharded call."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    from cocons_amd.shard import MultiFit
+    locs, X, th, z, lp, Xp = _c5_problem()
+    mf = MultiFit(locs, X, z, wl.SMOOTH_LIMITS, devices=[0, 0])
+    st, qf = mf.predict_core(th, lp, Xp)
+    with pytest.raises(ca.CoconsHipError):
+        mf.neg2loglik_core(th)                 # no RCCL communicator over a repeated device
+    mf.close()
+    st1, qf1 = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS).predict_core(th, lp, Xp)
+    assert np.max(np.abs(st - st1)) <= 1e-10 * np.max(np.abs(st1))
+    assert np.max(np.abs(qf - qf1)) <= 1e-10 * np.max(np.abs(qf1))
