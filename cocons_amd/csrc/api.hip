@@ -236,9 +236,10 @@ struct cocons_fit {
     hipEvent_t ev[8];
     hipStream_t stream2;          // stream the resident diagonal-tile engine is launched on
     hipEvent_t ev_eng;            // orders the engine launch behind the reset of its flag words
-    unsigned *dflags;             // 2 * flags_cap words: in[t], out[t] (see launch_potrf_engine)
+    unsigned *dflags;             // 3 * flags_cap words in[t], out[t], xr[t] (see launch_potrf_engine) + the alive word
     int flags_cap;
     bool engine_ok;               // false: plain schedule (batch slots; or after a hand-off timed out)
+    bool engine_live;             // the engine of the NEXT factorize call is already launched (engine_start)
     // collectives of the natively sharded evaluation (see "native sharded evaluation" below)
     int coll_kind;                // 0 none, 1 RCCL communicator, 2 caller-provided transport
     int coll_rank, coll_world;
@@ -600,6 +601,35 @@ static void count_update_flops(cocons_fit *f, int kw, int t0)
     f->upd_flops += K * m * (m + 1.0) + 2.0 * K * (double)f->nrhs_cur * m;
 }
 
+// Reset the hand-off words and launch the diagonal-block engine (see factorize) for a factorisation of view
+// v on the second stream, ordered behind the reset.  The engine's 8 waves take every VGPR of a CU, so it can
+// only be placed on an EMPTY one: enqueue_eval calls this before the assembly, when the chip is idle, and
+// factorize holds the main stream behind a one-lane gate kernel until the engine reports itself resident.
+// (Launched between the assembly and the first trailing update it could lose that race and then wait for
+// a whole update to drain; with workgroups that wait for the engine on every CU it would never be placed.)
+static bool engine_wanted(cocons_fit *f, const FactorView &v) { return engine_enabled() && f->engine_ok && v.nt > 4; }
+
+static int engine_start(cocons_fit *f, const FactorView &v)
+{
+    if (f->engine_live) return 0;
+    const int nt = v.nt;
+    hipStream_t M = f->stream;
+    if (f->flags_cap < nt) {
+        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->dflags) { HIPCHK(hipFree(f->dflags)); f->dflags = nullptr; }
+        f->flags_cap = round_up(nt + 8, 64);
+        HIPCHK(hipMalloc(&f->dflags, (3 * (size_t)f->flags_cap + 64) * sizeof(unsigned)));
+    }
+    unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
+    HIPCHK(hipMemsetAsync(f->dflags, 0, (3 * (size_t)f->flags_cap + 64) * sizeof(unsigned), M));
+    HIPCHK(hipEventRecord(f->ev_eng, M));
+    HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
+    launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
+                        f->dflags + 3 * (size_t)f->flags_cap, f->stream2);
+    f->engine_live = true;
+    return 0;
+}
+
 // Bordered right-looking factorisation, outer block = 2 tiles (256 columns).
 //
 // Plain schedule (COCONS_ENGINE=0, or fewer than 5 tiles), everything on the main stream:
@@ -621,7 +651,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
 {
     const int nt = v.nt, mt = v.mt;
     hipStream_t M = f->stream;
-    if (!engine_enabled() || !f->engine_ok || nt <= 4) {
+    if (!engine_wanted(f, v)) {
         for (int k = 0; k < nt; k += 2) {
             panel_ops(f, v, k, M);
             if (k + 2 < nt) {
@@ -631,18 +661,11 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         }
         return 0;
     }
-    if (f->flags_cap < nt) {
-        HIPCHK(hipStreamSynchronize(f->stream2));
-        if (f->dflags) { HIPCHK(hipFree(f->dflags)); f->dflags = nullptr; }
-        f->flags_cap = round_up(nt + 8, 64);
-        HIPCHK(hipMalloc(&f->dflags, 3 * (size_t)f->flags_cap * sizeof(unsigned)));
-    }
+    if (int rc = engine_start(f, v)) return rc;          // no-op when enqueue_eval started it before the assembly
+    f->engine_live = false;
     unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
     unsigned *abort_word = (unsigned *)(f->dinfo + 1);
-    HIPCHK(hipMemsetAsync(f->dflags, 0, 3 * (size_t)f->flags_cap * sizeof(unsigned), M));
-    HIPCHK(hipEventRecord(f->ev_eng, M));
-    HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
-    launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, abort_word, f->stream2);
+    launch_engine_gate(f->dflags + 3 * (size_t)f->flags_cap, abort_word, M);
     panel_ops(f, v, 0, M);
     for (int k = 0; k + 2 < nt; k += 2) {
         const int t = k + 2;
@@ -677,6 +700,8 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
     if (int rc = fit_alloc_matrix(f, nrhs)) return rc;
     if (stage_events) hipEventRecord(f->ev[0], f->stream);
     if (int rc = reset_info(f)) return rc;
+    if (engine_wanted(f, main_view(f)))
+        if (int rc = engine_start(f, main_view(f))) return rc;
     assemble_sigma(f, theta, 0, 0, f->npad);
     assemble_rhs(f, mean, use_trend, xb, nxb, 0, f->npad);
     if (stage_events) hipEventRecord(f->ev[1], f->stream);
@@ -693,6 +718,10 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
 
 static int info_status(cocons_fit *f)
 {
+    // COCONS_DEBUG_ABORT=1: say which wait gave up (0x1tt / 0x2tt engine waiting for tile tt, 0x3tt panel solve
+    // waiting for the engine's tile tt, 0x5.. in-panel update, 0x600 the gate waiting for the engine to be resident)
+    if (f->hinfo[1] != 0 && getenv("COCONS_DEBUG_ABORT"))
+        fprintf(stderr, "cocons: hand-off time-out, code 0x%x\n", f->hinfo[1]);
     if (f->hinfo[1] != 0)
         return fail(ENGINE_ABORT, "hand-off between the diagonal-tile engine and the main stream timed out");
     int info = f->hinfo[0];
@@ -711,6 +740,7 @@ static bool engine_retry(cocons_fit *f, int st)
 {
     if (st != ENGINE_ABORT || !f->engine_ok) return false;
     f->engine_ok = false;
+    f->engine_live = false;
     hipStreamSynchronize(f->stream2);
     return true;
 }

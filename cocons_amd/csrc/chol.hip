@@ -405,15 +405,16 @@ __device__ __forceinline__ void signal_add(unsigned *word)
 
 // one lane; returns false on abort / timeout.  ACQUIRE = false: the caller reads the handed-off bytes with
 // load_wt only
+// code: what the abort word is set to on a time-out (who gave up: diagnostic, any non-zero value aborts)
 template <bool ACQUIRE = true>
-__device__ __forceinline__ bool wait_ge(unsigned *word, unsigned need, unsigned *abort_word)
+__device__ __forceinline__ bool wait_ge(unsigned *word, unsigned need, unsigned *abort_word, unsigned code = 1u)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
         if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
         if (__builtin_amdgcn_s_memrealtime() - t0 > ENGINE_TIMEOUT_TICKS) {
-            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(abort_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
         __builtin_amdgcn_s_sleep(16);
@@ -447,6 +448,7 @@ struct EngineArgs {
     int *info;
     unsigned *in, *out, *xr; // per-tile flag words
     unsigned *abort_word;
+    unsigned *alive;         // raised once the workgroup is resident (see engine_gate_kernel)
 };
 
 __global__ void __launch_bounds__(512)
@@ -459,8 +461,9 @@ potrf_engine_kernel(EngineArgs e)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *A = e.A;
     const size_t lda = e.lda;
+    if (tid == 0) __hip_atomic_store(e.alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int t = e.t0; t < e.nt; t += 2) {
-        if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word) ? 1 : 0;
+        if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
@@ -470,7 +473,7 @@ potrf_engine_kernel(EngineArgs e)
         if (tid == 0) signal_add(e.out + t);
         if (t + 1 >= e.nt) return;
 
-        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word) ? 1 : 0;
+        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
@@ -525,6 +528,16 @@ potrf_engine_kernel(EngineArgs e)
     }
 }
 
+// The engine needs a CU to itself (its 8 waves take every VGPR of the four SIMDs): once a chip-filling launch
+// is running, a CU only empties when that launch drains -- and never while workgroups that WAIT for the
+// engine sit on every CU.  So the main stream does not start the factorisation's launches before the
+// engine is resident: this one-lane kernel waits for its alive word (bounded like every other wait).
+__global__ void __launch_bounds__(64)
+engine_gate_kernel(unsigned *alive, unsigned *abort_word)
+{
+    if (threadIdx.x == 0) (void)wait_ge<false>(alive, 1u, abort_word, 0x600u);
+}
+
 // ---------------------------------------------------------------------------
 // Panel solve: rows [r0, r1) of block column c0:  X <- X * L(c0)^-T.
 // One workgroup = 64 rows; each wave owns a 16 x 128 strip held in registers (8 blocks).
@@ -537,7 +550,7 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsig
     __shared__ int ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wait_word) {     // the diagonal tile comes from the engine, which may still be at work
-        if (tid == 0) ok = wait_ge(wait_word, 1u, abort_word) ? 1 : 0;
+        if (tid == 0) ok = wait_ge(wait_word, 1u, abort_word, 0x300u + c0 / TILE) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (!ok) return;
@@ -627,7 +640,7 @@ update_kernel(UpdArgs a)
     const int wi = wave & 1, wj = wave >> 1;
     if (a.wait_word) {     // operand tile comes from the engine
         int *wait_ok = (int *)&sI[0][0];      // (no LDS of its own: 20,480 B is exactly an eighth of a CU's)
-        if (tid == 0) *wait_ok = wait_ge(a.wait_word, 1u, a.abort_word) ? 1 : 0;
+        if (tid == 0) *wait_ok = wait_ge(a.wait_word, 1u, a.abort_word, 0x500u + a.tj0) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int ok = *wait_ok;
@@ -805,7 +818,7 @@ update4_kernel(UpdArgs a)
     const int wi = wave & 1, wj = wave >> 1;
     if (a.wait_word) {     // operand tile comes from the engine
         int *wait_ok = (int *)upd4_smem;
-        if (tid == 0) *wait_ok = wait_ge(a.wait_word, 1u, a.abort_word) ? 1 : 0;
+        if (tid == 0) *wait_ok = wait_ge(a.wait_word, 1u, a.abort_word, 0x500u + a.tj0) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int ok = *wait_ok;
@@ -1048,13 +1061,18 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
     hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), shm, s, A, lda, c0, dinv, info);
 }
 
+void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s)
+{
+    hipLaunchKernelGGL(engine_gate_kernel, dim3(1), dim3(64), 0, s, alive, abort_word);
+}
+
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
-                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s)
+                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s)
 {
     if (t0 >= nt) return;
     EngineArgs e;
     e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
-    e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word;
+    e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive;
     // 136 KB: the 128 KB LDS copy of X plus the flag word; leaves room for ONE update workgroup beside the
     // engine.  (Asking for all 160 KB measured 7 % slower trailing updates chip-wide while the engine was
     // resident; 76 .. 152 KB did not.)

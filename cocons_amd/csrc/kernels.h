@@ -92,8 +92,10 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
 //                     dinv + (tile & 1) * 2048) is published;
 //   xr[t]    raised to 1 when X = A(t+1,t) L(t)^-T is published.
 // abort_word: set by any party whose bounded wait ran out; everybody leaves when it is non-zero.
+//   alive    raised by the engine once it is resident; launch_engine_gate(alive, ...) holds a stream until then
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
-                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s);
+                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s);
+void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s);
 // rows [r0, r1) x cols [c0, c0+128):  X <- X * L(c0)^{-T}, L read from A(c0,c0).
 // wait_word != NULL: the tile comes from the engine -- every workgroup first waits for *wait_word >= 1
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
