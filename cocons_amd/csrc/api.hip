@@ -236,7 +236,8 @@ struct cocons_fit {
     hipEvent_t ev[8];
     hipStream_t stream2;          // stream the resident diagonal-tile engine is launched on
     hipEvent_t ev_eng;            // orders the engine launch behind the reset of its flag words
-    unsigned *dflags;             // 3 * flags_cap words in[t], out[t], xr[t] (see launch_potrf_engine) + the alive word
+    unsigned *dflags;             // flags_cap words each: in[t], out[t], xr[t] (see launch_potrf_engine); 64: the alive word;
+                                  // flags_cap: tile counters of the trailing updates
     int flags_cap;
     bool engine_ok;               // false: plain schedule (batch slots; or after a hand-off timed out)
     bool engine_live;             // the engine of the NEXT factorize call is already launched (engine_start)
@@ -575,7 +576,7 @@ static bool engine_enabled()
 // one trailing-update launch (tile columns [t0, t1) of the trapezoid below (t0, t0)), optionally
 // bracketed by timing events (profile runs): appended as (start, stop)
 static void timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int t0, int t1, hipStream_t s,
-                         std::vector<hipEvent_t> *ev_upd, unsigned *sig, int sig_tile)
+                         std::vector<hipEvent_t> *ev_upd, unsigned *sig, int sig_tile, unsigned *queue = nullptr)
 {
     const int mt = v.mt;
     if (t1 <= t0) return;
@@ -583,11 +584,11 @@ static void timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int 
         hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a, s);
-        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile);
+        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, nullptr, queue);
         hipEventRecord(b, s);
         ev_upd->push_back(a); ev_upd->push_back(b);
     } else {
-        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile);
+        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, nullptr, queue);
     }
 }
 
@@ -603,25 +604,41 @@ static void count_update_flops(cocons_fit *f, int kw, int t0)
 
 // Reset the hand-off words and launch the diagonal-block engine (see factorize) for a factorisation of view
 // v on the second stream, ordered behind the reset.  The engine's 8 waves take every VGPR of a CU, so it can
-// only be placed on an EMPTY one: enqueue_eval calls this before the assembly, when the chip is idle, and
-// factorize holds the main stream behind a one-lane gate kernel until the engine reports itself resident.
+// only be placed on an EMPTY one: enqueue_eval calls this between the covariance assembly and the short
+// right-hand-side kernel, and factorize holds the main stream behind a one-lane gate kernel until the engine
+// reports itself resident.
 // (Launched between the assembly and the first trailing update it could lose that race and then wait for
 // a whole update to drain; with workgroups that wait for the engine on every CU it would never be placed.)
 static bool engine_wanted(cocons_fit *f, const FactorView &v) { return engine_enabled() && f->engine_ok && v.nt > 4; }
+
+// the hand-off words and tile counters of one factorisation with nt tiles, zeroed on the main stream
+static int flags_reset(cocons_fit *f, int nt)
+{
+    if (f->flags_cap < nt) {
+        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->dflags) { HIPCHK(hipFree(f->dflags)); f->dflags = nullptr; }
+        f->flags_cap = round_up(nt + 8, 64);
+        HIPCHK(hipMalloc(&f->dflags, (4 * (size_t)f->flags_cap + 64) * sizeof(unsigned)));
+    }
+    HIPCHK(hipMemsetAsync(f->dflags, 0, (4 * (size_t)f->flags_cap + 64) * sizeof(unsigned), f->stream));
+    return 0;
+}
+
+// one tile counter per trailing update: see update_kernel's dynamic tile order (COCONS_UPD_DYNAMIC=0: static)
+static unsigned *tile_queue(cocons_fit *f, int k)
+{
+    static int dyn = -1;
+    if (dyn < 0) { const char *e = getenv("COCONS_UPD_DYNAMIC"); dyn = e ? atoi(e) : 1; }
+    return dyn ? f->dflags + 3 * (size_t)f->flags_cap + 64 + k / 2 : nullptr;
+}
 
 static int engine_start(cocons_fit *f, const FactorView &v)
 {
     if (f->engine_live) return 0;
     const int nt = v.nt;
     hipStream_t M = f->stream;
-    if (f->flags_cap < nt) {
-        HIPCHK(hipStreamSynchronize(f->stream2));
-        if (f->dflags) { HIPCHK(hipFree(f->dflags)); f->dflags = nullptr; }
-        f->flags_cap = round_up(nt + 8, 64);
-        HIPCHK(hipMalloc(&f->dflags, (3 * (size_t)f->flags_cap + 64) * sizeof(unsigned)));
-    }
+    if (int rc = flags_reset(f, nt)) return rc;
     unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
-    HIPCHK(hipMemsetAsync(f->dflags, 0, (3 * (size_t)f->flags_cap + 64) * sizeof(unsigned), M));
     HIPCHK(hipEventRecord(f->ev_eng, M));
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
     launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
@@ -652,11 +669,12 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     const int nt = v.nt, mt = v.mt;
     hipStream_t M = f->stream;
     if (!engine_wanted(f, v)) {
+        if (int rc = flags_reset(f, nt)) return rc;
         for (int k = 0; k < nt; k += 2) {
             panel_ops(f, v, k, M);
             if (k + 2 < nt) {
                 if (ev_upd) count_update_flops(f, 2, k + 2);
-                timed_update(f, v, k, 2, k + 2, nt, M, ev_upd, nullptr, -1);
+                timed_update(f, v, k, 2, k + 2, nt, M, ev_upd, nullptr, -1, tile_queue(f, k));
             }
         }
         return 0;
@@ -672,7 +690,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         const bool two = t + 1 < nt;                 // the block has a second tile
         const int r0 = two ? t + 2 : t + 1;          // first tile row below the diagonal block
         if (ev_upd) count_update_flops(f, 2, t);
-        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t);
+        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k));
         launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, mt * TILE, f->dinv + (size_t)(t & 1) * 2048, M,
                          out + t, abort_word);
         if (two) {
@@ -700,9 +718,12 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
     if (int rc = fit_alloc_matrix(f, nrhs)) return rc;
     if (stage_events) hipEventRecord(f->ev[0], f->stream);
     if (int rc = reset_info(f)) return rc;
+    assemble_sigma(f, theta, 0, 0, f->npad);
+    // the engine becomes resident while the (short) right-hand-side kernel runs: not earlier -- a second
+    // queue with a resident kernel cuts the workgroup dispatch rate of every other launch to a quarter
+    // (tools/diag/occupancy_probe.hip), which costs the 12,000-workgroup assembly 6 % -- and not later, see engine_start
     if (engine_wanted(f, main_view(f)))
         if (int rc = engine_start(f, main_view(f))) return rc;
-    assemble_sigma(f, theta, 0, 0, f->npad);
     assemble_rhs(f, mean, use_trend, xb, nxb, 0, f->npad);
     if (stage_events) hipEventRecord(f->ev[1], f->stream);
     if (int rc = factorize(f, main_view(f), ev_upd)) return rc;
@@ -2035,22 +2056,6 @@ extern "C" int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamDestroy(ps));
     HIPCHK(hipFree(d));
-    return 0;
-}
-
-// diagnostic (COCONS_UPD_STAMP=1): out3 = {in-kernel clock of the update kernels in GHz, mean shader
-// cycles per workgroup, workgroups} since the last call; resets the counters
-extern "C" int cocons_debug_upd_clock(double *out3)
-{
-    unsigned long long *d = upd_stamp_buffer();
-    if (!d || !out3) return fail(-1, "cocons_debug_upd_clock: stamps are off (set COCONS_UPD_STAMP=1)");
-    unsigned long long h[3];
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(d, 0, sizeof h));
-    out3[0] = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
-    out3[1] = h[2] ? (double)h[0] / (double)h[2] : 0.0;
-    out3[2] = (double)h[2];
     return 0;
 }
 

@@ -596,153 +596,181 @@ struct UpdArgs {
     const double *P; size_t ldp;   // panel: element (global row, k) at P[row + k*ldp]
     int K;
     int ti0, tj0, lower_only;      // tile indices in units of TM
-    int H;                         // lower_only: rows of the trapezoid (ti1 - tj0), 1-D grid over its tiles
+    int H, W;                      // lower_only: rows / columns of the trapezoid in tiles, 1-D order over its tiles
     unsigned *sig; int sig_tile;   // engine hand-off: workgroups inside the diagonal block (tiles sig_tile, sig_tile+1)
                                    // add 1 to sig[sig_tile] (tile (t,t)) or sig[sig_tile+1] (tiles (t+1,t), (t+1,t+1))
     unsigned *wait_word, *abort_word;  // engine hand-off: every workgroup first waits for *wait_word >= 1
-    unsigned long long *stamp;     // diagnostic (COCONS_UPD_STAMP=1): += {shader cycles, 100 MHz ticks, 1} per workgroup
     int ptiles, world, rank;       // sharded path: only 128-tile columns whose panel (tj128 / ptiles) is owned
+    unsigned *queue; unsigned ntiles;  // dynamic tile order (lower_only launches): shared counter, zero at launch; tiles in all
 };
 
 // ROLE only names the instantiation (0 = trailing update, 1 = in-panel / sharded update) so that
 // profiler summaries keep the dominant trailing launches apart from the narrow ones
 template <int TM, int KC, int ROLE>
-__global__ void __launch_bounds__(256, (TM == 128 ? 2 : 8))
+__global__ void __launch_bounds__(256, 8)
 update_kernel(UpdArgs a)
 {
     constexpr int LDT = TM + 16;   // lanes l and l+16 land 128 B apart mod 256 -> conflict-free b64 reads
     constexpr int NB = TM / 32;    // 16x16 blocks per wave and dimension
     constexpr int TPC = 256 / KC;  // threads per panel column
     constexpr int RPT = TM / TPC;  // rows staged per thread and side
-    int ti, tj;
-    if (a.lower_only) {
-        // 1-D grid over the tiles (ti >= tj) of the trapezoid, column by column: column j (0-based
-        // from tj0) holds H - j tiles and starts at j H - j (j-1)/2.  No empty workgroups.
-        long long L = blockIdx.x;
-        const double hh = 2.0 * a.H + 1.0;
-        int j = (int)((hh - sqrt(hh * hh - 8.0 * (double)L)) * 0.5);
-        while (j > 0 && (long long)j * a.H - (long long)j * (j - 1) / 2 > L) --j;
-        while ((long long)(j + 1) * a.H - (long long)(j + 1) * j / 2 <= L) ++j;
-        const long long c0 = (long long)j * a.H - (long long)j * (j - 1) / 2;
-        tj = a.tj0 + j;
-        ti = a.tj0 + j + (int)(L - c0);
-    } else {
-        ti = a.ti0 + blockIdx.x;
-        tj = a.tj0 + blockIdx.y;
-    }
-    if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;
-    // does this workgroup's tile lie inside the diagonal block the engine is waiting for?
-    const int sig_Ti = (ti * TM) / TILE - a.sig_tile, sig_Tj = (tj * TM) / TILE - a.sig_tile;
-    const bool sig_wg = a.sig != nullptr && sig_Ti >= 0 && sig_Ti <= 1 && sig_Tj >= 0 && sig_Tj <= sig_Ti;
     __shared__ double sI[2][KC * LDT];
     __shared__ double sJ[2][KC * LDT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave & 1, wj = wave >> 1;
+    // (no LDS beyond the two operand rings: 20,480 B is exactly an eighth of a CU's; the word the workgroup
+    // has to share -- wait result, next tile index -- lives in the padding of the first staged column,
+    // rows TM .. LDT-1, which no staging store and no operand read touches)
+    unsigned *share = (unsigned *)&sI[0][TM];
+    const int tid = threadIdx.x;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.wait_word) {     // operand tile comes from the engine
-        int *wait_ok = (int *)&sI[0][0];      // (no LDS of its own: 20,480 B is exactly an eighth of a CU's)
-        if (tid == 0) *wait_ok = wait_ge(a.wait_word, 1u, a.abort_word, 0x500u + a.tj0) ? 1 : 0;
+        if (tid == 0) *share = wait_ge(a.wait_word, 1u, a.abort_word, 0x500u + a.tj0) ? 1u : 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int ok = *wait_ok;
+        const unsigned ok = *share;
         __syncthreads();
         if (!ok) return;
     }
-    unsigned long long st_c = 0, st_r = 0;
-    if (a.stamp) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
-
-    // staging map: thread -> (panel column kc, RPT consecutive rows)
-    const int kc = tid / TPC, rg = (tid % TPC) * RPT;
-    const double *gI = a.P + (size_t)(ti * TM + rg) + (size_t)kc * a.ldp;
-    const double *gJ = a.P + (size_t)(tj * TM + rg) + (size_t)kc * a.ldp;
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    d2 stI[RPT / 2], stJ[RPT / 2];
-
-    d4 acc[NB][NB];
-#pragma unroll
-    for (int x = 0; x < NB; ++x)
-#pragma unroll
-        for (int y = 0; y < NB; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
 
     const int nch = a.K / KC;
-#pragma unroll
-    for (int v = 0; v < RPT / 2; ++v) {
-        stI[v] = *(const d2 *)(gI + 2 * v);
-        stJ[v] = *(const d2 *)(gJ + 2 * v);
-    }
-#pragma unroll
-    for (int v = 0; v < RPT / 2; ++v) {
-        *(d2 *)(&sI[0][kc * LDT + rg + 2 * v]) = stI[v];
-        *(d2 *)(&sJ[0][kc * LDT + rg + 2 * v]) = stJ[v];
-    }
-    __syncthreads();
+    typedef double d2 __attribute__((ext_vector_type(2)));
 
-    const int ro = (lane >> 4) * LDT + (lane & 15);
-    for (int ch = 0; ch < nch; ++ch) {
-        const int cur = ch & 1;
-        if (ch + 1 < nch) {
-            const double *pI = gI + (size_t)(ch + 1) * KC * a.ldp;
-            const double *pJ = gJ + (size_t)(ch + 1) * KC * a.ldp;
-#pragma unroll
-            for (int v = 0; v < RPT / 2; ++v) {
-                stI[v] = *(const d2 *)(pI + 2 * v);
-                stJ[v] = *(const d2 *)(pJ + 2 * v);
+    // Tile index.  Static (a.queue == nullptr): the workgroup's own block index, one tile.  Dynamic: the
+    // launch has about as many workgroups as the chip holds and each takes tiles off a shared counter
+    // until it runs dry -- CUs that are slower or partly taken (the engine owns one) simply take fewer.
+    // The hardware's own placement is static round-robin over XCDs and shader engines: one CU less in one
+    // of them measured 5.5 % on the whole launch.
+    // (The first tile is the block index -- thousands of workgroups asking the one counter at the same
+    // moment cost 8 us per launch --, later ones are gridDim.x + the counter's value.)
+    unsigned L = blockIdx.x;
+    for (;;) {
+        // per-thread offsets are re-derived for every tile from a laundered thread index: hoisted out of
+        // this loop they live through it and spill (the kernel sits exactly at its 64 registers)
+        // (and the thread index itself from the wave index, kept scalar, and the lane count: no register held)
+        int lane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        const int wave = wave_s, t2 = 64 * wave + lane;
+        const int wi = wave & 1, wj = wave >> 1;
+        // staging map: thread -> (panel column kc, RPT consecutive rows)
+        const int kc = t2 / TPC, rg = (t2 % TPC) * RPT;
+        const int ro = (lane >> 4) * LDT + (lane & 15);
+        int ti, tj;
+        if (a.lower_only) {
+            // 1-D order over the tiles (ti >= tj) of the trapezoid, column by column: column j (0-based
+            // from tj0) holds H - j tiles and starts at j H - j (j-1)/2.  Bisection in integers: L is
+            // uniform, so this stays on the scalar unit.
+            int lo = 0, hi = a.W - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (mid * a.H - mid * (mid - 1) / 2 <= (int)L) lo = mid; else hi = mid - 1;
             }
+            const int j = lo;
+            tj = a.tj0 + j;
+            ti = a.tj0 + j + ((int)L - (j * a.H - j * (j - 1) / 2));
+        } else {
+            ti = a.ti0 + blockIdx.x;
+            tj = a.tj0 + blockIdx.y;
         }
-        const double *bI = &sI[cur][ro + (TM / 2) * wi];
-        const double *bJ = &sJ[cur][ro + (TM / 2) * wj];
+        if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;   // (static launches only)
+        // does this tile lie inside the diagonal block the engine is waiting for?
+        const int sig_Ti = (ti * TM) / TILE - a.sig_tile, sig_Tj = (tj * TM) / TILE - a.sig_tile;
+        const bool sig_wg = a.sig != nullptr && sig_Ti >= 0 && sig_Ti <= 1 && sig_Tj >= 0 && sig_Tj <= sig_Ti;
+
+        const double *gI = a.P + (size_t)(ti * TM + rg) + (size_t)kc * a.ldp;
+        const double *gJ = a.P + (size_t)(tj * TM + rg) + (size_t)kc * a.ldp;
+        d2 stI[RPT / 2], stJ[RPT / 2];
+
+        d4 acc[NB][NB];
 #pragma unroll
-        for (int s = 0; s < KC / 4; ++s) {
-            double pi_[NB], pj_[NB];
+        for (int x = 0; x < NB; ++x)
 #pragma unroll
-            for (int x = 0; x < NB; ++x) {
-                pi_[x] = bI[s * 4 * LDT + 16 * x];
-                pj_[x] = bJ[s * 4 * LDT + 16 * x];
-            }
+            for (int y = 0; y < NB; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+
 #pragma unroll
-            for (int x = 0; x < NB; ++x)
-#pragma unroll
-                for (int y = 0; y < NB; ++y) acc[x][y] = MFMA64(pj_[y], pi_[x], acc[x][y]);
+        for (int v = 0; v < RPT / 2; ++v) {
+            stI[v] = *(const d2 *)(gI + 2 * v);
+            stJ[v] = *(const d2 *)(gJ + 2 * v);
         }
-        if (ch + 1 < nch) {
 #pragma unroll
-            for (int v = 0; v < RPT / 2; ++v) {
-                *(d2 *)(&sI[cur ^ 1][kc * LDT + rg + 2 * v]) = stI[v];
-                *(d2 *)(&sJ[cur ^ 1][kc * LDT + rg + 2 * v]) = stJ[v];
-            }
+        for (int v = 0; v < RPT / 2; ++v) {
+            *(d2 *)(&sI[0][kc * LDT + rg + 2 * v]) = stI[v];
+            *(d2 *)(&sJ[0][kc * LDT + rg + 2 * v]) = stJ[v];
         }
         __syncthreads();
-    }
-    // C -= acc, one accumulator block (4 elements) at a time: loads first, then the stores (written as
-    // `*p -= acc` the compiler must assume that a store aliases the next load and serialises the memory
-    // round trips; all sixteen at once would cost the 8th wave per SIMD in registers)
-    double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi + (lane & 15)) +
-                 (size_t)(tj * TM + (TM / 2) * wj + (lane >> 4)) * a.ldc;
+
+        for (int ch = 0; ch < nch; ++ch) {
+            const int cur = ch & 1;
+            if (ch + 1 < nch) {
+                const double *pI = gI + (size_t)(ch + 1) * KC * a.ldp;
+                const double *pJ = gJ + (size_t)(ch + 1) * KC * a.ldp;
 #pragma unroll
-    for (int x = 0; x < NB; ++x)
-#pragma unroll
-        for (int y = 0; y < NB; ++y) {
-            double *p = Cb + 16 * x + (size_t)(16 * y) * a.ldc;
-            d4 cv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cv[r] = p[(size_t)(4 * r) * a.ldc];
-            cv -= acc[x][y];
-            if (sig_wg) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) store_wt(p + (size_t)(4 * r) * a.ldc, cv[r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p[(size_t)(4 * r) * a.ldc] = cv[r];
+                for (int v = 0; v < RPT / 2; ++v) {
+                    stI[v] = *(const d2 *)(pI + 2 * v);
+                    stJ[v] = *(const d2 *)(pJ + 2 * v);
+                }
             }
+            const double *bI = &sI[cur][ro + (TM / 2) * wi];
+            const double *bJ = &sJ[cur][ro + (TM / 2) * wj];
+#pragma unroll
+            for (int s = 0; s < KC / 4; ++s) {
+                double pi_[NB], pj_[NB];
+#pragma unroll
+                for (int x = 0; x < NB; ++x) {
+                    pi_[x] = bI[s * 4 * LDT + 16 * x];
+                    pj_[x] = bJ[s * 4 * LDT + 16 * x];
+                }
+#pragma unroll
+                for (int x = 0; x < NB; ++x)
+#pragma unroll
+                    for (int y = 0; y < NB; ++y) acc[x][y] = MFMA64(pj_[y], pi_[x], acc[x][y]);
+            }
+            if (ch + 1 < nch) {
+#pragma unroll
+                for (int v = 0; v < RPT / 2; ++v) {
+                    *(d2 *)(&sI[cur ^ 1][kc * LDT + rg + 2 * v]) = stI[v];
+                    *(d2 *)(&sJ[cur ^ 1][kc * LDT + rg + 2 * v]) = stJ[v];
+                }
+            }
+            __syncthreads();
         }
-    if (a.stamp && tid == 0) {
-        atomicAdd(a.stamp, __builtin_amdgcn_s_memtime() - st_c);
-        atomicAdd(a.stamp + 1, __builtin_amdgcn_s_memrealtime() - st_r);
-        atomicAdd(a.stamp + 2, 1ull);
-    }
-    if (sig_wg) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // next tile: asked for now (not earlier: a tile reserved while another is being worked on is a tile
+        // an idle workgroup cannot take at the end of the launch), read after the epilogue that hides the round trip
+        unsigned Lnext = 0;
+        if (a.queue && t2 == 0)
+            Lnext = gridDim.x + __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // C -= acc, one accumulator block (4 elements) at a time: loads first, then the stores (written as
+        // `*p -= acc` the compiler must assume that a store aliases the next load and serialises the memory
+        // round trips; all sixteen at once would cost the 8th wave per SIMD in registers)
+        double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi + (lane & 15)) +
+                     (size_t)(tj * TM + (TM / 2) * wj + (lane >> 4)) * a.ldc;
+#pragma unroll
+        for (int x = 0; x < NB; ++x)
+#pragma unroll
+            for (int y = 0; y < NB; ++y) {
+                double *p = Cb + 16 * x + (size_t)(16 * y) * a.ldc;
+                d4 cv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cv[r] = p[(size_t)(4 * r) * a.ldc];
+                cv -= acc[x][y];
+                if (sig_wg) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) store_wt(p + (size_t)(4 * r) * a.ldc, cv[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[(size_t)(4 * r) * a.ldc] = cv[r];
+                }
+            }
+        if (sig_wg) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t2 == 0) signal_add(a.sig + a.sig_tile + sig_Ti);
+        }
+        if (!a.queue) break;
+        if (t2 == 0) *share = Lnext;
         __syncthreads();
-        if (tid == 0) signal_add(a.sig + a.sig_tile + sig_Ti);
+        L = (unsigned)__builtin_amdgcn_readfirstlane((int)*share);     // uniform: keep the tile arithmetic scalar
+        if (L >= a.ntiles) break;
+        // (the next write to the word comes after the barriers of the next tile, which no wave passes before
+        // all have read it here)
     }
 }
 
@@ -825,8 +853,6 @@ update4_kernel(UpdArgs a)
         __syncthreads();
         if (!ok) return;
     }
-    unsigned long long st_c = 0, st_r = 0;
-    if (a.stamp) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)upd4_smem;
 
     // DMA source: lane l of wave w fills bytes [1024 w + 16 l, +16) of a side image = column k = 2 w + (l >> 5),
@@ -925,11 +951,6 @@ update4_kernel(UpdArgs a)
                     double *p = Cb + (16 * x + 4 * ((bq + s) & 3)) + (size_t)(16 * y + 4 * ((bq + 2 * t) & 3)) * a.ldc;
                     if (sig_wg) store_wt(p, cv[x][y][s][t] - acc[x][y][s][t]); else *p = cv[x][y][s][t] - acc[x][y][s][t];
                 }
-    if (a.stamp && tid == 0) {
-        atomicAdd(a.stamp, __builtin_amdgcn_s_memtime() - st_c);
-        atomicAdd(a.stamp + 1, __builtin_amdgcn_s_memrealtime() - st_r);
-        atomicAdd(a.stamp + 2, 1ull);
-    }
     if (sig_wg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1090,36 +1111,28 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
     hipLaunchKernelGGL(trsm_tile_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, dinv, wait_word, abort_word);
 }
 
-// diagnostic stamps of the update kernels (COCONS_UPD_STAMP=1): three device counters
-unsigned long long *upd_stamp_buffer()
+// COCONS_UPD_MFMA4=1 selects the 4x4x4 kernel for the updates (static tile order only)
+static bool upd_form4()
 {
-    static int on = -1;
-    static unsigned long long *buf = nullptr;
-    if (on < 0) {
-        const char *e = getenv("COCONS_UPD_STAMP");
-        on = e ? atoi(e) : 0;
-        if (on) {
-            if (hipMalloc(&buf, 4 * sizeof(unsigned long long)) != hipSuccess) { buf = nullptr; on = 0; }
-            else hipMemset(buf, 0, 4 * sizeof(unsigned long long));
-        }
-    }
-    return buf;
+    static int form4 = -1;
+    if (form4 < 0) { const char *e = getenv("COCONS_UPD_MFMA4"); form4 = e ? atoi(e) : 0; }
+    return form4 != 0;
 }
 
 void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig, int sig_tile,
-                        unsigned *wait_word, unsigned *abort_word)
+                        unsigned *wait_word, unsigned *abort_word, unsigned *queue)
 {
     if (ti1 <= ti0 || tj1 <= tj0 || K <= 0) return;
     UpdArgs a;
+    a.queue = nullptr; a.ntiles = 0;
     a.C = A; a.ldc = lda; a.P = P; a.ldp = ldp; a.K = K;
     a.lower_only = lower_only ? 1 : 0;
     a.ptiles = ptiles; a.world = world; a.rank = rank;
     a.sig = sig; a.sig_tile = sig_tile;
     a.wait_word = wait_word; a.abort_word = abort_word;
-    a.stamp = upd_stamp_buffer();
-    a.H = 0;
+    a.H = 0; a.W = 0;
     // 64 x 64 tiles throughout (the 128 x 128 shape measured 31 TFLOP/s against 50): tile indices in
     // units of 64 from here on
     a.ti0 = 2 * ti0; a.tj0 = 2 * tj0;
@@ -1129,8 +1142,25 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
         if (ti0 != tj0) { a.lower_only = 0; }    // strictly-below rectangle: every tile does work
         else {
             const long long H = 2LL * (ti1 - tj0), W = 2LL * (tj1 - tj0);
-            a.H = (int)H;
-            grid = dim3((unsigned)(W * H - W * (W - 1) / 2), 1);
+            a.H = (int)H; a.W = (int)W;
+            const long long total = W * H - W * (W - 1) / 2;
+            grid = dim3((unsigned)total, 1);
+            if (queue && world == 1 && !upd_form4()) {
+                // dynamic tile order: as many workgroups as the chip holds (8 per CU), tiles off *queue (zero now)
+                static int slots = 0;
+                if (!slots) {
+                    int dev = 0, cus = 256;
+                    hipGetDevice(&dev);
+                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                    slots = 8 * cus;
+                }
+                // (one CU's worth fewer: the engine owns a CU, and a workgroup that is not resident from the
+                // start would take its first, static tile late)
+                if (total > slots) {
+                    a.queue = queue; a.ntiles = (unsigned)total;
+                    grid = dim3((unsigned)(slots - 8), 1);
+                }
+            }
         }
     }
     const bool trailing = (K >= 2 * TILE) && world == 1;
@@ -1138,9 +1168,7 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     // COCONS_UPD_MFMA4=1 selects the 4x4x4 kernel: its instruction peaks at 76 TFLOP/s, but at a 32x32
     // tile per wave, one barrier per 32 instructions and 5 waves per SIMD the kernel around it lands
     // where the default does (what it needs next)
-    static int form4 = -1;
-    if (form4 < 0) { const char *e = getenv("COCONS_UPD_MFMA4"); form4 = e ? atoi(e) : 0; }
-    if (!form4) {
+    if (!upd_form4()) {
         if (trailing) hipLaunchKernelGGL((update_kernel<64, 8, 0>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((update_kernel<64, 8, 1>), grid, dim3(256), 0, s, a);
     } else {
@@ -1151,10 +1179,10 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
 
 void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig, int sig_tile,
-                   unsigned *wait_word, unsigned *abort_word)
+                   unsigned *wait_word, unsigned *abort_word, unsigned *queue)
 {
     launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile,
-                       wait_word, abort_word);
+                       wait_word, abort_word, queue);
 }
 
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,

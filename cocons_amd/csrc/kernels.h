@@ -104,9 +104,11 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
 // tile-col in [tj0,tj1); lower_only keeps ti >= tj.  All tile indices in units of TILE.
 // sig / sig_tile: hand-off to the engine (sig = the in[] array, sig_tile = even tile of the diagonal block);
 // wait_word: an operand tile comes from the engine -- every workgroup first waits for *wait_word >= 1.
+// queue: a device word that is ZERO when the launch starts -- the launch then takes about as many workgroups
+// as the chip holds and they draw the tiles of the trapezoid from that counter (lower_only launches).
 void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig = nullptr, int sig_tile = -1,
-                   unsigned *wait_word = nullptr, unsigned *abort_word = nullptr);
+                   unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr);
 // like launch_update but the (i,k) and (j,k) operands come from a separate packed
 // panel buffer P (ldp rows, row index = global row), used by the sharded path.
 // (ptiles, world, rank): when world > 1 only tile columns tj with (tj / ptiles) % world == rank
@@ -114,11 +116,8 @@ void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int t
 void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig = nullptr, int sig_tile = -1,
-                        unsigned *wait_word = nullptr, unsigned *abort_word = nullptr);
+                        unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr);
 
-// diagnostic (COCONS_UPD_STAMP=1): device counters {shader cycles, 100 MHz ticks, workgroups} summed over
-// every update workgroup since the last reset; nullptr when off
-unsigned long long *upd_stamp_buffer();
 
 // reductions: out[0] = sum_{i<n} log(A(i,i)); out[1 + a*nr + b] = sum_{c<n} A(row0+a,c) A(row0+b,c)
 void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s);
