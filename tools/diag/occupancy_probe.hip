@@ -23,12 +23,30 @@ __global__ void __launch_bounds__(256, 8) probe(unsigned long long ticks, unsign
     }
 }
 
-__global__ void hog(unsigned long long ticks)
+// mode 0: s_memrealtime + s_sleep loop; 1: s_sleep only (fixed count); 2: busy ALU loop, no sleep, no clock reads;
+// 3: s_memrealtime loop without sleep; 4: polls a memory word (agent-scope atomic load) with s_sleep, like the engine
+__global__ void hog(unsigned long long ticks, int mode, unsigned *word, double *sink)
 {
     extern __shared__ double hs[];
     if (threadIdx.x == 0) hs[0] = 1.0;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (mode == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    } else if (mode == 1) {
+        for (unsigned long long i = 0; i < ticks / 4; ++i) __builtin_amdgcn_s_sleep(64);     // ~64*64 cycles each
+    } else if (mode == 2) {
+        double x = threadIdx.x;
+        for (unsigned long long i = 0; i < ticks * 4; ++i) x = x * 1.0000001 + 1e-9;
+        if (x == 12345.0) sink[0] = x;
+    } else if (mode == 3) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) { }
+    } else {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long n = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++n < ticks / 8) __builtin_amdgcn_s_sleep(16);
+        if (t0 == 1) sink[0] = 1.0;
+    }
 }
 
 int main()
@@ -42,9 +60,13 @@ int main()
     hipFuncSetAttribute((const void *)hog, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int withhog = 0; withhog < 3; ++withhog) {
+    unsigned *word; double *sink;
+    hipMalloc(&word, 64); hipMemset(word, 0, 64); hipMalloc(&sink, 64);
+    const int nmodes = 5;
+    for (int withhog = 0; withhog < 1 + nmodes; ++withhog) {
         if (withhog) {
-            hipLaunchKernelGGL(hog, dim3(withhog == 1 ? 1 : 8), dim3(64), 160 * 1024, h, 300000ull);   // 3 ms
+            printf("hog mode %d\n", withhog - 1);
+            hipLaunchKernelGGL(hog, dim3(1), dim3(64), 160 * 1024, h, 300000ull, withhog - 1, word, sink);   // ~3 ms
             hipStreamSynchronize(s);
             // crude: give the hog time to become resident
             hipLaunchKernelGGL(probe, dim3(1), dim3(256), 0, s, 5000ull, rec);
@@ -66,7 +88,7 @@ int main()
             int cur = 0, peak = 0;
             for (auto &x : ev) { cur += x.second; peak = std::max(peak, cur); }
             printf("hog workgroups %d rep %d: %d workgroups x 20 us took %.1f us -> %.2f rounds, peak concurrent %d\n",
-                   withhog == 0 ? 0 : (withhog == 1 ? 1 : 8), rep, nwg, ms * 1e3, ms * 1e3 / 20.0, peak);
+                   withhog == 0 ? 0 : 1, rep, nwg, ms * 1e3, ms * 1e3 / 20.0, peak);
         }
         // placement of a single-round launch (1176 workgroups, like a mid-size trailing update): workgroups per CU
         {
