@@ -43,8 +43,7 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (= fp64 vector peak): 256 CU x 4 SIMD
 #                                  x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 issues every 64 cycles
-PIPE_BUSY_PMC = 0.714            # matrix pipe busy fraction of the update kernel over one evaluation (rocprofv3 --pmc,
-#                                  profiles/r02_update_kernel_mfma_util.json); the rest of achieved/peak is the clock
+MFMA_UTIL_PROFILE = "r02_update_kernel_mfma_util.json"      # matrix pipe busy fraction of the update kernel (rocprofv3 --pmc)
 TRAFFIC_PROFILE = "r02_update_kernel_hbm_traffic.json"
 
 
@@ -300,11 +299,15 @@ def main():
                         "measured_in": "this run (HIP events around each launch on the launch stream)",
                         "flops_per_launch": flops / max(launches, 1),
                         "launch_ms": round(st["update_avg_ms"], 4), "launches_per_eval": launches,
-                        "pipe_busy_frac_pmc": PIPE_BUSY_PMC,
+                        "pipe_busy_frac_pmc": None,
                         "pipe_busy_source": "NOT measured in this run: profiles/r02_update_kernel_mfma_util.json "
                                             "(SQ_VALU_MFMA_BUSY_CYCLES over SIMD cycles, all 39 launches, plain schedule); "
                                             "bare-instruction probes in profiles/r02_mfma_f64_probe.json",
                         "traffic": None}
+            mu = os.path.join(ROOT, "profiles", MFMA_UTIL_PROFILE)
+            if n == 10000 and os.path.exists(mu):
+                with open(mu) as fh:
+                    roofline["pipe_busy_frac_pmc"] = round(json.load(fh).get("mfma_busy_over_simd_cycles_all_launches", 0.0), 3)
             tr = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
             if n == 10000 and os.path.exists(tr):
                 with open(tr) as fh:
