@@ -1,5 +1,5 @@
 """Time the first evaluations one by one (a hand-off time-out shows as one 250 ms evaluation followed by
-plain-schedule times)."""
+plain-schedule times); COCONS_DEBUG_ABORT=1 names the wait."""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
