@@ -7,7 +7,10 @@ include/cocons_hip.h.  See DESIGN.md / INTEGRATION.md.
 from .host import (  # noqa: F401
     ASPECTS,
     CoconsFit,
+    CoconsTaperFit,
     GetNeg2loglikelihood,
+    GetNeg2loglikelihoodTaper,
+    GetNeg2loglikelihoodTaperProfile,
     GetNeg2loglikelihoodProfile,
     GetNeg2loglikelihoodREML,
     GetNeg2loglikelihood_batch,

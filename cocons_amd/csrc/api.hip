@@ -241,6 +241,11 @@ struct cocons_fit {
     int flags_cap;
     bool engine_ok;               // false: plain schedule (batch slots; or after a hand-off timed out)
     bool engine_live;             // the engine of the NEXT factorize call is already launched (engine_start)
+    // taper fit (cocons_fit_create_taper): the spam pattern (1-based CSR) with the taper's entries; the
+    // -2 log-likelihood is then that of the TAPERED covariance, evaluated through the dense factorisation
+    int taper_nnz;                // > 0: taper fit
+    int *d_tci, *d_trp;
+    double *d_tval, *d_tcov;      // taper entries (constant), covariance entries of the current theta
     // collectives of the natively sharded evaluation (see "native sharded evaluation" below)
     int coll_kind;                // 0 none, 1 RCCL communicator, 2 caller-provided transport
     int coll_rank, coll_world;
@@ -297,6 +302,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
         if (f->ev_eng) hipEventDestroy(f->ev_eng);
         hipFree(f->dflags);
+        hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_tcov);
         if (f->cstream) { hipStreamSynchronize(f->cstream); hipStreamDestroy(f->cstream); }
         for (auto &e : f->ev_main) if (e) hipEventDestroy(e);
         for (auto &e : f->ev_comm) if (e) hipEventDestroy(e);
@@ -451,6 +457,57 @@ extern "C" cocons_fit *cocons_fit_create(int n, int p, int r, int q, const doubl
     return fit_create_impl(n, p, r, q, locs, X, z, x_betas, smooth_limits, device, true);
 }
 
+// Taper fit: the handle of an optimisation of GetNeg2loglikelihoodTaper (R/neg2loglikelihood.R:20-53).  The
+// pattern (colindices / rowpointers, 1-based as spam stores them, symmetric, diagonal stored) and the taper's
+// entries are those of `ref_taper`; cocons_neg2loglik_dense on this handle returns
+//   sum_k [ n log 2 pi + 2 sum log diag chol(S) + resid_k' S^-1 resid_k ],   S = taper o cov_rns_taper(theta),
+// the value spam's sparse Cholesky gives, obtained here through the DENSE factorisation of S (zeros stored):
+// valid while n^2 doubles fit the device, and an n = 10^4 evaluation costs what a dense one costs.  The
+// observations keep the caller's order (the pattern refers to it).
+extern "C" cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double *locs, const double *X, const double *z,
+                                               const double *smooth_limits, int device, int nnz, const int *colindices,
+                                               const int *rowpointers, const double *taper_entries)
+{
+    if (n <= 0 || nnz <= 0 || !colindices || !rowpointers || !taper_entries || r < 1) {
+        fail(-1, "cocons_fit_create_taper: bad argument");
+        return nullptr;
+    }
+    if (rowpointers[0] != 1 || rowpointers[n] != nnz + 1) {
+        fail(-1, "cocons_fit_create_taper: rowpointers do not match nnz (1-based CSR expected)");
+        return nullptr;
+    }
+    for (int i = 0; i < n; ++i) {
+        bool diag = false;
+        if (rowpointers[i + 1] < rowpointers[i]) { fail(-1, "cocons_fit_create_taper: rowpointers decrease"); return nullptr; }
+        for (int w = rowpointers[i] - 1; w < rowpointers[i + 1] - 1; ++w) {
+            if (colindices[w] < 1 || colindices[w] > n) { fail(-1, "cocons_fit_create_taper: column index out of range"); return nullptr; }
+            if (colindices[w] == i + 1) diag = true;
+        }
+        if (!diag) {
+            char msg[96];
+            snprintf(msg, sizeof msg, "row %d stores no diagonal entry", i + 1);
+            fail(-1, "cocons_fit_create_taper: %s", msg);
+            return nullptr;
+        }
+    }
+    cocons_fit *f = fit_create_impl(n, p, r, 0, locs, X, z, nullptr, smooth_limits, device, false);
+    if (!f) return nullptr;
+    bool ok = hipMalloc(&f->d_tci, (size_t)nnz * sizeof(int)) == hipSuccess &&
+              hipMalloc(&f->d_trp, (size_t)(n + 1) * sizeof(int)) == hipSuccess &&
+              hipMalloc(&f->d_tval, (size_t)nnz * sizeof(double)) == hipSuccess &&
+              hipMalloc(&f->d_tcov, (size_t)nnz * sizeof(double)) == hipSuccess &&
+              hipMemcpy(f->d_tci, colindices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(f->d_trp, rowpointers, (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(f->d_tval, taper_entries, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        fail(-100, "cocons_fit_create_taper: device allocation or upload failed");
+        cocons_fit_destroy(f);
+        return nullptr;
+    }
+    f->taper_nnz = nnz;
+    return f;
+}
+
 extern "C" void *cocons_fit_stream(cocons_fit *f) { return f ? (void *)f->stream : nullptr; }
 
 extern "C" int cocons_fit_set_stream(cocons_fit *f, void *stream)
@@ -499,6 +556,36 @@ static void assemble_sigma(cocons_fit *f, const double *theta, int which, int co
     pa.bj0 = col0 / 64;
     pa.gr = ms.gr; pa.nu_fixed = ms.nu_fixed;
     launch_pair_sym(ms.mode, false, pa, f->stream);
+}
+
+// Taper fit: Sigma_tap = taper o cov_rns_taper(theta) (R/neg2loglikelihood.R:25-31) as a dense lower triangle.
+// Parameters exactly as cocons_cov_rns_taper prepares them (FULL scale vector, src/cocons_taper.cpp:207).
+static int assemble_sigma_taper(cocons_fit *f, const double *theta)
+{
+    ThetaVecs tv;
+    make_theta_vecs(theta, f->p, tv);
+    for (int i = 0; i < f->p; ++i) tv.two_scale_je[i] = 2 * theta[TH_SCALE * f->p + i];
+    ModeSel ms = select_mode(theta, f->p, f->smooth_limits, 0);
+    LocArgs la;
+    la.n = f->n; la.p = f->p;
+    la.X = f->dX; la.ldx = f->n;
+    la.locs = f->dlocs; la.ldl = f->n;
+    la.out = f->dloc; la.stride = f->npad;
+    la.smooth_kind = ms.smooth_kind;
+    la.smooth_min = f->smooth_limits[0]; la.smooth_max = f->smooth_limits[1];
+    la.th = tv;
+    launch_loc_params(la, f->stream);
+    HIPCHK(hipMemsetAsync(f->dA, 0, f->lda * (size_t)f->npad * sizeof(double), f->stream));
+    launch_taper(ms.mode, false, f->n, f->taper_nnz, f->d_tci, f->d_trp, f->dloc, f->npad, f->dloc, f->npad,
+                 ms.nu_fixed, f->d_tcov, f->stream);
+    launch_taper_scatter(f->n, f->npad, f->d_trp, f->d_tci, f->d_tcov, f->d_tval, f->dA, f->lda, f->stream);
+    return 0;
+}
+
+static int no_taper(cocons_fit *f, const char *who)
+{
+    if (f->taper_nnz > 0) return fail(-1, "%s: not available on a taper fit (cocons_neg2loglik_dense is)", who);
+    return 0;
 }
 
 // right-hand-side rows under the matrix: rows npad.. : z columns (minus trend), then xb columns
@@ -718,7 +805,8 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
     if (int rc = fit_alloc_matrix(f, nrhs)) return rc;
     if (stage_events) hipEventRecord(f->ev[0], f->stream);
     if (int rc = reset_info(f)) return rc;
-    assemble_sigma(f, theta, 0, 0, f->npad);
+    if (f->taper_nnz > 0) { if (int rc = assemble_sigma_taper(f, theta)) return rc; }
+    else assemble_sigma(f, theta, 0, 0, f->npad);
     // the engine becomes resident while the (short) right-hand-side kernel runs: not earlier -- a second
     // queue with a resident kernel cuts the workgroup dispatch rate of every other launch to a quarter
     // (tools/diag/occupancy_probe.hip), which costs the 12,000-workgroup assembly 6 % -- and not later, see engine_start
@@ -813,6 +901,7 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
                                        double *values, int *status)
 {
     if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_neg2loglik_batch")) return rc;
     if (nb < 0 || (nb > 0 && (!thetas || !means || !values || !status)))
         return fail(-1, "cocons_neg2loglik_batch: bad argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_batch: fit has no z");
@@ -951,6 +1040,7 @@ static int profile_tail(cocons_fit *f, int nxb, double n_eff, bool reml, double 
 extern "C" int cocons_neg2loglik_profile(cocons_fit *f, const double *theta, double *sum_logliks, double *parts)
 {
     if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_neg2loglik_profile")) return rc;
     if (!theta || !sum_logliks) return fail(-1, "cocons_neg2loglik_profile: null argument");
     if (f->r < 1 || f->q < 1) return fail(-1, "cocons_neg2loglik_profile: fit needs z and x_betas");
     for (;;) {
@@ -967,6 +1057,7 @@ extern "C" int cocons_neg2loglik_profile(cocons_fit *f, const double *theta, dou
 extern "C" int cocons_neg2loglik_reml(cocons_fit *f, const double *theta, int rank, double *sum_logliks, double *parts)
 {
     if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_neg2loglik_reml")) return rc;
     if (!theta || !sum_logliks) return fail(-1, "cocons_neg2loglik_reml: null argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_reml: fit has no z");
     for (;;) {
@@ -1200,6 +1291,7 @@ extern "C" int cocons_cov_rows(cocons_fit *f, const double *theta, int classic, 
                                double *out)
 {
     if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_cov_rows")) return rc;
     if (!theta || nidx <= 0 || !idx || !out) return fail(-1, "cocons_cov_rows: bad argument");
     const int n = f->n, p = f->p;
     for (int b = 0; b < nidx; ++b)
@@ -1245,6 +1337,7 @@ extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const do
                                     double *stochastic, double *quadform)
 {
     if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_predict_dense")) return rc;
     if (!theta || !mean || m <= 0 || !locs_pred || !X_pred || !stochastic || !quadform || z_col < 0 || z_col >= f->r)
         return fail(-1, "cocons_predict_dense: bad argument");
     const int p = f->p, n = f->n;
@@ -1318,6 +1411,7 @@ extern "C" int cocons_sim_dense(cocons_fit *f, const double *theta, const double
                                 int nsim, const double *iiderrors, double *out)
 {
     if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_sim_dense")) return rc;
     if (!theta || !mean || nsim <= 0 || !iiderrors || !out) return fail(-1, "cocons_sim_dense: bad argument");
     if (f->sorted) {
         // L E depends on the ORDER of the observations (the factor of a permuted matrix is not the
@@ -1386,6 +1480,7 @@ extern "C" int cocons_sim_cond_dense(cocons_fit *f, const double *theta, const d
                                      const double *locs_unobs, int nsim, const double *iiderrors, double *out)
 {
     if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_sim_cond_dense")) return rc;
     if (!theta || !mean || m <= 0 || !locs_pred || !X_pred || !locs_unobs || nsim <= 0 || !iiderrors || !out ||
         z_col < 0 || z_col >= f->r)
         return fail(-1, "cocons_sim_cond_dense: bad argument");
@@ -1569,6 +1664,7 @@ extern "C" int cocons_shard_set_exchange(cocons_fit *f, void *buf0, void *buf1, 
 extern "C" int cocons_shard_begin(cocons_fit *f, const double *theta, const double *mean, int rank, int world)
 {
     if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_shard_begin")) return rc;
     if (!theta || !mean || world < 1 || rank < 0 || rank >= world) return fail(-1, "cocons_shard_begin: bad argument");
     if (f->r < 1) return fail(-1, "cocons_shard_begin: fit has no z");
     f->rank = rank; f->world = world; f->nrhs_cur = f->r;
@@ -1742,6 +1838,7 @@ extern "C" int cocons_comm_unique_id(void *id_out)
 extern "C" int cocons_fit_comm_init(cocons_fit *f, int nranks, int rank, const void *idp)
 {
     if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_fit_comm_init")) return rc;
     if (!idp || nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "cocons_fit_comm_init: bad argument");
     if (f->coll_kind) return fail(-1, "cocons_fit_comm_init: the fit already has collectives");
     RcclApi *R = rccl_api();
@@ -1761,6 +1858,7 @@ extern "C" int cocons_fit_set_collectives(cocons_fit *f, int rank, int world, co
                                           cocons_allreduce_fn allreduce, void *user)
 {
     if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_fit_set_collectives")) return rc;
     if (world < 1 || rank < 0 || rank >= world || !bcast || !allreduce)
         return fail(-1, "cocons_fit_set_collectives: bad argument");
     if (f->coll_kind == 1) return fail(-1, "cocons_fit_set_collectives: the fit already has an RCCL communicator");

@@ -252,6 +252,28 @@ void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const 
     }
 }
 
+// Tapered covariance written into the dense factorisation buffer (the buffer is zero when this runs): stored
+// entry w of row i (1-based CSR as spam keeps it) goes to the lower triangle, A(i,j) = taper[w] * cov[w] for
+// i >= j; the strictly upper entries of the (symmetric) pattern are skipped.  One thread per row, and the
+// identity on the padding diagonal n .. npad-1.
+__global__ void taper_scatter_kernel(int n, int npad, const int *rp, const int *ci, const double *cov,
+                                     const double *taper, double *A, size_t lda)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    if (i >= n) { A[(size_t)i + (size_t)i * lda] = 1.0; return; }
+    for (int w = rp[i] - 1; w < rp[i + 1] - 1; ++w) {
+        const int j = ci[w] - 1;
+        if (j <= i) A[(size_t)i + (size_t)j * lda] = taper[w] * cov[w];
+    }
+}
+
+void launch_taper_scatter(int n, int npad, const int *rp, const int *ci, const double *cov, const double *taper,
+                          double *A, size_t lda, hipStream_t s)
+{
+    hipLaunchKernelGGL(taper_scatter_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, n, npad, rp, ci, cov, taper, A, lda);
+}
+
 // Selected rows of the dense covariance (or of cov2cor of it) without ever forming the n x n matrix: what
 // plot(type = "correlations") uses of cov_rns (R/methods.R:161-165: tmp_cov[ww, ]).  Entry (i, j) with the
 // reference's orientation (ii = the smaller index, src/cocons_full.cpp:119-120); cov2cor as stats::cov2cor:

@@ -331,6 +331,80 @@ class CoconsFit:
                 "update_flops": ms[7]}
 
 
+class CoconsTaperFit(CoconsFit):
+    """Handle of an optimisation of GetNeg2loglikelihoodTaper: (locs, x_covariates, z, smooth.limits) plus the
+    spam pattern of `ref_taper` (colindices / rowpointers, 1-based, symmetric, diagonal stored) and its entries.
+    `neg2loglik_core` (inherited) then evaluates the -2 log-likelihood core of the TAPERED covariance through the
+    dense factorisation -- spam's value while n^2 doubles fit the device.  Everything else a dense handle
+    offers is refused by the library."""
+
+    def __init__(self, locs, x_covariates, z, smooth_limits, colindices, rowpointers, taper_entries, device=-1):
+        L = _lib.load()
+        self._L = L
+        locs, X = _f(locs), _f(x_covariates)
+        self.n, self.p = X.shape
+        if locs.shape != (self.n, 2):
+            raise ValueError("locs must be n x 2")
+        z = _f(np.asarray(z, dtype=np.float64).reshape(self.n, -1))
+        self.r = z.shape[1]
+        self.q = 0
+        self.smooth_limits = np.asarray(smooth_limits, dtype=np.float64).copy()
+        self.x_covariates = X
+        ci = np.ascontiguousarray(np.asarray(colindices, dtype=np.int32))
+        rp = np.ascontiguousarray(np.asarray(rowpointers, dtype=np.int32))
+        te = np.ascontiguousarray(np.asarray(taper_entries, dtype=np.float64))
+        if te.size != ci.size:
+            raise ValueError("taper entries and colindices differ in length")
+        self._h = L.cocons_fit_create_taper(self.n, self.p, self.r, _p(locs), _p(X), _p(z), _p(self.smooth_limits),
+                                            int(device), int(ci.size), _ip(ci), _ip(rp), _p(te))
+        if not self._h:
+            raise _lib.CoconsHipError("cocons_fit_create_taper failed: " + _lib.last_error())
+
+
+def GetNeg2loglikelihoodTaper(theta, par_pos, ref_taper, locs, x_covariates, smooth_limits, z, n, lam, safe=True,
+                              fit=None):
+    """R/neg2loglikelihood.R:20-53.  `ref_taper` = (colindices, rowpointers, entries) of the spam taper matrix;
+    `fit` (optional) a CoconsTaperFit built once from the same data.  cholS has no counterpart: the factorisation
+    is dense."""
+    tl = getModelLists(theta, par_pos, "diff")
+    f, own = (fit, False) if fit is not None else (CoconsTaperFit(locs, x_covariates, z, smooth_limits, *ref_taper), True)
+    try:
+        try:
+            val, _ = f.neg2loglik_core(tl)
+        except CholeskyError:
+            if safe:
+                return 1e6                                  # :35-39
+            raise RuntimeError("Cholesky error")
+        return val + getPen(n * f.r, lam, tl, smooth_limits)
+    finally:
+        if own:
+            f.close()
+
+
+def GetNeg2loglikelihoodTaperProfile(theta, par_pos, ref_taper, locs, x_covariates, smooth_limits, z, n, lam,
+                                     safe=True, fit=None):
+    """R/neg2loglikelihood.R:73-108: std.dev[1] = 0, the marginal variance profiled out."""
+    tl = getModelLists(theta, par_pos, "diff")
+    sd = np.array(tl["std.dev"], dtype=np.float64, copy=True)
+    sd[0] = 0.0                                             # :80
+    tl["std.dev"] = sd
+    f, own = (fit, False) if fit is not None else (CoconsTaperFit(locs, x_covariates, z, smooth_limits, *ref_taper), True)
+    try:
+        try:
+            _, parts = f.neg2loglik_core(tl)
+        except CholeskyError:
+            if safe:
+                return 1e6
+            raise RuntimeError("Cholesky error")
+        r = f.r
+        logdet, sum_in = parts[0], float(np.sum(parts[1:]))
+        return (r * n * np.log(2 * np.pi) + r * n + r * 2 * logdet + r * n * np.log(sum_in / (r * n))
+                + getPen(n * r, lam, tl, smooth_limits))    # :102-106
+    finally:
+        if own:
+            f.close()
+
+
 def _with_fit(fit, locs, x_covariates, z, smooth_limits, x_betas=None):
     if fit is not None:
         return fit, False

@@ -109,3 +109,28 @@ cocons_hip_multi_predict <- function(m, theta_list, newlocs, X_pred, z_col = 1L)
   if (res[[1]] > 0L) stop("Cholesky error")
   res[[2]]
 }
+
+# ---- type = "sparse": the taper objective through the dense factorisation on the device --------------------
+# handle of one optimisation; ref_taper is the spam object coco() builds (R/cocons.R), n^2 doubles must fit the GPU
+cocons_hip_taper_fit <- function(locs, x_covariates, z, smooth.limits, ref_taper, device = -1L)
+  .Call(`_cocons_hip_fit_create_taper`, locs, x_covariates, as.matrix(z), as.double(smooth.limits), as.integer(device),
+        ref_taper@colindices, ref_taper@rowpointers, as.double(ref_taper@entries))
+
+# body of GetNeg2loglikelihoodTaper (R/neg2loglikelihood.R:20-53); cholS is not used
+.cocons.hip.GetNeg2loglikelihoodTaper <- function(theta, par.pos, fit, smooth.limits, z, n, lambda, safe = TRUE) {
+  theta_list <- getModelLists(theta = theta, par.pos = par.pos, type = "diff")
+  val <- .cocons.hip.result(.Call(`_cocons_hip_neg2loglik`, fit, theta_list[-1], theta_list$mean), safe)
+  if (is.null(val)) return(1e+06)
+  val + .cocons.getPen(n * dim(z)[2], lambda, theta_list, smooth.limits)
+}
+
+# body of GetNeg2loglikelihoodTaperProfile (R/neg2loglikelihood.R:73-108)
+.cocons.hip.GetNeg2loglikelihoodTaperProfile <- function(theta, par.pos, fit, smooth.limits, z, n, lambda, safe = TRUE) {
+  theta_list <- getModelLists(theta = theta, par.pos = par.pos, type = "diff")
+  theta_list$std.dev[1] <- 0
+  v <- .cocons.hip.result(.Call(`_cocons_hip_neg2loglik_parts`, fit, theta_list[-1], theta_list$mean), safe)
+  if (is.null(v)) return(1e+06)
+  r <- dim(z)[2]; logdet <- v[2]; sum_in <- sum(v[-(1:2)])
+  r * n * log(2 * pi) + r * n + r * 2 * logdet + r * n * log(sum_in / (r * n)) +
+    .cocons.getPen(n * r, lambda, theta_list, smooth.limits)
+}

@@ -189,6 +189,28 @@ SEXP _cocons_hip_fit_create(SEXP locs, SEXP X, SEXP z, SEXP x_betas, SEXP smooth
     return ptr;
 }
 
+/* taper handle (cocons_fit_create_taper): ref_taper's slots go in as they are -- colindices / rowpointers
+ * INTEGER vectors, 1-based; entries REAL -- and stay on the device for the whole optimisation */
+SEXP _cocons_hip_fit_create_taper(SEXP locs, SEXP X, SEXP z, SEXP smooth_limits, SEXP device, SEXP colindices,
+                                  SEXP rowpointers, SEXP entries)
+{
+    const int n = Rf_nrows(X), p = Rf_ncols(X);
+    const int r = Rf_isMatrix(z) ? Rf_ncols(z) : 1;
+    if (Rf_nrows(locs) != n || Rf_ncols(locs) != 2) Rf_error("locs must be n x 2");
+    if (!Rf_isInteger(colindices) || !Rf_isInteger(rowpointers)) Rf_error("colindices / rowpointers must be integer (spam slots)");
+    if (XLENGTH(rowpointers) != (R_xlen_t)n + 1 || XLENGTH(entries) != XLENGTH(colindices))
+        Rf_error("ref_taper does not match the data (n = %d)", n);
+    cocons_fit *f = cocons_fit_create_taper(n, p, r, REAL(locs), REAL(X), REAL(z), REAL(smooth_limits), Rf_asInteger(device),
+                                            (int)XLENGTH(colindices), INTEGER(colindices), INTEGER(rowpointers), REAL(entries));
+    if (!f) Rf_error("cocons_fit_create_taper: %s", cocons_last_error());
+    SEXP tag = PROTECT(Rf_allocVector(INTSXP, 4));
+    INTEGER(tag)[0] = n; INTEGER(tag)[1] = p; INTEGER(tag)[2] = r; INTEGER(tag)[3] = 0;
+    SEXP ptr = PROTECT(R_MakeExternalPtr(f, tag, R_NilValue));
+    R_RegisterCFinalizerEx(ptr, fit_finalizer, TRUE);
+    UNPROTECT(2);
+    return ptr;
+}
+
 SEXP _cocons_hip_fit_close(SEXP ptr)
 {
     fit_finalizer(ptr);
@@ -210,6 +232,23 @@ SEXP _cocons_hip_neg2loglik(SEXP fitp, SEXP theta, SEXP mean)
     int rc = cocons_neg2loglik_dense(f, T, REAL(mean), &val, NULL);
     hip_check(rc, "GetNeg2loglikelihood");
     return status_value(rc, Rf_ScalarReal(val));
+}
+
+/* the same with its parts: list(status, c(sum_logliks, logdet_half, quad_1 .. quad_r)) -- what
+ * GetNeg2loglikelihoodTaperProfile (R/neg2loglikelihood.R:98-106) is formed from on a taper handle */
+SEXP _cocons_hip_neg2loglik_parts(SEXP fitp, SEXP theta, SEXP mean)
+{
+    cocons_fit *f = fit_of(fitp);
+    const int r = fit_r(fitp);
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, fit_p(fitp), T);
+    if (XLENGTH(mean) != fit_p(fitp)) Rf_error("theta$mean must have length %d", fit_p(fitp));
+    SEXP v = PROTECT(Rf_allocVector(REALSXP, 2 + r));
+    int rc = cocons_neg2loglik_dense(f, T, REAL(mean), REAL(v), REAL(v) + 1);
+    hip_check(rc, "GetNeg2loglikelihood");
+    SEXP out = status_value(rc, v);
+    UNPROTECT(1);
+    return out;
 }
 
 /* nb evaluations at once: thetas = list of theta lists, means = list of mean vectors (or a p x nb matrix);
@@ -392,7 +431,9 @@ static const R_CallMethodDef CallEntries[] = {
     {"_cocons_cov_rns_taper", (DL_FUNC)&_cocons_cov_rns_taper, 6},
     {"_cocons_hip_device_count", (DL_FUNC)&_cocons_hip_device_count, 0},
     {"_cocons_hip_fit_create", (DL_FUNC)&_cocons_hip_fit_create, 6},
+    {"_cocons_hip_fit_create_taper", (DL_FUNC)&_cocons_hip_fit_create_taper, 8},
     {"_cocons_hip_fit_close", (DL_FUNC)&_cocons_hip_fit_close, 1},
+    {"_cocons_hip_neg2loglik_parts", (DL_FUNC)&_cocons_hip_neg2loglik_parts, 3},
     {"_cocons_hip_neg2loglik", (DL_FUNC)&_cocons_hip_neg2loglik, 3},
     {"_cocons_hip_neg2loglik_batch", (DL_FUNC)&_cocons_hip_neg2loglik_batch, 3},
     {"_cocons_hip_neg2loglik_profile", (DL_FUNC)&_cocons_hip_neg2loglik_profile, 2},

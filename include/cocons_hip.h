@@ -75,6 +75,20 @@ int cocons_cov_rns_taper_pred(int n, int m, int p, const double *theta, const do
                               const double *smooth_limits, int nnz, const int *colindices,
                               const int *rowpointers, double *entries);
 
+/* ---- taper objective through the dense factorisation (second slice) ----------------
+ * replaces the body of GetNeg2loglikelihoodTaper (R/neg2loglikelihood.R:20-53): ref_taper@entries *
+ * cov_rns_taper(...), update.spam.chol.NgPeyton, determinant, forwardsolve.  The handle takes what is constant
+ * over the optimisation -- locs, x_covariates, z (n x r), smooth.limits and ref_taper's pattern (colindices /
+ * rowpointers, 1-based, symmetric, diagonal stored) with its entries -- and cocons_neg2loglik_dense on it
+ * returns  sum_k [ n log 2 pi + 2 sum log diag chol(S) + resid_k' S^-1 resid_k ],  S = taper o cov_rns_taper(theta):
+ * spam's value, from a DENSE factorisation of S (zeros stored) -- for n^2 doubles within the device's memory.
+ * `parts` as for the dense handle (log-det half, quadratic forms), from which the caller forms
+ * GetNeg2loglikelihoodTaperProfile (:73-108, with theta$std.dev[1] = 0).  Every other fit entry point
+ * refuses a taper handle.  NULL + cocons_last_error() on failure.                                          */
+cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double *locs, const double *X, const double *z,
+                                    const double *smooth_limits, int device, int nnz, const int *colindices,
+                                    const int *rowpointers, const double *taper_entries);
+
 /* ---- fit handle: everything that is constant over an optimisation -------------
  * Created once per cocoOptim / getHessian call from the arguments the reference
  * passes unchanged to every GetNeg2loglikelihood* evaluation

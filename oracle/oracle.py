@@ -263,6 +263,67 @@ def GetNeg2loglikelihood(theta, par_pos, locs, x_covariates, smooth_limits, z, n
     return total + getPen(n * z.shape[1], lam, tl, smooth_limits)
 
 
+def _taper_dense(ref_taper, entries, n):
+    """Dense symmetric matrix of a spam pattern (colindices, rowpointers 1-based) with the given entries."""
+    ci, rp, _ = ref_taper
+    S = np.zeros((n, n))
+    for i in range(n):
+        for w in range(rp[i] - 1, rp[i + 1] - 1):
+            S[i, ci[w] - 1] = entries[w]
+    return S
+
+
+def GetNeg2loglikelihoodTaper(theta, par_pos, ref_taper, locs, x_covariates, smooth_limits, z, n, lam, safe=True):
+    """R/neg2loglikelihood.R:20-53 with the sparse Cholesky (spam, absent here) replaced by a dense one of the
+    same matrix: ref_taper@entries * cov_rns_taper(...) (:25-31), 2 * log det of the factor (:43) and
+    crossprod(forwardsolve(cholS, resid)) (:49-50) are properties of the matrix, not of its storage.
+    ref_taper = (colindices, rowpointers, entries), 1-based as spam stores them."""
+    tl = getModelLists(theta, par_pos, "diff")
+    ci, rp, te = ref_taper
+    ent = np.asarray(te, dtype=np.float64) * cov_rns_taper(tl, locs, x_covariates, ci, rp, smooth_limits)
+    R, info = _chol_upper(_taper_dense(ref_taper, ent, n))
+    if R is None:
+        if safe:
+            return 1e6
+        raise RuntimeError("Cholesky error")
+    logdet = float(np.sum(np.log(np.diag(R))))
+    X = np.asarray(x_covariates, dtype=np.float64)
+    z = np.asarray(z, dtype=np.float64).reshape(X.shape[0], -1)
+    trend = X @ tl["mean"]
+    total = 0.0
+    for k in range(z.shape[1]):
+        y = _forwardsolve_t(R, z[:, k] - trend)
+        total += n * math.log(2 * math.pi) + 2 * logdet + float(y @ y)
+    return total + getPen(n * z.shape[1], lam, tl, smooth_limits)
+
+
+def GetNeg2loglikelihoodTaperProfile(theta, par_pos, ref_taper, locs, x_covariates, smooth_limits, z, n, lam,
+                                     safe=True):
+    """R/neg2loglikelihood.R:73-108 (dense factorisation as above)."""
+    tl = getModelLists(theta, par_pos, "diff")
+    sd = np.array(tl["std.dev"], dtype=np.float64, copy=True)
+    sd[0] = 0.0
+    tl["std.dev"] = sd
+    ci, rp, te = ref_taper
+    ent = np.asarray(te, dtype=np.float64) * cov_rns_taper(tl, locs, x_covariates, ci, rp, smooth_limits)
+    R, info = _chol_upper(_taper_dense(ref_taper, ent, n))
+    if R is None:
+        if safe:
+            return 1e6
+        raise RuntimeError("Cholesky error")
+    logdet = float(np.sum(np.log(np.diag(R))))
+    X = np.asarray(x_covariates, dtype=np.float64)
+    z = np.asarray(z, dtype=np.float64).reshape(X.shape[0], -1)
+    r = z.shape[1]
+    trend = X @ tl["mean"]
+    sum_in = 0.0
+    for k in range(r):
+        y = _forwardsolve_t(R, z[:, k] - trend)
+        sum_in += float(y @ y)
+    return (r * n * math.log(2 * math.pi) + r * n + r * 2 * logdet + r * n * math.log(sum_in / (r * n))
+            + getPen(n * r, lam, tl, smooth_limits))
+
+
 def GetNeg2loglikelihoodProfile(theta, par_pos, locs, x_covariates, smooth_limits, z, n, x_betas, lam, safe=True):
     """R/neg2loglikelihood.R:127-165 (literal: chol2inv + P_mat)."""
     tl = getModelLists(theta, par_pos, "diff")

@@ -540,6 +540,76 @@ def wl_limits():
     return wl.SMOOTH_LIMITS
 
 
+def _wendland1(d, delta):
+    """spam::cov.wend1 with range delta and sill 1: (1 - h)^4 (4 h + 1) for h = d / delta < 1 (the taper the
+    package documentation uses for type = 'sparse')."""
+    h = np.minimum(d / delta, 1.0)
+    return (1.0 - h) ** 4 * (4.0 * h + 1.0)
+
+
+def _taper_pattern(locs, delta):
+    """(colindices, rowpointers, entries) of the Wendland-1 taper matrix, 1-based CSR as spam stores it."""
+    ci, rp = _csr_within(locs, locs, delta)
+    ent = np.empty(ci.size)
+    for i in range(locs.shape[0]):
+        w0, w1 = rp[i] - 1, rp[i + 1] - 1
+        d = np.sqrt(np.sum((locs[ci[w0:w1] - 1] - locs[i]) ** 2, axis=1))
+        ent[w0:w1] = _wendland1(d, delta)
+    return ci, rp, ent
+
+
+@pytest.mark.parametrize("n,r", [(150, 1), (700, 2), (1500, 1)])
+def test_taper_objective_vs_oracle(oracle, n, r):
+    """GetNeg2loglikelihoodTaper / ...TaperProfile (R/neg2loglikelihood.R:20-108) on a taper handle: the value of
+    the tapered covariance through the dense factorisation, against the CPU restatement (dense Cholesky of the same
+    matrix), plain and engine schedule sizes, one and two realisations, with the penalty."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, rng = _problem(n, seed=700 + n)
+    z = rng.standard_normal((n, r))
+    delta = 0.25 if n < 1000 else 0.12
+    ref_taper = _taper_pattern(locs, delta)
+    pp = wl.par_pos_full()
+    tv = wl.theta_vector_from_lists(th, pp)
+    lam = (0.1, 0.2, 0.3)
+    fit = ca.CoconsTaperFit(locs, X, z, wl.SMOOTH_LIMITS, *ref_taper)
+    got = ca.GetNeg2loglikelihoodTaper(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    want = oracle.GetNeg2loglikelihoodTaper(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+    assert abs(got - want) <= N2LL_RTOL * abs(want)
+    gotp = ca.GetNeg2loglikelihoodTaperProfile(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    wantp = oracle.GetNeg2loglikelihoodTaperProfile(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+    assert abs(gotp - wantp) <= N2LL_RTOL * abs(wantp)
+    # a second evaluation on the same handle (the buffer is re-zeroed), and the handle-less form
+    tv2 = tv.copy()
+    tv2[0] += 0.05
+    got2 = ca.GetNeg2loglikelihoodTaper(tv2, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    want2 = oracle.GetNeg2loglikelihoodTaper(tv2, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+    assert abs(got2 - want2) <= N2LL_RTOL * abs(want2)
+    if n <= 200:
+        got3 = ca.GetNeg2loglikelihoodTaper(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+        assert got3 == got
+    # what a taper handle does not offer is refused, not computed on the wrong matrix
+    with pytest.raises(ca.CoconsHipError, match="taper"):
+        fit.cov_rows(th, np.array([0]))
+    fit.close()
+
+
+def test_taper_fit_rejects_bad_patterns():
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, rng = _problem(50, seed=5)
+    ci, rp, ent = _taper_pattern(locs, 0.3)
+    z = rng.standard_normal(50)
+    with pytest.raises(ca.CoconsHipError, match="rowpointers"):
+        ca.CoconsTaperFit(locs, X, z, wl.SMOOTH_LIMITS, ci, rp - 1, ent)          # 0-based pointers
+    keep = np.ones(ci.size, dtype=bool)
+    keep[rp[7] - 1 + int(np.nonzero(ci[rp[7] - 1:rp[8] - 1] == 8)[0][0])] = False   # drop the diagonal of row 8
+    rp2 = rp.copy()
+    rp2[8:] -= 1
+    with pytest.raises(ca.CoconsHipError, match="diagonal"):
+        ca.CoconsTaperFit(locs, X, z, wl.SMOOTH_LIMITS, ci[keep], rp2, ent[keep])
+
+
 def test_cov_rows_and_cor_rows(oracle):
     """Rows of Sigma / cov2cor(Sigma) straight from the fit (cocons_cov_rows), the consumers of
     getCovMatrix (R/getFunctions.R:44-52, R/methods.R:161-165), against the full CPU matrix: both

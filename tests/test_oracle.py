@@ -198,3 +198,45 @@ def test_taper_golden_n24(oracle, golden_dir):
     dense = oracle.cov_rns(t1, l2, X1, (1.5, 1.5))
     sparse = oracle.cov_rns_taper(t1, l2, X1, ci, rp, (1.5, 1.5)).reshape(n, n)
     assert _relerr(sparse, dense) < 1e-13
+
+
+def test_taper_objective_independent_of_storage(oracle):
+    """The oracle evaluates GetNeg2loglikelihoodTaper (R/neg2loglikelihood.R:20-53) with a DENSE Cholesky of the
+    tapered matrix; the reference uses spam's sparse one.  log det and the quadratic form belong to the matrix:
+    a sparse LU of the same CSR matrix (scipy, SuperLU -- spam is not available here) gives the same value."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    from cocons_amd import workloads as wl
+    n = 400
+    rng = np.random.default_rng(12)
+    locs = rng.uniform(0, 1, size=(n, 2))
+    X = wl.design_from_locs(locs)["std.covs"]
+    th = wl.theta_full(scale0=math.log(0.2))
+    delta = 0.2
+    ci, rp, ent = [], [1], []
+    for i in range(n):
+        d = np.sqrt(np.sum((locs - locs[i]) ** 2, axis=1))
+        idx = np.nonzero(d <= delta)[0]
+        h = d[idx] / delta
+        ci.extend((idx + 1).tolist())
+        ent.extend(((1 - h) ** 4 * (4 * h + 1)).tolist())
+        rp.append(len(ci) + 1)
+    ref_taper = (np.array(ci, dtype=np.int32), np.array(rp, dtype=np.int32), np.array(ent))
+    z = rng.standard_normal((n, 2))
+    pp = wl.par_pos_full()
+    tv = wl.theta_vector_from_lists(th, pp)
+    lam = (0.0, 0.0, 0.0)
+    got = oracle.GetNeg2loglikelihoodTaper(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+    tl = oracle.getModelLists(tv, pp, "diff")
+    vals = ref_taper[2] * oracle.cov_rns_taper(tl, locs, X, ref_taper[0], ref_taper[1], wl.SMOOTH_LIMITS)
+    S = sp.csr_matrix((vals, ref_taper[0] - 1, ref_taper[1] - 1), shape=(n, n)).tocsc()
+    assert abs(S - S.T).max() < 1e-15 * abs(S).max()
+    lu = spl.splu(S)
+    logdet = float(np.sum(np.log(np.abs(lu.U.diagonal())))) + float(np.sum(np.log(np.abs(lu.L.diagonal()))))
+    want = 0.0
+    for k in range(2):
+        resid = z[:, k] - X @ tl["mean"]
+        want += n * math.log(2 * math.pi) + logdet + float(resid @ lu.solve(resid))
+    assert abs(got - want) < 1e-10 * abs(want)
+    prof = oracle.GetNeg2loglikelihoodTaperProfile(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+    assert np.isfinite(prof)
