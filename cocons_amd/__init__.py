@@ -15,6 +15,7 @@ from .host import (  # noqa: F401
     GetNeg2loglikelihoodREML,
     GetNeg2loglikelihood_batch,
     cocoPredict_dense,
+    cocoPredict_sparse,
     cocoSim_cond_dense,
     cocoSim_dense,
     cov_rns,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "cocons_cov_rows": (c_int, [c_vp, c_dp, c_int, c_int, ctypes.POINTER(c_int), c_int, c_dp]),
     "cocons_sumsmoothlone": (ctypes.c_double, [c_dp, c_int, ctypes.c_double, ctypes.c_double]),
     "cocons_fit_create": (c_vp, [c_int, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_int]),
+    "cocons_predict_taper": (c_int, [c_vp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_int, ctypes.POINTER(c_int),
+                                     ctypes.POINTER(c_int), c_dp, c_dp, c_dp]),
     "cocons_fit_create_taper": (c_vp, [c_int, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_int, c_int,
                                        ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_dp]),
     "cocons_fit_destroy": (None, [c_vp]),

@@ -1404,6 +1404,102 @@ extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const do
     return st;
 }
 
+// Kriging core of the sparse branch of cocoPredict (R/predict.R:216-283) on a taper handle: S = taper o
+// cov_rns_taper(theta) as in the objective, C = pred_taper o cov_rns_taper_pred(theta) (m x n, its own pattern);
+// one bordered DENSE factorisation replaces  inv_cov <- spam::solve(S, t(C))  ("memory intensive", :244) and gives
+//   stochastic[i] = C[i,] S^-1 resid    (:252)      quadform[i] = C[i,] S^-1 C[i,]'    (:267)
+extern "C" int cocons_predict_taper(cocons_fit *f, const double *theta, const double *mean, int z_col, int m,
+                                    const double *locs_pred, const double *X_pred, int nnz_pred,
+                                    const int *colindices_pred, const int *rowpointers_pred,
+                                    const double *taper_entries_pred, double *stochastic, double *quadform)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (f->taper_nnz <= 0) return fail(-1, "cocons_predict_taper: not a taper fit");
+    if (!theta || !mean || m <= 0 || !locs_pred || !X_pred || !stochastic || !quadform || z_col < 0 || z_col >= f->r ||
+        nnz_pred < 0 || !rowpointers_pred || (nnz_pred > 0 && (!colindices_pred || !taper_entries_pred)))
+        return fail(-1, "cocons_predict_taper: bad argument");
+    const int p = f->p, n = f->n;
+    if (rowpointers_pred[0] != 1 || rowpointers_pred[m] != nnz_pred + 1)
+        return fail(-1, "cocons_predict_taper: rowpointers do not match nnz (1-based CSR expected)");
+    for (int w = 0; w < nnz_pred; ++w)
+        if (colindices_pred[w] < 1 || colindices_pred[w] > n) return fail(-1, "cocons_predict_taper: column index out of range");
+    if (m > f->pred_cap) {
+        hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad); hipFree(f->dred);
+        f->dlocp = f->dXp = f->dlocsp = f->dstoch = f->dquad = f->dred = nullptr;
+        f->pred_cap = 0;
+        HIPCHK(hipMalloc(&f->dlocp, (size_t)LOCP_FIELDS * m * sizeof(double)));
+        HIPCHK(hipMalloc(&f->dXp, (size_t)m * p * sizeof(double)));
+        HIPCHK(hipMalloc(&f->dlocsp, (size_t)m * 2 * sizeof(double)));
+        HIPCHK(hipMalloc(&f->dstoch, (size_t)m * sizeof(double)));
+        HIPCHK(hipMalloc(&f->dquad, (size_t)m * sizeof(double)));
+        HIPCHK(hipMalloc(&f->dred, row_reduce_scratch_doubles(n, m) * sizeof(double)));
+        f->pred_cap = m;
+    }
+    if (int rc = fit_alloc_matrix(f, m + 1)) return rc;
+    hipStream_t s = f->stream;
+    int *dci = nullptr, *drp = nullptr;
+    double *dtv = nullptr, *dcv = nullptr;
+    const size_t nz = nnz_pred > 0 ? (size_t)nnz_pred : 1;
+    int st = 0;
+    do {
+#define CKP(expr) { hipError_t e__ = (expr); if (e__ != hipSuccess) { st = fail(-100 - (int)e__, "cocons_predict_taper: %s", hipGetErrorString(e__)); break; } }
+        CKP(hipMalloc(&dci, nz * sizeof(int)));
+        CKP(hipMalloc(&drp, (size_t)(m + 1) * sizeof(int)));
+        CKP(hipMalloc(&dtv, nz * sizeof(double)));
+        CKP(hipMalloc(&dcv, nz * sizeof(double)));
+        CKP(hipMemcpyAsync(f->dXp, X_pred, (size_t)m * p * sizeof(double), hipMemcpyHostToDevice, s));
+        CKP(hipMemcpyAsync(f->dlocsp, locs_pred, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+        CKP(hipMemcpyAsync(drp, rowpointers_pred, (size_t)(m + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+        if (nnz_pred > 0) {
+            CKP(hipMemcpyAsync(dci, colindices_pred, (size_t)nnz_pred * sizeof(int), hipMemcpyHostToDevice, s));
+            CKP(hipMemcpyAsync(dtv, taper_entries_pred, (size_t)nnz_pred * sizeof(double), hipMemcpyHostToDevice, s));
+        }
+#undef CKP
+        for (;;) {
+            if ((st = reset_info(f))) break;
+            if ((st = assemble_sigma_taper(f, theta))) break;          // zeroes the whole buffer, border rows included
+            RhsArgs ra;
+            memset(&ra, 0, sizeof ra);
+            ra.n = n; ra.p = p; ra.X = f->dX; ra.ldx = n; ra.use_trend = 1;
+            for (int i = 0; i < p; ++i) ra.mean[i] = mean[i];
+            ra.src = f->dz + (size_t)z_col * n; ra.lds = n;
+            ra.out = f->dA; ra.ld = f->lda; ra.row0 = f->npad; ra.nrows = 1;
+            ra.nrows_zero = f->rhs_act - 1;
+            ra.col0 = 0; ra.ncols_out = f->npad;
+            launch_rhs_rows(ra, s);
+            // parameters as cocons_cov_rns_taper_pred prepares them: FULL scale vector, prediction-branch smoothness
+            ThetaVecs tv;
+            make_theta_vecs(theta, p, tv);
+            for (int i = 0; i < p; ++i) tv.two_scale_je[i] = 2 * theta[TH_SCALE * p + i];
+            ModeSel ms = select_mode(theta, p, f->smooth_limits, 2);
+            LocArgs lp;
+            lp.n = m; lp.p = p; lp.X = f->dXp; lp.ldx = m; lp.locs = f->dlocsp; lp.ldl = m;
+            lp.out = f->dlocp; lp.stride = m; lp.smooth_kind = ms.smooth_kind;
+            lp.smooth_min = f->smooth_limits[0]; lp.smooth_max = f->smooth_limits[1]; lp.th = tv;
+            launch_loc_params(lp, s);
+            LocArgs lo = lp;
+            lo.n = n; lo.X = f->dX; lo.ldx = n; lo.locs = f->dlocs; lo.ldl = n; lo.out = f->dloc; lo.stride = f->npad;
+            launch_loc_params(lo, s);                                   // (after the entries of S were computed: stream order)
+            launch_taper(MODE_GEOM, true, m, nnz_pred, dci, drp, f->dlocp, m, f->dloc, f->npad, 0.0, dcv, s);
+            if (nnz_pred > 0) launch_taper_scatter_rows(m, drp, dci, dcv, dtv, f->dA, f->lda, f->npad + 1, s);
+            factorize(f, main_view(f), nullptr);
+            launch_row_reduce(f->dA, f->lda, n, f->npad, f->npad + 1, m, f->dstoch, f->dquad, f->dred, s);
+            hipMemcpyAsync(stochastic, f->dstoch, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s);
+            hipMemcpyAsync(quadform, f->dquad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s);
+            hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { st = fail(-100 - (int)e, "cocons_predict_taper: %s", hipGetErrorString(e)); break; }
+            st = info_status(f);
+            if (engine_retry(f, st)) continue;
+            break;
+        }
+    } while (0);
+    hipStreamSynchronize(s);
+    hipFree(dci); hipFree(drp); hipFree(dtv); hipFree(dcv);
+    return st;
+}
+
 // ---------------------------------------------------------------------------
 // marginal simulation core: replaces R/sim.R:147-172
 //   covmat <- cov_rns[_classic](...); cholS <- chol(covmat); t(sweep(t(iiderrors) %*% cholS, 2, X %*% mean, "+"))

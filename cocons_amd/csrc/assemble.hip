@@ -268,6 +268,22 @@ __global__ void taper_scatter_kernel(int n, int npad, const int *rp, const int *
     }
 }
 
+// Tapered cross-covariance rows under the matrix: stored entry w of prediction row i goes to A(row0 + i, j).
+// (The rows are zero when this runs.)  One thread per prediction location.
+__global__ void taper_scatter_rows_kernel(int m, const int *rp, const int *ci, const double *cov, const double *taper,
+                                          double *A, size_t lda, int row0)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    for (int w = rp[i] - 1; w < rp[i + 1] - 1; ++w) A[(size_t)(row0 + i) + (size_t)(ci[w] - 1) * lda] = taper[w] * cov[w];
+}
+
+void launch_taper_scatter_rows(int m, const int *rp, const int *ci, const double *cov, const double *taper, double *A,
+                               size_t lda, int row0, hipStream_t s)
+{
+    hipLaunchKernelGGL(taper_scatter_rows_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, rp, ci, cov, taper, A, lda, row0);
+}
+
 void launch_taper_scatter(int n, int npad, const int *rp, const int *ci, const double *cov, const double *taper,
                           double *A, size_t lda, hipStream_t s)
 {

@@ -72,6 +72,8 @@ void launch_rhs_rows(const RhsArgs &a, hipStream_t s);
 void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const int *rp, const double *rows,
                   size_t stride_rows, const double *cols, size_t stride, double nu_fixed, double *out, hipStream_t s);
 // rows idx[0..nidx) of the dense covariance (cor != 0: of cov2cor of it); out row b at out + b * n
+void launch_taper_scatter_rows(int m, const int *rp, const int *ci, const double *cov, const double *taper, double *A,
+                               size_t lda, int row0, hipStream_t s);
 // dense lower-triangular image of a tapered covariance from its CSR entries (see taper_scatter_kernel)
 void launch_taper_scatter(int n, int npad, const int *rp, const int *ci, const double *cov, const double *taper,
                           double *A, size_t lda, hipStream_t s);

@@ -361,6 +361,45 @@ class CoconsTaperFit(CoconsFit):
             raise _lib.CoconsHipError("cocons_fit_create_taper failed: " + _lib.last_error())
 
 
+    def predict_core(self, theta_list, locs_pred, x_covariates_pred, pred_taper, z_col=0):
+        """(stochastic, quadform) of the sparse branch of cocoPredict; pred_taper = (colindices, rowpointers,
+        entries) of the m x n taper between prediction and observed locations (1-based CSR)."""
+        T = theta_table(theta_list)
+        mean = np.ascontiguousarray(np.asarray(theta_list["mean"], dtype=np.float64))
+        lp, Xp = _f(locs_pred), _f(x_covariates_pred)
+        m = Xp.shape[0]
+        ci = np.ascontiguousarray(np.asarray(pred_taper[0], dtype=np.int32))
+        rp = np.ascontiguousarray(np.asarray(pred_taper[1], dtype=np.int32))
+        te = np.ascontiguousarray(np.asarray(pred_taper[2], dtype=np.float64))
+        st, qf = np.empty(m), np.empty(m)
+        _lib.check(self._L.cocons_predict_taper(self._h, _p(T), _p(mean), int(z_col), m, _p(lp), _p(Xp), int(ci.size),
+                                                _ip(ci), _ip(rp), _p(te), _p(st), _p(qf)), "cocons_predict_taper")
+        return st, qf
+
+
+def cocoPredict_sparse(theta_list, locs, newlocs, X_std, X_pred_std, smooth_limits, z, ref_taper, pred_taper,
+                       type="pred", fit=None):
+    """Sparse branch of cocoPredict, R/predict.R:190-283, from the point where the scaled design matrices, the
+    adjusted theta list and the two taper matrices (taper_two = ref_taper, pred_taper; (colindices, rowpointers,
+    entries) each) exist."""
+    f, own = (fit, False) if fit is not None else (CoconsTaperFit(locs, X_std, z, smooth_limits, *ref_taper), True)
+    try:
+        st, qf = f.predict_core(theta_list, newlocs, X_pred_std, pred_taper)
+    finally:
+        if own:
+            f.close()
+    Xp = np.asarray(X_pred_std, dtype=np.float64)
+    systematic = Xp @ np.asarray(theta_list["mean"], dtype=np.float64)                    # :247
+    if type == "mean":
+        return {"systematic": systematic, "stochastic": st}
+    with np.errstate(invalid="ignore"):
+        unc = 1 / np.exp(-(Xp @ theta_list["std.dev"])) + np.exp(Xp @ theta_list["nugget"])   # :264-265
+    unc = unc - qf                                                                         # :267
+    neg = unc < 1e-10
+    unc[neg] = np.abs(unc[neg])                                                            # :269-271
+    return {"systematic": systematic, "stochastic": st, "sd.pred": np.sqrt(unc)}
+
+
 def GetNeg2loglikelihoodTaper(theta, par_pos, ref_taper, locs, x_covariates, smooth_limits, z, n, lam, safe=True,
                               fit=None):
     """R/neg2loglikelihood.R:20-53.  `ref_taper` = (colindices, rowpointers, entries) of the spam taper matrix;

@@ -134,3 +134,13 @@ cocons_hip_taper_fit <- function(locs, x_covariates, z, smooth.limits, ref_taper
   r * n * log(2 * pi) + r * n + r * 2 * logdet + r * n * log(sum_in / (r * n)) +
     .cocons.getPen(n * r, lambda, theta_list, smooth.limits)
 }
+
+# sparse branch of cocoPredict (R/predict.R:216-283): the lines from cov_rns_taper to rowSums(pred_taper * t(inv_cov)) become
+#   kr <- .cocons.hip.predict.taper(fit, theta_list, newlocs, X_pred_std, pred_taper)   # pred_taper: the spam object of :229-231
+#   stochastic_part <- kr[, 1];  uncertainty_some <- uncertainty_some - kr[, 2]
+.cocons.hip.predict.taper <- function(fit, theta_list, newlocs, X_pred, pred_taper, z_col = 1L) {
+  res <- .Call(`_cocons_hip_predict_taper`, fit, theta_list[-1], theta_list$mean, as.integer(z_col), newlocs, X_pred,
+               pred_taper@colindices, pred_taper@rowpointers, as.double(pred_taper@entries))
+  if (res[[1]] > 0L) stop("Cholesky error")
+  res[[2]]
+}

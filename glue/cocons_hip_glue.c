@@ -421,6 +421,29 @@ SEXP _cocons_hip_multi_predict(SEXP mp, SEXP theta, SEXP mean, SEXP z_col, SEXP 
     return out;
 }
 
+/* kriging core of the sparse branch of cocoPredict on a taper handle: list(status, cbind(stochastic, quadform));
+ * pred_taper's slots as they are (integer colindices / rowpointers, 1-based; REAL entries) */
+SEXP _cocons_hip_predict_taper(SEXP fitp, SEXP theta, SEXP mean, SEXP z_col, SEXP locs_pred, SEXP X_pred,
+                               SEXP colindices, SEXP rowpointers, SEXP entries)
+{
+    cocons_fit *f = fit_of(fitp);
+    const int p = fit_p(fitp), m = Rf_nrows(X_pred);
+    if (Rf_ncols(X_pred) != p || Rf_nrows(locs_pred) != m) Rf_error("prediction design / locations do not match the fit");
+    if (!Rf_isInteger(colindices) || !Rf_isInteger(rowpointers) || XLENGTH(rowpointers) != (R_xlen_t)m + 1 ||
+        XLENGTH(entries) != XLENGTH(colindices))
+        Rf_error("pred_taper does not match the prediction locations");
+    double T[6 * COCONS_P_MAX];
+    theta_table(theta, p, T);
+    SEXP v = PROTECT(Rf_allocMatrix(REALSXP, m, 2));
+    int rc = cocons_predict_taper(f, T, REAL(mean), Rf_asInteger(z_col) - 1, m, REAL(locs_pred), REAL(X_pred),
+                                  (int)XLENGTH(colindices), INTEGER(colindices), INTEGER(rowpointers), REAL(entries),
+                                  REAL(v), REAL(v) + m);
+    hip_check(rc, "cocoPredict (sparse)");
+    SEXP out = status_value(rc, v);
+    UNPROTECT(1);
+    return out;
+}
+
 /* ---- registration (replaces src/RcppExports.cpp:105-118) --------------------------------------- */
 static const R_CallMethodDef CallEntries[] = {
     {"_cocons_sumsmoothlone", (DL_FUNC)&_cocons_sumsmoothlone, 3},
@@ -439,6 +462,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_cocons_hip_neg2loglik_profile", (DL_FUNC)&_cocons_hip_neg2loglik_profile, 2},
     {"_cocons_hip_neg2loglik_reml", (DL_FUNC)&_cocons_hip_neg2loglik_reml, 3},
     {"_cocons_hip_predict", (DL_FUNC)&_cocons_hip_predict, 6},
+    {"_cocons_hip_predict_taper", (DL_FUNC)&_cocons_hip_predict_taper, 9},
     {"_cocons_hip_sim", (DL_FUNC)&_cocons_hip_sim, 5},
     {"_cocons_hip_sim_cond", (DL_FUNC)&_cocons_hip_sim_cond, 8},
     {"_cocons_hip_cov_rows", (DL_FUNC)&_cocons_hip_cov_rows, 5},

@@ -89,6 +89,16 @@ cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double *locs, con
                                     const double *smooth_limits, int device, int nnz, const int *colindices,
                                     const int *rowpointers, const double *taper_entries);
 
+/* Kriging core of the sparse branch of cocoPredict (R/predict.R:216-283) on a taper handle: replaces
+ * cov_rns_taper / cov_rns_taper_pred times their tapers, inv_cov <- spam::solve(taper_two, t(pred_taper)) (:244),
+ * crossprod(resid, inv_cov) (:252) and rowSums(pred_taper * t(inv_cov)) (:267).  pred_taper's slots go in as they
+ * are (m rows, columns = observations, 1-based); theta / mean / z_col as for cocons_predict_dense.
+ * stochastic[m], quadform[m] come back; the systematic part and the variance lines (:247-249, :264-272) stay in R. */
+int cocons_predict_taper(cocons_fit *fit, const double *theta, const double *mean, int z_col, int m,
+                         const double *locs_pred, const double *X_pred, int nnz_pred, const int *colindices_pred,
+                         const int *rowpointers_pred, const double *taper_entries_pred,
+                         double *stochastic, double *quadform);
+
 /* ---- fit handle: everything that is constant over an optimisation -------------
  * Created once per cocoOptim / getHessian call from the arguments the reference
  * passes unchanged to every GetNeg2loglikelihood* evaluation

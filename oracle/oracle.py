@@ -415,6 +415,34 @@ def cocoPredict_dense(theta_list, locs, newlocs, X_std, X_pred_std, smooth_limit
     return {"systematic": systematic_pred, "stochastic": stochastic, "sd.pred": np.sqrt(unc)}
 
 
+def cocoPredict_sparse(theta_list, locs, newlocs, X_std, X_pred_std, smooth_limits, z, ref_taper, pred_taper,
+                       type="pred"):
+    """Sparse branch of cocoPredict, R/predict.R:216-283, with spam::solve (absent here) replaced by a dense solve
+    of the same matrices.  ref_taper / pred_taper = (colindices, rowpointers, entries), 1-based."""
+    Xs, Xp = np.asarray(X_std, float), np.asarray(X_pred_std, float)
+    n, m = Xs.shape[0], Xp.shape[0]
+    ent = np.asarray(ref_taper[2], float) * cov_rns_taper(theta_list, locs, X_std, ref_taper[0], ref_taper[1], smooth_limits)
+    S = _taper_dense(ref_taper, ent, n)
+    entp = np.asarray(pred_taper[2], float) * cov_rns_taper_pred(theta_list, locs, newlocs, X_std, X_pred_std,
+                                                                  pred_taper[0], pred_taper[1], smooth_limits)
+    C = np.zeros((m, n))
+    ci, rp = pred_taper[0], pred_taper[1]
+    for i in range(m):
+        for w in range(rp[i] - 1, rp[i + 1] - 1):
+            C[i, ci[w] - 1] = entp[w]
+    inv_cov = np.linalg.solve(S, C.T)                                            # :244
+    systematic_pred = Xp @ theta_list["mean"]
+    resid = np.asarray(z, float).ravel() - Xs @ theta_list["mean"]
+    stochastic = resid @ inv_cov                                                 # :252
+    if type == "mean":
+        return {"systematic": systematic_pred, "stochastic": stochastic}
+    unc = 1 / np.exp(-(Xp @ theta_list["std.dev"])) + np.exp(Xp @ theta_list["nugget"])
+    unc = unc - np.sum(C * inv_cov.T, axis=1)                                    # :267
+    neg = unc < 1e-10
+    unc[neg] = np.abs(unc[neg])
+    return {"systematic": systematic_pred, "stochastic": stochastic, "sd.pred": np.sqrt(unc)}
+
+
 def cocoSim_dense(theta_list, locs, X_std, smooth_limits, iiderrors, type="classic"):
     """Marginal branch of cocoSim (dense), R/sim.R:147-172."""
     if type == "classic":

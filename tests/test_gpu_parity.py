@@ -594,6 +594,46 @@ def test_taper_objective_vs_oracle(oracle, n, r):
     fit.close()
 
 
+def test_taper_predict_vs_oracle(oracle):
+    """Sparse branch of cocoPredict (R/predict.R:216-283) on a taper handle against the CPU restatement: tapered
+    cross-covariance rows as border of the tapered matrix, one prediction location without any neighbour (an empty
+    row: stochastic 0, full marginal variance) and one on top of an observation."""
+    import cocons_amd as ca
+    n, m = 900, 300
+    locs, X, th, rng = _problem(n, seed=77)
+    z = rng.standard_normal(n)
+    delta = 0.15
+    ref_taper = _taper_pattern(locs, delta)
+    lp = rng.uniform(0, 1, size=(m, 2))
+    lp[3] = locs[100]
+    lp[4] = np.array([4.0, 4.0])
+    Xp = np.column_stack([np.ones(m), rng.standard_normal(m), rng.standard_normal(m)])
+    cip, rpp = _csr_within(lp, locs, delta)
+    entp = np.empty(cip.size)
+    for i in range(m):
+        w0, w1 = rpp[i] - 1, rpp[i + 1] - 1
+        d = np.sqrt(np.sum((locs[cip[w0:w1] - 1] - lp[i]) ** 2, axis=1))
+        entp[w0:w1] = _wendland1(d, delta)
+    pred_taper = (cip, rpp, entp)
+    assert rpp[5] == rpp[4]
+    fit = ca.CoconsTaperFit(locs, X, z, wl_limits(), *ref_taper)
+    got = ca.cocoPredict_sparse(th, locs, lp, X, Xp, wl_limits(), z, ref_taper, pred_taper, fit=fit)
+    want = oracle.cocoPredict_sparse(th, locs, lp, X, Xp, wl_limits(), z, ref_taper, pred_taper)
+    assert np.allclose(got["systematic"], want["systematic"], rtol=1e-13, atol=0)
+    scale = np.max(np.abs(want["stochastic"]))
+    assert np.max(np.abs(got["stochastic"] - want["stochastic"])) < 1e-10 * scale
+    assert got["stochastic"][4] == 0.0
+    assert np.max(np.abs(got["sd.pred"] - want["sd.pred"])) < 1e-9 * np.max(want["sd.pred"])
+    # the objective still works on the handle afterwards (the prediction grew the buffer)
+    v, _ = fit.neg2loglik_core(th)
+    from cocons_amd import workloads as wl
+    pp = wl.par_pos_full()
+    tv = wl.theta_vector_from_lists(th, pp)
+    w = oracle.GetNeg2loglikelihoodTaper(tv, pp, ref_taper, locs, X, wl_limits(), z.reshape(-1, 1), n, (0, 0, 0))
+    assert abs(v - w) <= N2LL_RTOL * abs(w)
+    fit.close()
+
+
 def test_taper_fit_rejects_bad_patterns():
     import cocons_amd as ca
     from cocons_amd import workloads as wl
