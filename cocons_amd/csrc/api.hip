@@ -901,10 +901,20 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
                                        double *values, int *status)
 {
     if (int rc = fit_check(f)) return rc;
-    if (int rc = no_taper(f, "cocons_neg2loglik_batch")) return rc;
     if (nb < 0 || (nb > 0 && (!thetas || !means || !values || !status)))
         return fail(-1, "cocons_neg2loglik_batch: bad argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_batch: fit has no z");
+    if (f->taper_nnz > 0) {
+        // taper handle: one evaluation after the other on the handle itself (its pattern is not cloned into slots)
+        for (int i = 0; i < nb; ++i) {
+            double v = NAN;
+            int st = cocons_neg2loglik_dense(f, thetas + (size_t)i * 6 * f->p, means + (size_t)i * f->p, &v, nullptr);
+            if (st < 0) { for (int k = i; k < nb; ++k) { values[k] = NAN; status[k] = -1; } return st; }
+            values[i] = st == 0 ? v : NAN;
+            status[i] = st;
+        }
+        return 0;
+    }
     static int nslots_env = -1;
     if (nslots_env < 0) {
         const char *e = getenv("COCONS_BATCH_SLOTS");

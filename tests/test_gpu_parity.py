@@ -588,6 +588,12 @@ def test_taper_objective_vs_oracle(oracle, n, r):
     if n <= 200:
         got3 = ca.GetNeg2loglikelihoodTaper(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
         assert got3 == got
+    # the batch entry (getHessian's points) runs them one after the other on a taper handle
+    tl, tl2 = ca.getModelLists(tv, pp, "diff"), ca.getModelLists(tv2, pp, "diff")
+    vals, st = fit.neg2loglik_batch_core([tl, tl2, tl])
+    assert np.all(st == 0) and vals[0] == vals[2]
+    pen, pen2 = ca.getPen(n * r, lam, tl, wl.SMOOTH_LIMITS), ca.getPen(n * r, lam, tl2, wl.SMOOTH_LIMITS)
+    assert abs(vals[0] + pen - got) <= 1e-12 * abs(got) and abs(vals[1] + pen2 - got2) <= 1e-12 * abs(got2)
     # what a taper handle does not offer is refused, not computed on the wrong matrix
     with pytest.raises(ca.CoconsHipError, match="taper"):
         fit.cov_rows(th, np.array([0]))
