@@ -246,6 +246,9 @@ struct cocons_fit {
     int taper_nnz;                // > 0: taper fit
     int *d_tci, *d_trp;
     double *d_tval, *d_tcov;      // taper entries (constant), covariance entries of the current theta
+    std::vector<int> *taper_hi;   // envelope of the (reordered) pattern per tile column: see FactorView::hi
+    int *d_thi; int taper_maxband; // device copy of taper_hi and max_c (hi[c] - c)
+    std::vector<int> *taper_inv;  // position of the caller's observation i in the handle's order (reverse Cuthill-McKee)
     // collectives of the natively sharded evaluation (see "native sharded evaluation" below)
     int coll_kind;                // 0 none, 1 RCCL communicator, 2 caller-provided transport
     int coll_rank, coll_world;
@@ -302,7 +305,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
         if (f->ev_eng) hipEventDestroy(f->ev_eng);
         hipFree(f->dflags);
-        hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_tcov);
+        hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_tcov); hipFree(f->d_thi);
         if (f->cstream) { hipStreamSynchronize(f->cstream); hipStreamDestroy(f->cstream); }
         for (auto &e : f->ev_main) if (e) hipEventDestroy(e);
         for (auto &e : f->ev_comm) if (e) hipEventDestroy(e);
@@ -314,6 +317,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     }
     delete f->h_locs; delete f->h_X; delete f->h_z;
+    delete f->taper_hi; delete f->taper_inv;
     delete f;
 }
 
@@ -490,15 +494,116 @@ extern "C" cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double
             return nullptr;
         }
     }
-    cocons_fit *f = fit_create_impl(n, p, r, 0, locs, X, z, nullptr, smooth_limits, device, false);
+    // Order the observations by reverse Cuthill-McKee on the pattern (COCONS_TAPER_RCM=0: keep the caller's order):
+    // the value does not depend on the order, the envelope of the factor does, and the factorisation below
+    // only touches tiles inside it.
+    std::vector<int> perm(n), inv(n);            // perm[new] = old, inv[old] = new
+    {
+        const char *e = getenv("COCONS_TAPER_RCM");
+        const bool rcm = e ? atoi(e) != 0 : true;
+        if (!rcm) { for (int i = 0; i < n; ++i) perm[i] = i; }
+        else {
+            std::vector<int> deg(n), order;
+            std::vector<char> seen(n, 0);
+            order.reserve(n);
+            for (int i = 0; i < n; ++i) deg[i] = rowpointers[i + 1] - rowpointers[i];
+            std::vector<int> nb;
+            auto bfs = [&](int root, std::vector<int> &out) {        // Cuthill-McKee order of root's component
+                const size_t first = out.size();
+                out.push_back(root); seen[root] = 1;
+                for (size_t h = first; h < out.size(); ++h) {
+                    const int u = out[h];
+                    nb.clear();
+                    for (int w = rowpointers[u] - 1; w < rowpointers[u + 1] - 1; ++w) {
+                        const int v2 = colindices[w] - 1;
+                        if (!seen[v2]) { seen[v2] = 1; nb.push_back(v2); }
+                    }
+                    std::sort(nb.begin(), nb.end(), [&](int a2, int b2) { return deg[a2] != deg[b2] ? deg[a2] < deg[b2] : a2 < b2; });
+                    for (int v2 : nb) out.push_back(v2);
+                }
+            };
+            std::vector<int> byd(n);
+            for (int i = 0; i < n; ++i) byd[i] = i;
+            std::sort(byd.begin(), byd.end(), [&](int a2, int b2) { return deg[a2] != deg[b2] ? deg[a2] < deg[b2] : a2 < b2; });
+            for (int c = 0; c < n; ++c) {
+                const int start = byd[c];
+                if (seen[start]) continue;
+                // pseudo-peripheral root: the last vertex of a first sweep from the component's minimum-degree vertex
+                std::vector<int> probe;
+                bfs(start, probe);
+                const int root = probe.back();
+                for (int u : probe) seen[u] = 0;
+                bfs(root, order);
+            }
+            for (int i = 0; i < n; ++i) perm[i] = order[n - 1 - i];
+        }
+        for (int i = 0; i < n; ++i) inv[perm[i]] = i;
+    }
+    std::vector<double> pl((size_t)2 * n), pX((size_t)p * n), pz((size_t)r * n);
+    for (int i = 0; i < n; ++i) {
+        const int o = perm[i];
+        pl[i] = locs[o]; pl[(size_t)n + i] = locs[(size_t)n + o];
+        for (int c = 0; c < p; ++c) pX[(size_t)c * n + i] = X[(size_t)c * n + o];
+        for (int c = 0; c < r; ++c) pz[(size_t)c * n + i] = z[(size_t)c * n + o];
+    }
+    std::vector<int> prp(n + 1), pci(nnz);
+    std::vector<double> pte(nnz);
+    prp[0] = 1;
+    for (int i = 0, w2 = 0; i < n; ++i) {
+        const int o = perm[i];
+        for (int w = rowpointers[o] - 1; w < rowpointers[o + 1] - 1; ++w, ++w2) {
+            pci[w2] = inv[colindices[w] - 1] + 1;
+            pte[w2] = taper_entries[w];
+        }
+        prp[i + 1] = w2 + 1;
+    }
+    cocons_fit *f = fit_create_impl(n, p, r, 0, pl.data(), pX.data(), pz.data(), nullptr, smooth_limits, device, false);
     if (!f) return nullptr;
+    // envelope per tile column: row i of the factor is non-zero from its first stored column on
+    f->taper_hi = new std::vector<int>(f->nt, 0);
+    f->taper_inv = new std::vector<int>(inv);
+    {
+        std::vector<int> &hi = *f->taper_hi;
+        for (int c = 0; c < f->nt; ++c) hi[c] = c + 1 < f->nt ? c + 1 : f->nt;
+        for (int i = 0; i < n; ++i) {
+            int first = i;
+            for (int w = prp[i] - 1; w < prp[i + 1] - 1; ++w) if (pci[w] - 1 < first) first = pci[w] - 1;
+            const int ti = i / TILE;
+            for (int c = first / TILE; c <= ti; ++c) if (hi[c] < ti + 1) hi[c] = ti + 1;
+        }
+        const char *e = getenv("COCONS_TAPER_BAND");
+        if (e && atoi(e) == 0) hi.clear();           // dense factorisation of the tapered matrix
+        if (!hi.empty()) {
+            // The schedule works on 256-column blocks and updates the square [t, hb) x [t, hb) with a block's panel:
+            // make the bound per block (both tile columns, at least the next diagonal block) and monotone, so that every
+            // tile an update touches lies inside the bound of its own column -- which is what gets zeroed.
+            std::vector<int> h2(f->nt);
+            int run = 0;
+            for (int c = 0; c < f->nt; ++c) {
+                const int k = c & ~1;
+                int hb = hi[k];
+                if (k + 1 < f->nt && hi[k + 1] > hb) hb = hi[k + 1];
+                const int need = k + 4 < f->nt ? k + 4 : f->nt;
+                if (hb < need) hb = need;
+                if (hb > f->nt) hb = f->nt;
+                if (hb > run) run = hb;
+                h2[c] = run;
+            }
+            hi = h2;
+            f->taper_maxband = 0;
+            for (int c = 0; c < f->nt; ++c) if (hi[c] - c > f->taper_maxband) f->taper_maxband = hi[c] - c;
+        }
+    }
     bool ok = hipMalloc(&f->d_tci, (size_t)nnz * sizeof(int)) == hipSuccess &&
               hipMalloc(&f->d_trp, (size_t)(n + 1) * sizeof(int)) == hipSuccess &&
               hipMalloc(&f->d_tval, (size_t)nnz * sizeof(double)) == hipSuccess &&
               hipMalloc(&f->d_tcov, (size_t)nnz * sizeof(double)) == hipSuccess &&
-              hipMemcpy(f->d_tci, colindices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(f->d_trp, rowpointers, (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(f->d_tval, taper_entries, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+              hipMemcpy(f->d_tci, pci.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(f->d_trp, prp.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(f->d_tval, pte.data(), (size_t)nnz * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && !f->taper_hi->empty())
+        ok = hipMalloc(&f->d_thi, (size_t)f->nt * sizeof(int)) == hipSuccess &&
+             hipMemcpy(f->d_thi, f->taper_hi->data(), (size_t)f->nt * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) {
         fail(-100, "cocons_fit_create_taper: device allocation or upload failed");
         cocons_fit_destroy(f);
@@ -575,7 +680,10 @@ static int assemble_sigma_taper(cocons_fit *f, const double *theta)
     la.smooth_min = f->smooth_limits[0]; la.smooth_max = f->smooth_limits[1];
     la.th = tv;
     launch_loc_params(la, f->stream);
-    HIPCHK(hipMemsetAsync(f->dA, 0, f->lda * (size_t)f->npad * sizeof(double), f->stream));
+    // zero what the factorisation will read: the tiles inside the envelope (the rows under the matrix are written in
+    // full by the right-hand-side kernel), or the whole buffer when the factorisation is not band-limited
+    if (f->d_thi) launch_band_zero(f->dA, f->lda, f->d_thi, f->nt, f->taper_maxband, f->stream);
+    else HIPCHK(hipMemsetAsync(f->dA, 0, f->lda * (size_t)f->npad * sizeof(double), f->stream));
     launch_taper(ms.mode, false, f->n, f->taper_nnz, f->d_tci, f->d_trp, f->dloc, f->npad, f->dloc, f->npad,
                  ms.nu_fixed, f->d_tcov, f->stream);
     launch_taper_scatter(f->n, f->npad, f->d_trp, f->d_tci, f->d_tcov, f->d_tval, f->dA, f->lda, f->stream);
@@ -624,13 +732,28 @@ struct FactorView {
     double *A;
     size_t lda;
     int nt, mt;
+    const int *hi = nullptr;   // band-limited factorisation (taper handles): hi[c] = one past the last tile row of tile
+                               // column c that can be non-zero in the factor (envelope of the pattern); nullptr = dense
 };
 
 static FactorView main_view(cocons_fit *f)
 {
     FactorView v;
     v.A = f->dA; v.lda = f->lda; v.nt = f->nt; v.mt = f->nt + f->rhs_act / TILE;
+    v.hi = (f->taper_hi && !f->taper_hi->empty()) ? f->taper_hi->data() : nullptr;
     return v;
+}
+
+// one past the last band row tile of the 256-column block starting at tile k (at least the next diagonal block, so
+// that the update which the engine's hand-off hangs on always covers it); -1 = dense
+static int band_hi(const FactorView &v, int k)
+{
+    if (!v.hi) return -1;
+    int h = v.hi[k];
+    if (k + 1 < v.nt && v.hi[k + 1] > h) h = v.hi[k + 1];
+    const int need = k + 4 < v.nt ? k + 4 : v.nt;
+    if (h < need) h = need;
+    return h < v.nt ? h : v.nt;
 }
 
 static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
@@ -639,12 +762,14 @@ static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
     double *A = v.A;
     const size_t lda = v.lda;
     double *q0 = f->dinv, *q1 = f->dinv + 8 * 256;
+    const int hb = band_hi(v, k);                       // rows [.., hb) of the band, then the rows under the matrix [nt, mt)
+    const int br = hb >= 0 ? hb * TILE : -1, er = nt * TILE;
     launch_potrf_tile(A, lda, k * TILE, q0, f->dinfo, s);
-    launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, mt * TILE, q0, s);
+    launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, mt * TILE, q0, s, nullptr, nullptr, br, er);
     if (k + 1 < nt) {
-        launch_update(A, lda, k * TILE, TILE, k + 1, mt, k + 1, k + 2, true, s);
+        launch_update(A, lda, k * TILE, TILE, k + 1, mt, k + 1, k + 2, true, s, nullptr, -1, nullptr, nullptr, nullptr, hb, nt);
         launch_potrf_tile(A, lda, (k + 1) * TILE, q1, f->dinfo, s);
-        launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, mt * TILE, q1, s);
+        launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, mt * TILE, q1, s, nullptr, nullptr, br, er);
     }
 }
 
@@ -667,15 +792,18 @@ static void timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int 
 {
     const int mt = v.mt;
     if (t1 <= t0) return;
+    const int hb = band_hi(v, k);                       // band-limited: tile columns and rows [t0, hb), plus the rows [nt, mt)
+    if (hb >= 0 && hb < t1) t1 = hb;
+    if (t1 <= t0) return;
     if (ev_upd) {
         hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a, s);
-        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, nullptr, queue);
+        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, nullptr, queue, hb, v.nt);
         hipEventRecord(b, s);
         ev_upd->push_back(a); ev_upd->push_back(b);
     } else {
-        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, nullptr, queue);
+        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, nullptr, queue, hb, v.nt);
     }
 }
 
@@ -778,12 +906,15 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         const int r0 = two ? t + 2 : t + 1;          // first tile row below the diagonal block
         if (ev_upd) count_update_flops(f, 2, t);
         timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k));
+        const int hb = band_hi(v, t);                // rows of block t's panel: [r0, hb) and the rows under the matrix
+        const int br = hb >= 0 ? hb * TILE : -1, er = nt * TILE;
         launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, mt * TILE, f->dinv + (size_t)(t & 1) * 2048, M,
-                         out + t, abort_word);
+                         out + t, abort_word, br, er);
         if (two) {
-            launch_update(v.A, v.lda, t * TILE, TILE, r0, mt, t + 1, t + 2, false, M, nullptr, -1, xr + t, abort_word);
+            launch_update(v.A, v.lda, t * TILE, TILE, r0, mt, t + 1, t + 2, false, M, nullptr, -1, xr + t, abort_word,
+                          nullptr, hb, nt);
             launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, r0 * TILE, mt * TILE,
-                             f->dinv + (size_t)((t + 1) & 1) * 2048, M, out + t + 1, abort_word);
+                             f->dinv + (size_t)((t + 1) & 1) * 2048, M, out + t + 1, abort_word, br, er);
         }
     }
     return 0;
@@ -1085,6 +1216,7 @@ extern "C" int cocons_neg2loglik_reml(cocons_fit *f, const double *theta, int ra
 extern "C" int cocons_fit_profile(cocons_fit *f, const double *theta, const double *mean, int reps, double *ms)
 {
     if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_fit_profile")) return rc;
     if (!theta || !mean || !ms || reps < 1) return fail(-1, "cocons_fit_profile: bad argument");
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < reps; ++it) {
@@ -1460,8 +1592,11 @@ extern "C" int cocons_predict_taper(cocons_fit *f, const double *theta, const do
         CKP(hipMemcpyAsync(f->dXp, X_pred, (size_t)m * p * sizeof(double), hipMemcpyHostToDevice, s));
         CKP(hipMemcpyAsync(f->dlocsp, locs_pred, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
         CKP(hipMemcpyAsync(drp, rowpointers_pred, (size_t)(m + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+        std::vector<int> mapped;                    // the pattern's columns in the handle's order of the observations
         if (nnz_pred > 0) {
-            CKP(hipMemcpyAsync(dci, colindices_pred, (size_t)nnz_pred * sizeof(int), hipMemcpyHostToDevice, s));
+            mapped.resize(nnz_pred);
+            for (int w = 0; w < nnz_pred; ++w) mapped[w] = (*f->taper_inv)[colindices_pred[w] - 1] + 1;
+            CKP(hipMemcpy(dci, mapped.data(), (size_t)nnz_pred * sizeof(int), hipMemcpyHostToDevice));
             CKP(hipMemcpyAsync(dtv, taper_entries_pred, (size_t)nnz_pred * sizeof(double), hipMemcpyHostToDevice, s));
         }
 #undef CKP

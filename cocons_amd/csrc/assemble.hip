@@ -268,6 +268,25 @@ __global__ void taper_scatter_kernel(int n, int npad, const int *rp, const int *
     }
 }
 
+// Zero the tiles of a band-limited factorisation buffer: tile column c, tile rows c .. hi[c]-1 (whole 128 x 128 tiles,
+// the upper part of the diagonal tile included: the tile factorisation loads full 16 x 16 diagonal blocks).
+__global__ void band_zero_kernel(double *A, size_t lda, const int *hi, int nt)
+{
+    const int c = blockIdx.x, rt = c + blockIdx.y;
+    if (rt >= hi[c]) return;
+    double *p = A + (size_t)rt * 128 + (size_t)c * 128 * lda;
+    for (int e = threadIdx.x; e < 128 * 64; e += blockDim.x) {       // 2 doubles per step
+        const int col = e >> 6, r2 = (e & 63) * 2;
+        *(double2 *)(p + r2 + (size_t)col * lda) = make_double2(0.0, 0.0);
+    }
+}
+
+void launch_band_zero(double *A, size_t lda, const int *d_hi, int nt, int max_band, hipStream_t s)
+{
+    if (nt <= 0 || max_band <= 0) return;
+    hipLaunchKernelGGL(band_zero_kernel, dim3(nt, max_band), dim3(256), 0, s, A, lda, d_hi, nt);
+}
+
 // Tapered cross-covariance rows under the matrix: stored entry w of prediction row i goes to A(row0 + i, j).
 // (The rows are zero when this runs.)  One thread per prediction location.
 __global__ void taper_scatter_rows_kernel(int m, const int *rp, const int *ci, const double *cov, const double *taper,

@@ -543,7 +543,8 @@ engine_gate_kernel(unsigned *alive, unsigned *abort_word)
 // One workgroup = 64 rows; each wave owns a 16 x 128 strip held in registers (8 blocks).
 // LDS holds the 36 lower 16x16 blocks of L and the 8 x 4 Q operands.
 __global__ void __launch_bounds__(256)
-trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsigned *wait_word, unsigned *abort_word)
+trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsigned *wait_word, unsigned *abort_word,
+                 int nb1, int e0)
 {
     __shared__ double SL[36 * 256];
     __shared__ double QS[8 * 256];
@@ -562,7 +563,10 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsig
                 SL[b * 256 + k * 16 + i] = A[(size_t)(c0 + 16 * ib + i) + (size_t)(c0 + 16 * kb + k) * lda];
         for (int e = tid; e < 8 * 256; e += 256) QS[e] = qin[e];
     }
-    const int rs = r0 + 64 * blockIdx.x + 16 * wave;
+    // rows: workgroups 0 .. nb1-1 cover [r0, r0 + 64 nb1), the others a second range from e0 (the right-hand-side rows
+    // under a band-limited factorisation; nb1 = all of them otherwise)
+    const int bx = blockIdx.x;
+    const int rs = (bx < nb1 ? r0 + 64 * bx : e0 + 64 * (bx - nb1)) + 16 * wave;
     d4 B[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) B[j] = glb_blk(A, lda, rs, c0 + 16 * j, lane);
@@ -602,6 +606,8 @@ struct UpdArgs {
     unsigned *wait_word, *abort_word;  // engine hand-off: every workgroup first waits for *wait_word >= 1
     int ptiles, world, rank;       // sharded path: only 128-tile columns whose panel (tj128 / ptiles) is owned
     unsigned *queue; unsigned ntiles;  // dynamic tile order (lower_only launches): shared counter, zero at launch; tiles in all
+    int Hb, ext0;                  // rows: local tile rows < Hb count from ti0 (tj0 when lower_only), the others from ext0
+                                   // (band-limited factorisation: band rows, then the right-hand-side rows)
 };
 
 // ROLE only names the instantiation (0 = trailing update, 1 = in-panel / sharded update) so that
@@ -665,9 +671,11 @@ update_kernel(UpdArgs a)
             }
             const int j = lo;
             tj = a.tj0 + j;
-            ti = a.tj0 + j + ((int)L - (j * a.H - j * (j - 1) / 2));
+            const int til = j + ((int)L - (j * a.H - j * (j - 1) / 2));
+            ti = til < a.Hb ? a.tj0 + til : a.ext0 + (til - a.Hb);
         } else {
-            ti = a.ti0 + blockIdx.x;
+            const int til = blockIdx.x;
+            ti = til < a.Hb ? a.ti0 + til : a.ext0 + (til - a.Hb);
             tj = a.tj0 + blockIdx.y;
         }
         if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;   // (static launches only)
@@ -1107,11 +1115,15 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
 }
 
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
-                      unsigned *wait_word, unsigned *abort_word)
+                      unsigned *wait_word, unsigned *abort_word, int band_r1, int ext_r0)
 {
-    int nb = (r1 - r0) / 64;
-    if (nb <= 0) return;
-    hipLaunchKernelGGL(trsm_tile_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, dinv, wait_word, abort_word);
+    // rows [r0, r1), or -- band-limited -- [r0, band_r1) and [ext_r0, r1)
+    int nb1 = ((band_r1 >= 0 ? band_r1 : r1) - r0) / 64, nb2 = band_r1 >= 0 ? (r1 - ext_r0) / 64 : 0;
+    if (nb1 < 0) nb1 = 0;
+    if (nb2 < 0) nb2 = 0;
+    if (nb1 + nb2 <= 0) return;
+    hipLaunchKernelGGL(trsm_tile_kernel, dim3(nb1 + nb2), dim3(256), 0, s, A, lda, c0, r0, dinv, wait_word, abort_word,
+                       nb1, ext_r0);
 }
 
 // COCONS_UPD_MFMA4=1 selects the 4x4x4 kernel for the updates (static tile order only)
@@ -1125,11 +1137,15 @@ static bool upd_form4()
 void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig, int sig_tile,
-                        unsigned *wait_word, unsigned *abort_word, unsigned *queue)
+                        unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0)
 {
-    if (ti1 <= ti0 || tj1 <= tj0 || K <= 0) return;
+    // tile rows [ti0, ti1), or -- band-limited -- [ti0, band_hi) and [ext0, ti1)
+    const bool band = band_hi >= 0;
+    const int rows_band = (band ? band_hi : ti1) - ti0, rows_ext = band ? ti1 - ext0 : 0;
+    if (rows_band + rows_ext <= 0 || rows_band < 0 || rows_ext < 0 || tj1 <= tj0 || K <= 0) return;
     UpdArgs a;
     a.queue = nullptr; a.ntiles = 0;
+    a.Hb = 2 * rows_band; a.ext0 = 2 * ext0;
     a.C = A; a.ldc = lda; a.P = P; a.ldp = ldp; a.K = K;
     a.lower_only = lower_only ? 1 : 0;
     a.ptiles = ptiles; a.world = world; a.rank = rank;
@@ -1139,12 +1155,12 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     // 64 x 64 tiles throughout (the 128 x 128 shape measured 31 TFLOP/s against 50): tile indices in
     // units of 64 from here on
     a.ti0 = 2 * ti0; a.tj0 = 2 * tj0;
-    dim3 grid(2 * (ti1 - ti0), 2 * (tj1 - tj0));
+    dim3 grid(2 * (rows_band + rows_ext), 2 * (tj1 - tj0));
     if (lower_only) {
         // requires ti0 >= tj0 == first column: the trapezoid rows tj0..ti1, columns tj0..tj1
         if (ti0 != tj0) { a.lower_only = 0; }    // strictly-below rectangle: every tile does work
         else {
-            const long long H = 2LL * (ti1 - tj0), W = 2LL * (tj1 - tj0);
+            const long long H = 2LL * (rows_band + rows_ext), W = 2LL * (tj1 - tj0);
             a.H = (int)H; a.W = (int)W;
             const long long total = W * H - W * (W - 1) / 2;
             grid = dim3((unsigned)total, 1);
@@ -1182,10 +1198,10 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
 
 void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig, int sig_tile,
-                   unsigned *wait_word, unsigned *abort_word, unsigned *queue)
+                   unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0)
 {
     launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile,
-                       wait_word, abort_word, queue);
+                       wait_word, abort_word, queue, band_hi, ext0);
 }
 
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,

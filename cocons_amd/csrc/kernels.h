@@ -72,6 +72,8 @@ void launch_rhs_rows(const RhsArgs &a, hipStream_t s);
 void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const int *rp, const double *rows,
                   size_t stride_rows, const double *cols, size_t stride, double nu_fixed, double *out, hipStream_t s);
 // rows idx[0..nidx) of the dense covariance (cor != 0: of cov2cor of it); out row b at out + b * n
+// zero the tiles inside the envelope (d_hi: device copy of FactorView::hi; max_band = max over c of hi[c] - c)
+void launch_band_zero(double *A, size_t lda, const int *d_hi, int nt, int max_band, hipStream_t s);
 void launch_taper_scatter_rows(int m, const int *rp, const int *ci, const double *cov, const double *taper, double *A,
                                size_t lda, int row0, hipStream_t s);
 // dense lower-triangular image of a tapered covariance from its CSR entries (see taper_scatter_kernel)
@@ -103,8 +105,9 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
 void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s);
 // rows [r0, r1) x cols [c0, c0+128):  X <- X * L(c0)^{-T}, L read from A(c0,c0).
 // wait_word != NULL: the tile comes from the engine -- every workgroup first waits for *wait_word >= 1
+// band_r1 >= 0 (band-limited factorisation): rows [r0, band_r1) and [ext_r0, r1) instead of [r0, r1).
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
-                      unsigned *wait_word = nullptr, unsigned *abort_word = nullptr);
+                      unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, int band_r1 = -1, int ext_r0 = 0);
 // C(i,j) -= sum_{k in [k0,k0+K)} A(i,k) A(j,k) for tiles with tile-row in [ti0,ti1),
 // tile-col in [tj0,tj1); lower_only keeps ti >= tj.  All tile indices in units of TILE.
 // sig / sig_tile: hand-off to the engine (sig = the in[] array, sig_tile = even tile of the diagonal block);
@@ -113,7 +116,8 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
 // as the chip holds and they draw the tiles of the trapezoid from that counter (lower_only launches).
 void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig = nullptr, int sig_tile = -1,
-                   unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr);
+                   unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
+                   int band_hi = -1, int ext0 = 0);      // band_hi >= 0: tile rows [ti0, band_hi) and [ext0, ti1)
 // like launch_update but the (i,k) and (j,k) operands come from a separate packed
 // panel buffer P (ldp rows, row index = global row), used by the sharded path.
 // (ptiles, world, rank): when world > 1 only tile columns tj with (tj / ptiles) % world == rank
@@ -121,7 +125,8 @@ void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int t
 void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig = nullptr, int sig_tile = -1,
-                        unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr);
+                        unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
+                        int band_hi = -1, int ext0 = 0);
 
 
 // reductions: out[0] = sum_{i<n} log(A(i,i)); out[1 + a*nr + b] = sum_{c<n} A(row0+a,c) A(row0+b,c)

@@ -1,5 +1,6 @@
-"""Time the taper objective (GetNeg2loglikelihoodTaper through the dense factorisation on the device) on a g x g
-grid with a Wendland-1 taper of range delta: python tools/taper_timing.py [g=100] [delta=0.06]."""
+"""Time the taper objective (GetNeg2loglikelihoodTaper through the band-limited dense-tile factorisation on the device)
+on a g x g grid with a Wendland-1 taper of range delta: python tools/taper_timing.py [g=100] [delta=0.06] [cpu].
+The CPU comparison (SuperLU) runs for n <= 12000 or when the third argument is "cpu" (300 s at n = 40000)."""
 import os
 import sys
 import time
@@ -44,6 +45,8 @@ dt = (time.perf_counter() - t0) / K
 print("taper objective: %.3f ms per evaluation (%.1f evals/s), value %.6f" % (1e3 * dt, 1 / dt, v))
 # context: a sparse direct factorisation of the same matrix on this host's CPU (scipy / SuperLU, one thread's worth of
 # work; spam's supernodal Cholesky is not available here and would be roughly 2x cheaper than an LU)
+if n > 12000 and not (len(sys.argv) > 3 and sys.argv[3] == "cpu"):
+    sys.exit(0)
 try:
     import scipy.sparse as sp
     import scipy.sparse.linalg as spl
