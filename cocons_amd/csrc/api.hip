@@ -1028,6 +1028,36 @@ static void dense_collect(cocons_fit *f, double *sum_logliks, double *parts)
 // evaluation overlaps the MFMA-bound updates and the VALU-bound assembly of the others.
 // thetas: nb x (6 p) row-major tables; means: nb x p; values[nb]; status[nb] (0 / k>0 like the
 // single call).  Returns 0 unless a HIP / argument error occurred.
+// A second handle over the same data with its own factorisation buffer and streams: one slot of
+// cocons_neg2loglik_batch.  A taper handle's clone shares nothing on the device (pattern and taper entries are
+// copied device to device) and keeps the order and the envelope of its original.
+static cocons_fit *clone_for_slot(cocons_fit *f)
+{
+    if (f->taper_nnz <= 0)
+        return cocons_fit_create(f->n, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
+                                 f->smooth_limits, f->device);
+    cocons_fit *c = fit_create_impl(f->n, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
+                                    f->smooth_limits, f->device, false);      // h_* of a taper handle are in ITS order
+    if (!c) return nullptr;
+    const size_t nnz = (size_t)f->taper_nnz;
+    bool ok = hipMalloc(&c->d_tci, nnz * sizeof(int)) == hipSuccess &&
+              hipMalloc(&c->d_trp, (size_t)(f->n + 1) * sizeof(int)) == hipSuccess &&
+              hipMalloc(&c->d_tval, nnz * sizeof(double)) == hipSuccess &&
+              hipMalloc(&c->d_tcov, nnz * sizeof(double)) == hipSuccess &&
+              hipMemcpy(c->d_tci, f->d_tci, nnz * sizeof(int), hipMemcpyDeviceToDevice) == hipSuccess &&
+              hipMemcpy(c->d_trp, f->d_trp, (size_t)(f->n + 1) * sizeof(int), hipMemcpyDeviceToDevice) == hipSuccess &&
+              hipMemcpy(c->d_tval, f->d_tval, nnz * sizeof(double), hipMemcpyDeviceToDevice) == hipSuccess;
+    c->taper_hi = new std::vector<int>(*f->taper_hi);
+    c->taper_inv = new std::vector<int>(*f->taper_inv);
+    c->taper_maxband = f->taper_maxband;
+    if (ok && f->d_thi)
+        ok = hipMalloc(&c->d_thi, (size_t)f->nt * sizeof(int)) == hipSuccess &&
+             hipMemcpy(c->d_thi, f->d_thi, (size_t)f->nt * sizeof(int), hipMemcpyDeviceToDevice) == hipSuccess;
+    if (!ok) { cocons_fit_destroy(c); return nullptr; }
+    c->taper_nnz = f->taper_nnz;
+    return c;
+}
+
 extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thetas, const double *means,
                                        double *values, int *status)
 {
@@ -1035,17 +1065,6 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
     if (nb < 0 || (nb > 0 && (!thetas || !means || !values || !status)))
         return fail(-1, "cocons_neg2loglik_batch: bad argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_batch: fit has no z");
-    if (f->taper_nnz > 0) {
-        // taper handle: one evaluation after the other on the handle itself (its pattern is not cloned into slots)
-        for (int i = 0; i < nb; ++i) {
-            double v = NAN;
-            int st = cocons_neg2loglik_dense(f, thetas + (size_t)i * 6 * f->p, means + (size_t)i * f->p, &v, nullptr);
-            if (st < 0) { for (int k = i; k < nb; ++k) { values[k] = NAN; status[k] = -1; } return st; }
-            values[i] = st == 0 ? v : NAN;
-            status[i] = st;
-        }
-        return 0;
-    }
     static int nslots_env = -1;
     if (nslots_env < 0) {
         const char *e = getenv("COCONS_BATCH_SLOTS");
@@ -1059,8 +1078,7 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
     // (lda * npad * 8 bytes: 0.83 GB at n = 10^4); if one cannot be created (out of memory) the
     // batch runs on the slots that exist -- slot 0 is the fit itself, so it always completes
     while ((int)f->slots->size() < S - 1) {
-        cocons_fit *c = cocons_fit_create(f->n, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(),
-                                          f->h_z->data(), nullptr, f->smooth_limits, f->device);
+        cocons_fit *c = clone_for_slot(f);
         if (!c) { (void)hipGetLastError(); break; }
         f->slots->push_back(c);
     }

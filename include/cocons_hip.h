@@ -83,9 +83,9 @@ int cocons_cov_rns_taper_pred(int n, int m, int p, const double *theta, const do
  * returns  sum_k [ n log 2 pi + 2 sum log diag chol(S) + resid_k' S^-1 resid_k ],  S = taper o cov_rns_taper(theta):
  * spam's value, from a DENSE factorisation of S (zeros stored) -- for n^2 doubles within the device's memory.
  * `parts` as for the dense handle (log-det half, quadratic forms), from which the caller forms
- * GetNeg2loglikelihoodTaperProfile (:73-108, with theta$std.dev[1] = 0).  cocons_neg2loglik_batch evaluates its
- * points one after the other on such a handle, cocons_predict_taper is its prediction core; every other fit entry
- * point refuses it.  NULL + cocons_last_error() on failure.                                                */
+ * GetNeg2loglikelihoodTaperProfile (:73-108, with theta$std.dev[1] = 0).  cocons_neg2loglik_batch pipelines its
+ * points over clones of such a handle as for a dense one, cocons_predict_taper is its prediction core; every other
+ * fit entry point refuses it.  NULL + cocons_last_error() on failure.                                                */
 cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double *locs, const double *X, const double *z,
                                     const double *smooth_limits, int device, int nnz, const int *colindices,
                                     const int *rowpointers, const double *taper_entries);

@@ -43,6 +43,17 @@ for _ in range(K):
     v, parts = fit.neg2loglik_core(th)
 dt = (time.perf_counter() - t0) / K
 print("taper objective: %.3f ms per evaluation (%.1f evals/s), value %.6f" % (1e3 * dt, 1 / dt, v))
+nb = 33                                           # one finite-difference gradient of a 16-parameter model
+tls = []
+for i in range(nb):
+    t2 = {k: np.array(v, dtype=float) for k, v in th.items()}
+    t2["std.dev"][0] += 1e-3 * i
+    tls.append(t2)
+fit.neg2loglik_batch_core(tls[:4])
+t0 = time.perf_counter()
+vals, st = fit.neg2loglik_batch_core(tls)
+dtb = time.perf_counter() - t0
+print("batch of %d independent evaluations: %.1f evals/s (all ok: %s)" % (nb, nb / dtb, bool(np.all(st == 0))))
 # context: a sparse direct factorisation of the same matrix on this host's CPU (scipy / SuperLU, one thread's worth of
 # work; spam's supernodal Cholesky is not available here and would be roughly 2x cheaper than an LU)
 if n > 12000 and not (len(sys.argv) > 3 and sys.argv[3] == "cpu"):
