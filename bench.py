@@ -280,6 +280,42 @@ def main():
         dtb = time.perf_counter() - t1
         batch = {"evals": nbatch, "evals_per_s": round(nbatch / dtb, 4), "all_ok": bool((bs == 0).all())}
 
+    # extra (N=1, n = 10^4 only): the taper objective (GetNeg2loglikelihoodTaper, type = "sparse") of the same grid with a
+    # Wendland-1 taper of range 0.06 (~104 neighbours per row) through the band-limited factorisation; a supplementary
+    # number, never `value`
+    taper = None
+    if world == 1 and n == 10000 and args.inflight > 1:
+        try:
+            delta = 0.06
+            cell = {}
+            for i, (x, y) in enumerate(locs):
+                cell.setdefault((int(x / delta), int(y / delta)), []).append(i)
+            ci, rp, ent = [], [1], []
+            for i, (x, y) in enumerate(locs):
+                cx, cy = int(x / delta), int(y / delta)
+                cand = np.array(sorted(j for a in (-1, 0, 1) for b in (-1, 0, 1) for j in cell.get((cx + a, cy + b), [])))
+                d = np.sqrt(np.sum((locs[cand] - locs[i]) ** 2, axis=1))
+                keep = d <= delta
+                h = d[keep] / delta
+                ci.extend((cand[keep] + 1).tolist())
+                ent.extend(((1 - h) ** 4 * (4 * h + 1)).tolist())
+                rp.append(len(ci) + 1)
+            tfit = ca.CoconsTaperFit(locs, X, z, wl.SMOOTH_LIMITS, np.array(ci, dtype=np.int32),
+                                     np.array(rp, dtype=np.int32), np.array(ent), device=local_rank)
+            for _ in range(3):
+                tv, _ = tfit.neg2loglik_core(th)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                tv, _ = tfit.neg2loglik_core(th)
+            torch.cuda.synchronize()
+            dtt = (time.perf_counter() - t1) / args.steps
+            taper = {"workload": "GetNeg2loglikelihoodTaper, same grid, Wendland-1 taper delta=0.06", "nnz": len(ci),
+                     "ms_per_eval": round(1e3 * dtt, 4), "evals_per_s": round(1.0 / dtt, 3), "neg2loglik": tv}
+            tfit.close()
+        except Exception as e:                          # noqa: BLE001 -- supplementary: reported, not fatal
+            taper = {"error": repr(e)}
+
     out = None
     if rank == 0:
         # stage timings and the dominant kernel's roofline come from THIS run: HIP events on the launch
@@ -347,6 +383,7 @@ def main():
             "neg2loglik": val,
             "throughput_inflight": inflight,
             "throughput_batch_api": batch,
+            "taper_path": taper,
             "replica_mode": replica,
             "parity_rel_err_vs_cpu": parity,
             "roofline": roofline,
