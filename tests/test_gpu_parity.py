@@ -324,6 +324,46 @@ def test_ragged_sizes_all_entry_points(oracle, n):
         assert np.allclose(qf, np.sum(Cw * sol.T, axis=1), rtol=1e-8, atol=1e-12)
 
 
+def test_widest_design_matrix(oracle):
+    """p = COCONS_P_MAX = 32 covariates in every aspect (the widest design the ABI takes): entries, the prediction
+    cross-covariance, the objective and the taper entries against the CPU restatement; p = 33 is refused."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n, p = 300, 32
+    rng = np.random.default_rng(3232)
+    locs = rng.uniform(0, 1, size=(n, 2))
+    X = np.column_stack([np.ones(n)] + [rng.standard_normal(n) * 0.3 for _ in range(p - 1)])
+    sm = 0.03
+    th = {"mean": rng.standard_normal(p) * 0.1,
+          "std.dev": np.r_[0.1, rng.standard_normal(p - 1) * sm],
+          "scale": np.r_[np.log(0.3), rng.standard_normal(p - 1) * sm],
+          "aniso": np.r_[0.0, rng.standard_normal(p - 1) * sm],
+          "tilt": np.r_[0.1, rng.standard_normal(p - 1) * sm],
+          "smooth": np.r_[0.2, rng.standard_normal(p - 1) * sm],
+          "nugget": np.r_[np.log(0.05), rng.standard_normal(p - 1) * sm]}
+    want = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    assert _relerr(ca.cov_rns(th, locs, X, wl.SMOOTH_LIMITS), want) < ENTRY_RTOL
+    m = 40
+    lp = rng.uniform(0, 1, size=(m, 2))
+    Xp = np.column_stack([np.ones(m)] + [rng.standard_normal(m) * 0.3 for _ in range(p - 1)])
+    assert _relerr(ca.cov_rns_pred(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS),
+                   oracle.cov_rns_pred(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS)) < ENTRY_RTOL
+    z = rng.standard_normal(n)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    val, parts = fit.neg2loglik_core(th)
+    info, ld, quad, _ = oracle.chol_ld(want, (z - X @ th["mean"])[:, None])
+    assert info == 0
+    truth = n * np.log(2 * np.pi) + 2 * ld + quad[0]
+    assert abs(val - truth) <= 1e-9 * abs(truth)
+    ci, rp = _csr_within(locs, locs, 0.2)
+    assert _relerr(ca.cov_rns_taper(th, locs, X, ci, rp, wl.SMOOTH_LIMITS),
+                   oracle.cov_rns_taper(th, locs, X, ci, rp, wl.SMOOTH_LIMITS)) < ENTRY_RTOL
+    X33 = np.column_stack([X, rng.standard_normal(n)])
+    th33 = {k: np.r_[v, 0.0] for k, v in th.items()}
+    with pytest.raises(ValueError, match="up to 32"):
+        ca.cov_rns(th33, locs, X33, wl.SMOOTH_LIMITS)
+
+
 def test_handle_refuses_use_after_fork():
     """cocoOptim forks its workers (R/optim.R:117-121); a HIP context does not survive fork, so a
     handle created in the parent must be refused in the child (before any HIP call)."""
