@@ -245,7 +245,7 @@ struct cocons_fit {
     // -2 log-likelihood is then that of the TAPERED covariance, evaluated through the dense factorisation
     int taper_nnz;                // > 0: taper fit
     int *d_tci, *d_trp;
-    double *d_tval, *d_tcov;      // taper entries (constant), covariance entries of the current theta
+    double *d_tval;               // taper entries (constant)
     std::vector<int> *taper_hi;   // envelope of the (reordered) pattern per tile column: see FactorView::hi
     int *d_thi; int taper_maxband; // device copy of taper_hi and max_c (hi[c] - c)
     std::vector<int> *taper_inv;  // position of the caller's observation i in the handle's order (reverse Cuthill-McKee)
@@ -305,7 +305,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
         if (f->ev_eng) hipEventDestroy(f->ev_eng);
         hipFree(f->dflags);
-        hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_tcov); hipFree(f->d_thi);
+        hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_thi);
         if (f->cstream) { hipStreamSynchronize(f->cstream); hipStreamDestroy(f->cstream); }
         for (auto &e : f->ev_main) if (e) hipEventDestroy(e);
         for (auto &e : f->ev_comm) if (e) hipEventDestroy(e);
@@ -597,7 +597,6 @@ extern "C" cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double
     bool ok = hipMalloc(&f->d_tci, (size_t)nnz * sizeof(int)) == hipSuccess &&
               hipMalloc(&f->d_trp, (size_t)(n + 1) * sizeof(int)) == hipSuccess &&
               hipMalloc(&f->d_tval, (size_t)nnz * sizeof(double)) == hipSuccess &&
-              hipMalloc(&f->d_tcov, (size_t)nnz * sizeof(double)) == hipSuccess &&
               hipMemcpy(f->d_tci, pci.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(f->d_trp, prp.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(f->d_tval, pte.data(), (size_t)nnz * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
@@ -688,8 +687,8 @@ static int assemble_sigma_taper(cocons_fit *f, const double *theta)
     if (f->d_thi) launch_band_zero(f->dA, f->lda, f->d_thi, f->nt, f->taper_maxband, f->stream);
     else HIPCHK(hipMemsetAsync(f->dA, 0, f->lda * (size_t)f->npad * sizeof(double), f->stream));
     launch_taper(ms.mode, false, f->n, f->taper_nnz, f->d_tci, f->d_trp, f->dloc, f->npad, f->dloc, f->npad,
-                 ms.nu_fixed, f->d_tcov, f->stream);
-    launch_taper_scatter(f->n, f->npad, f->d_trp, f->d_tci, f->d_tcov, f->d_tval, f->dA, f->lda, f->stream);
+                 ms.nu_fixed, nullptr, f->stream, f->d_tval, f->dA, f->lda, 0);
+    launch_pad_identity(f->dA, f->lda, f->n, f->npad, f->stream);
     return 0;
 }
 
@@ -1061,7 +1060,6 @@ static cocons_fit *clone_for_slot(cocons_fit *f)
     bool ok = hipMalloc(&c->d_tci, nnz * sizeof(int)) == hipSuccess &&
               hipMalloc(&c->d_trp, (size_t)(f->n + 1) * sizeof(int)) == hipSuccess &&
               hipMalloc(&c->d_tval, nnz * sizeof(double)) == hipSuccess &&
-              hipMalloc(&c->d_tcov, nnz * sizeof(double)) == hipSuccess &&
               hipMemcpy(c->d_tci, f->d_tci, nnz * sizeof(int), hipMemcpyDeviceToDevice) == hipSuccess &&
               hipMemcpy(c->d_trp, f->d_trp, (size_t)(f->n + 1) * sizeof(int), hipMemcpyDeviceToDevice) == hipSuccess &&
               hipMemcpy(c->d_tval, f->d_tval, nnz * sizeof(double), hipMemcpyDeviceToDevice) == hipSuccess;
@@ -1616,7 +1614,7 @@ extern "C" int cocons_predict_taper(cocons_fit *f, const double *theta, const do
     if (int rc = fit_alloc_matrix(f, m + 1)) return rc;
     hipStream_t s = f->stream;
     int *dci = nullptr, *drp = nullptr;
-    double *dtv = nullptr, *dcv = nullptr;
+    double *dtv = nullptr;
     const size_t nz = nnz_pred > 0 ? (size_t)nnz_pred : 1;
     int st = 0;
     do {
@@ -1624,7 +1622,6 @@ extern "C" int cocons_predict_taper(cocons_fit *f, const double *theta, const do
         CKP(hipMalloc(&dci, nz * sizeof(int)));
         CKP(hipMalloc(&drp, (size_t)(m + 1) * sizeof(int)));
         CKP(hipMalloc(&dtv, nz * sizeof(double)));
-        CKP(hipMalloc(&dcv, nz * sizeof(double)));
         CKP(hipMemcpyAsync(f->dXp, X_pred, (size_t)m * p * sizeof(double), hipMemcpyHostToDevice, s));
         CKP(hipMemcpyAsync(f->dlocsp, locs_pred, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
         CKP(hipMemcpyAsync(drp, rowpointers_pred, (size_t)(m + 1) * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1661,8 +1658,8 @@ extern "C" int cocons_predict_taper(cocons_fit *f, const double *theta, const do
             LocArgs lo = lp;
             lo.n = n; lo.X = f->dX; lo.ldx = n; lo.locs = f->dlocs; lo.ldl = n; lo.out = f->dloc; lo.stride = f->npad;
             launch_loc_params(lo, s);                                   // (after the entries of S were computed: stream order)
-            launch_taper(MODE_GEOM, true, m, nnz_pred, dci, drp, f->dlocp, m, f->dloc, f->npad, 0.0, dcv, s);
-            if (nnz_pred > 0) launch_taper_scatter_rows(m, drp, dci, dcv, dtv, f->dA, f->lda, f->npad + 1, s);
+            launch_taper(MODE_GEOM, true, m, nnz_pred, dci, drp, f->dlocp, m, f->dloc, f->npad, 0.0, nullptr, s,
+                         dtv, f->dA, f->lda, f->npad + 1);
             factorize(f, main_view(f), nullptr);
             launch_row_reduce(f->dA, f->lda, n, f->npad, f->npad + 1, m, f->dstoch, f->dquad, f->dred, s);
             hipMemcpyAsync(stochastic, f->dstoch, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s);
@@ -1677,7 +1674,7 @@ extern "C" int cocons_predict_taper(cocons_fit *f, const double *theta, const do
         }
     } while (0);
     hipStreamSynchronize(s);
-    hipFree(dci); hipFree(drp); hipFree(dtv); hipFree(dcv);
+    hipFree(dci); hipFree(drp); hipFree(dtv);
     return st;
 }
 

@@ -215,6 +215,10 @@ struct TaperArgs {
     const double *cols; size_t stride;        // SoA of the column side (observations)
     double nu_fixed;
     double *out;
+    // dense target (taper handles): A != nullptr => the entry times its taper value goes straight into the
+    // factorisation buffer instead of out[] -- the lower triangle A(ii, jj), jj <= ii, of the symmetric pattern (the
+    // upper entries are not even evaluated), or, PRED, row row0 + ii of the rows under the matrix
+    const double *tapv; double *A; size_t lda; int row0;
 };
 
 template <int MODE, bool PRED>
@@ -229,19 +233,23 @@ taper_kernel(TaperArgs a)
         if (a.rp[mid] - 1 <= w) lo = mid; else hi = mid - 1;
     }
     const int ii = lo, jj = a.ci[w] - 1;
+    if (a.A && !PRED && jj > ii) return;
     double v;
     if (!PRED && ii == jj) v = a.rows[ii + 11 * a.stride_rows];
     else v = taper_value_idx<MODE, PRED>(a.rows, a.stride_rows, ii, a.cols, a.stride, jj, a.nu_fixed);
-    a.out[w] = v;
+    if (a.A) a.A[(size_t)((PRED ? a.row0 : 0) + ii) + (size_t)jj * a.lda] = a.tapv[w] * v;
+    else a.out[w] = v;
 }
 
 void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const int *rp, const double *rows,
-                  size_t stride_rows, const double *cols, size_t stride, double nu_fixed, double *out, hipStream_t s)
+                  size_t stride_rows, const double *cols, size_t stride, double nu_fixed, double *out, hipStream_t s,
+                  const double *tapv, double *A, size_t lda, int row0)
 {
     if (nnz <= 0) return;
     TaperArgs a;
     a.nrows = nrows; a.nnz = nnz; a.ci = ci; a.rp = rp; a.rows = rows; a.stride_rows = stride_rows;
     a.cols = cols; a.stride = stride; a.nu_fixed = nu_fixed; a.out = out;
+    a.tapv = tapv; a.A = A; a.lda = lda; a.row0 = row0;
     dim3 g((nnz + 255) / 256), b(256);
     if (pred) { hipLaunchKernelGGL((taper_kernel<MODE_GEOM, true>), g, b, 0, s, a); return; }
     switch (mode) {
@@ -249,22 +257,6 @@ void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const 
     case MODE_THREEHALF: hipLaunchKernelGGL((taper_kernel<MODE_THREEHALF, false>), g, b, 0, s, a); break;
     case MODE_FIVEHALF: hipLaunchKernelGGL((taper_kernel<MODE_FIVEHALF, false>), g, b, 0, s, a); break;
     default: hipLaunchKernelGGL((taper_kernel<MODE_GEOM, false>), g, b, 0, s, a); break;
-    }
-}
-
-// Tapered covariance written into the dense factorisation buffer (the buffer is zero when this runs): stored
-// entry w of row i (1-based CSR as spam keeps it) goes to the lower triangle, A(i,j) = taper[w] * cov[w] for
-// i >= j; the strictly upper entries of the (symmetric) pattern are skipped.  One thread per row, and the
-// identity on the padding diagonal n .. npad-1.
-__global__ void taper_scatter_kernel(int n, int npad, const int *rp, const int *ci, const double *cov,
-                                     const double *taper, double *A, size_t lda)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npad) return;
-    if (i >= n) { A[(size_t)i + (size_t)i * lda] = 1.0; return; }
-    for (int w = rp[i] - 1; w < rp[i + 1] - 1; ++w) {
-        const int j = ci[w] - 1;
-        if (j <= i) A[(size_t)i + (size_t)j * lda] = taper[w] * cov[w];
     }
 }
 
@@ -287,26 +279,16 @@ void launch_band_zero(double *A, size_t lda, const int *d_hi, int nt, int max_ba
     hipLaunchKernelGGL(band_zero_kernel, dim3(nt, max_band), dim3(256), 0, s, A, lda, d_hi, nt);
 }
 
-// Tapered cross-covariance rows under the matrix: stored entry w of prediction row i goes to A(row0 + i, j).
-// (The rows are zero when this runs.)  One thread per prediction location.
-__global__ void taper_scatter_rows_kernel(int m, const int *rp, const int *ci, const double *cov, const double *taper,
-                                          double *A, size_t lda, int row0)
+// identity on the padding diagonal n .. npad-1 of a taper handle's buffer (its tiles were zeroed)
+__global__ void pad_identity_kernel(double *A, size_t lda, int n, int npad)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    for (int w = rp[i] - 1; w < rp[i + 1] - 1; ++w) A[(size_t)(row0 + i) + (size_t)(ci[w] - 1) * lda] = taper[w] * cov[w];
+    const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) A[(size_t)i + (size_t)i * lda] = 1.0;
 }
 
-void launch_taper_scatter_rows(int m, const int *rp, const int *ci, const double *cov, const double *taper, double *A,
-                               size_t lda, int row0, hipStream_t s)
+void launch_pad_identity(double *A, size_t lda, int n, int npad, hipStream_t s)
 {
-    hipLaunchKernelGGL(taper_scatter_rows_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, rp, ci, cov, taper, A, lda, row0);
-}
-
-void launch_taper_scatter(int n, int npad, const int *rp, const int *ci, const double *cov, const double *taper,
-                          double *A, size_t lda, hipStream_t s)
-{
-    hipLaunchKernelGGL(taper_scatter_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, n, npad, rp, ci, cov, taper, A, lda);
+    if (npad > n) hipLaunchKernelGGL(pad_identity_kernel, dim3((npad - n + 255) / 256), dim3(256), 0, s, A, lda, n, npad);
 }
 
 // Selected rows of the dense covariance (or of cov2cor of it) without ever forming the n x n matrix: what

@@ -70,15 +70,13 @@ void launch_pair_rect(int mode, const PairArgs &a, hipStream_t s);
 void launch_rhs_rows(const RhsArgs &a, hipStream_t s);
 // entries of the sparse/taper covariance for a CSR pattern (1-based indices, device arrays)
 void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const int *rp, const double *rows,
-                  size_t stride_rows, const double *cols, size_t stride, double nu_fixed, double *out, hipStream_t s);
+                  size_t stride_rows, const double *cols, size_t stride, double nu_fixed, double *out, hipStream_t s,
+                  const double *tapv = nullptr, double *A = nullptr, size_t lda = 0, int row0 = 0);   // A: dense target, see TaperArgs
 // rows idx[0..nidx) of the dense covariance (cor != 0: of cov2cor of it); out row b at out + b * n
 // zero the tiles inside the envelope (d_hi: device copy of FactorView::hi; max_band = max over c of hi[c] - c)
 void launch_band_zero(double *A, size_t lda, const int *d_hi, int nt, int max_band, hipStream_t s);
-void launch_taper_scatter_rows(int m, const int *rp, const int *ci, const double *cov, const double *taper, double *A,
-                               size_t lda, int row0, hipStream_t s);
-// dense lower-triangular image of a tapered covariance from its CSR entries (see taper_scatter_kernel)
-void launch_taper_scatter(int n, int npad, const int *rp, const int *ci, const double *cov, const double *taper,
-                          double *A, size_t lda, hipStream_t s);
+// identity on the padding diagonal of a taper handle's buffer
+void launch_pad_identity(double *A, size_t lda, int n, int npad, hipStream_t s);
 void launch_cov_rows(int mode, int n, int nidx, const int *idx, const double *loc, size_t stride, double gr,
                      double nu_fixed, int cor, double *out, hipStream_t s);
 // out[i] = 2^(1-nu)/Gamma(nu) u^nu K_nu(u) by the device routine of the pair kernels (diagnostic)
