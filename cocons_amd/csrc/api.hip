@@ -594,6 +594,18 @@ extern "C" cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double
             for (int c = 0; c < f->nt; ++c) if (hi[c] - c > f->taper_maxband) f->taper_maxband = hi[c] - c;
         }
     }
+    // the device keeps the lower triangle of the pattern only (the upper half is never evaluated)
+    {
+        int w2 = 0;
+        for (int i = 0; i < n; ++i) {
+            const int a0 = prp[i] - 1, a1 = prp[i + 1] - 1;
+            prp[i] = w2 + 1;
+            for (int w = a0; w < a1; ++w)
+                if (pci[w] - 1 <= i) { pci[w2] = pci[w]; pte[w2] = pte[w]; ++w2; }
+        }
+        prp[n] = w2 + 1;
+        nnz = w2;
+    }
     bool ok = hipMalloc(&f->d_tci, (size_t)nnz * sizeof(int)) == hipSuccess &&
               hipMalloc(&f->d_trp, (size_t)(n + 1) * sizeof(int)) == hipSuccess &&
               hipMalloc(&f->d_tval, (size_t)nnz * sizeof(double)) == hipSuccess &&
