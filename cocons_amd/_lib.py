@@ -65,10 +65,7 @@ SIGNATURES = {
     "cocons_sim_cond_dense": (c_int, [c_vp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_dp, c_int, c_dp, c_dp]),
     "cocons_chol_solve": (c_int, [c_int, c_dp, c_int, c_dp, c_dp, c_dp, c_dp]),
     "cocons_fit_profile": (c_int, [c_vp, c_dp, c_dp, c_int, c_dp]),
-    "cocons_mfma_f64_probe": (c_int, [c_int, c_dp]),
-    "cocons_mfma_f64_probe_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_dp]),
-    "cocons_vfma_f64_probe": (c_int, [c_int, c_dp]),
-    "cocons_debug_matern": (c_int, [c_int, c_dp, c_dp, c_dp]),
+    "cocons_fit_engine_state": (c_int, [c_vp, ctypes.POINTER(c_int)]),
     "cocons_comm_unique_id": (c_int, [c_vp]),
     "cocons_fit_comm_init": (c_int, [c_vp, c_int, c_int, c_vp]),
     "cocons_fit_set_collectives": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -92,6 +89,16 @@ SIGNATURES = {
 }
 
 
+# every symbol include/cocons_hip_diag.h declares (probes and pointwise diagnostics: not the drop-in boundary)
+DIAG_SIGNATURES = {
+    "cocons_mfma_f64_probe": (c_int, [c_int, c_dp]),
+    "cocons_mfma_f64_probe_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_dp]),
+    "cocons_vfma_f64_probe": (c_int, [c_int, c_dp]),
+    "cocons_debug_matern": (c_int, [c_int, c_dp, c_dp, c_dp]),
+    "cocons_corun_probe": (c_int, [c_int, c_int, c_int, c_int, c_dp]),
+}
+
+
 def load():
     """Load the HIP library (no HIP call is made by loading it)."""
     global _lib
@@ -101,7 +108,7 @@ def load():
                 "HIP extension not built: %s is missing (run __graft_entry__.build() or "
                 "`make -C cocons_amd/csrc`); there is no CPU fallback" % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(DIAG_SIGNATURES.items()):
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

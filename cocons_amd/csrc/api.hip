@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "../../include/cocons_hip_diag.h"
 #include "matern_device.hpp"   // PairMode, LOCP_FIELDS (host-visible enums)
 
 using namespace cocons;
@@ -239,8 +240,14 @@ struct cocons_fit {
     unsigned *dflags;             // flags_cap words each: in[t], out[t], xr[t] (see launch_potrf_engine); 64: the alive word;
                                   // flags_cap: tile counters of the trailing updates
     int flags_cap;
-    bool engine_ok;               // false: plain schedule (batch slots; or after a hand-off timed out)
+    bool engine_ok;               // false: this handle never uses the resident engine (batch slots, band-limited taper fits)
     bool engine_live;             // the engine of the NEXT factorize call is already launched (engine_start)
+    bool engine_used;             // the factorisation enqueued last runs on the engine schedule
+    bool engine_active_last;      // the last COMPLETED operation ran on the engine schedule (cocons_fit_engine_state)
+    int engine_skip;              // operations still to run on the plain schedule after a hand-off timed out (back-off)
+    int engine_fails;             // consecutive time-outs (the back-off doubles with each, up to 64 operations)
+    int engine_retries;           // time-outs in the life of the handle, each answered by one repeat on the plain schedule
+    int engine_last_abort;        // abort word of the last time-out (who gave up: see info_status)
     // taper fit (cocons_fit_create_taper): the spam pattern (1-based CSR) with the taper's entries; the
     // -2 log-likelihood is then that of the TAPERED covariance, evaluated through the dense factorisation
     int taper_nnz;                // > 0: taper fit
@@ -287,6 +294,10 @@ static int fit_alloc_matrix(cocons_fit *f, int rhs_rows)
     f->rhs_cap = cap;
     f->lda = (size_t)f->npad + cap;
     HIPCHK(hipMalloc(&f->dA, f->lda * (size_t)f->npad * sizeof(double)));
+    // never-written parts must not hold NaN bit patterns: a band-limited factorisation only clears its envelope, and
+    // 0 * garbage must stay 0 whatever the allocator hands back
+    HIPCHK(hipMemsetAsync(f->dA, 0, f->lda * (size_t)f->npad * sizeof(double), f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
     return 0;
 }
 
@@ -809,15 +820,16 @@ static void timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int 
     const int hb = band_hi(v, k);                       // band-limited: tile columns and rows [t0, hb), plus the rows [nt, mt)
     if (hb >= 0 && hb < t1) t1 = hb;
     if (t1 <= t0) return;
+    unsigned *abort_word = sig ? (unsigned *)(f->dinfo + 1) : nullptr;   // engine schedule: see update_kernel
     if (ev_upd) {
         hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a, s);
-        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, nullptr, queue, hb, v.nt);
+        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, abort_word, queue, hb, v.nt);
         hipEventRecord(b, s);
         ev_upd->push_back(a); ev_upd->push_back(b);
     } else {
-        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, nullptr, queue, hb, v.nt);
+        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, abort_word, queue, hb, v.nt);
     }
 }
 
@@ -838,7 +850,10 @@ static void count_update_flops(cocons_fit *f, int kw, int t0)
 // reports itself resident.
 // (Launched between the assembly and the first trailing update it could lose that race and then wait for
 // a whole update to drain; with workgroups that wait for the engine on every CU it would never be placed.)
-static bool engine_wanted(cocons_fit *f, const FactorView &v) { return engine_enabled() && f->engine_ok && v.nt > 4; }
+static bool engine_wanted(cocons_fit *f, const FactorView &v)
+{
+    return engine_enabled() && f->engine_ok && f->engine_skip == 0 && v.nt > 4;
+}
 
 // the hand-off words and tile counters of one factorisation with nt tiles, zeroed on the main stream
 static int flags_reset(cocons_fit *f, int nt)
@@ -898,13 +913,16 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     const int nt = v.nt, mt = v.mt;
     hipStream_t M = f->stream;
     if (!engine_wanted(f, v)) {
+        f->engine_used = false;
         if (int rc = flags_reset(f, nt)) return rc;
         if (v.hi) {
             // band-limited: one tile column per step (factor, solve, update with K = 128) -- inside a narrow envelope
             // the in-panel update of the two-tile block costs more than the second, cheaper trailing update
             // (4.71 -> 4.53 ms at n = 10^4)
+            // (row bound = the column's OWN envelope hi[k] -- per 256-block, monotone, >= k + 1 --, not band_hi(): for an
+            // odd k that is the NEXT block's bound, beyond what band_zero_kernel clears in column k)
             for (int k = 0; k < nt; ++k) {
-                const int hb = band_hi(v, k);
+                const int hb = v.hi[k] < nt ? v.hi[k] : nt;
                 double *q = f->dinv + (size_t)(k & 1) * 2048;
                 launch_potrf_tile(v.A, v.lda, k * TILE, q, f->dinfo, M);
                 launch_trsm_tile(v.A, v.lda, k * TILE, (k + 1) * TILE, mt * TILE, q, M, nullptr, nullptr, hb * TILE, nt * TILE);
@@ -925,6 +943,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     }
     if (int rc = engine_start(f, v)) return rc;          // no-op when enqueue_eval started it before the assembly
     f->engine_live = false;
+    f->engine_used = true;
     unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
     unsigned *abort_word = (unsigned *)(f->dinfo + 1);
     launch_engine_gate(f->dflags + 3 * (size_t)f->flags_cap, abort_word, M);
@@ -993,6 +1012,10 @@ static int info_status(cocons_fit *f)
         fprintf(stderr, "cocons: hand-off time-out, code 0x%x\n", f->hinfo[1]);
     if (f->hinfo[1] != 0)
         return fail(ENGINE_ABORT, "hand-off between the diagonal-tile engine and the main stream timed out");
+    // the operation ran to its end on the schedule factorize chose: book-keeping of the engine's back-off
+    f->engine_active_last = f->engine_used;
+    if (f->engine_used) f->engine_fails = 0;
+    else if (f->engine_skip > 0) --f->engine_skip;
     int info = f->hinfo[0];
     if (info != 0x7f7f7f7f) {
         if (info > f->n) info = f->n;   // failure reported inside the identity padding cannot happen; clamp anyway
@@ -1002,16 +1025,32 @@ static int info_status(cocons_fit *f)
     return 0;
 }
 
-// The engine could not be scheduled in time (another process or stream kept every CU busy, or a
-// profiler serialises kernels): this fit falls back to the plain schedule for good and the caller
-// repeats the operation once.
+// The engine could not be scheduled in time, or one of its partners could not (another process or stream kept
+// every CU busy, or a profiler serialises kernels): the caller repeats THIS operation once on the plain schedule;
+// the handle stays on it for a few more operations (2, 4, ... 64 with consecutive time-outs) and then tries the
+// engine again.  Every time-out is counted (cocons_fit_engine_state).
 static bool engine_retry(cocons_fit *f, int st)
 {
-    if (st != ENGINE_ABORT || !f->engine_ok) return false;
-    f->engine_ok = false;
+    if (st != ENGINE_ABORT || !f->engine_used) return false;
+    f->engine_retries++;
+    f->engine_last_abort = f->hinfo[1];
+    if (f->engine_fails < 6) f->engine_fails++;
+    f->engine_skip = 1 << f->engine_fails;
     f->engine_live = false;
+    f->engine_used = false;
     hipStreamSynchronize(f->stream2);
     return true;
+}
+
+// out[0] = 1 if the last completed operation of the handle ran on the engine schedule, out[1] = hand-off time-outs
+// so far (each was followed by a repeat on the plain schedule), out[2] = abort code of the last one (0 = none)
+extern "C" int cocons_fit_engine_state(cocons_fit *f, int *out)
+{
+    if (!f || !out) return fail(-1, "cocons_fit_engine_state: null argument");
+    out[0] = f->engine_active_last ? 1 : 0;
+    out[1] = f->engine_retries;
+    out[2] = f->engine_last_abort;
+    return 0;
 }
 
 static const double LOG_2PI = 1.8378770664093454835606594728112;
@@ -1083,6 +1122,7 @@ static cocons_fit *clone_for_slot(cocons_fit *f)
              hipMemcpy(c->d_thi, f->d_thi, (size_t)f->nt * sizeof(int), hipMemcpyDeviceToDevice) == hipSuccess;
     if (!ok) { cocons_fit_destroy(c); return nullptr; }
     c->taper_nnz = f->taper_nnz;
+    c->engine_ok = f->engine_ok;              // a band-limited handle never uses the engine, nor do its clones
     return c;
 }
 
@@ -1132,6 +1172,12 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
         pending[s] = -1;
         HIPCHK(hipStreamSynchronize(c->stream));
         int st = info_status(c);
+        if (engine_retry(c, st)) {           // hand-off time-out: this evaluation again, on the plain schedule
+            if (int rc = enqueue_eval(c, thetas + (size_t)i * tp, means + (size_t)i * f->p, true, nullptr, 0, nullptr, false))
+                return rc;
+            HIPCHK(hipStreamSynchronize(c->stream));
+            st = info_status(c);
+        }
         status[i] = st;
         if (st == 0) dense_collect(c, &values[i], nullptr);
         else values[i] = NAN;

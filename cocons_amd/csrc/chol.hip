@@ -393,7 +393,9 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
 // Every spin is bounded: after ENGINE_TIMEOUT_TICKS of the 100 MHz constant clock the waiter sets the
 // abort word and every party leaves; the host then repeats the factorisation on the plain schedule
 // instead of hanging the GPU.  A legitimate wait lasts at most one trailing-update launch (< 1 ms).
-#define ENGINE_TIMEOUT_TICKS 25000000ull    // 250 ms
+#define ENGINE_TIMEOUT_TICKS 10000000ull    // 100 ms
+#define GATE_TIMEOUT_TICKS 500000ull        // 5 ms: the engine is resident within microseconds or -- every CU taken by
+                                            // someone else's kernels -- not for a long while
 
 __device__ __forceinline__ void signal_add(unsigned *word)
 {
@@ -407,13 +409,14 @@ __device__ __forceinline__ void signal_add(unsigned *word)
 // load_wt only
 // code: what the abort word is set to on a time-out (who gave up: diagnostic, any non-zero value aborts)
 template <bool ACQUIRE = true>
-__device__ __forceinline__ bool wait_ge(unsigned *word, unsigned need, unsigned *abort_word, unsigned code = 1u)
+__device__ __forceinline__ bool wait_ge(unsigned *word, unsigned need, unsigned *abort_word, unsigned code = 1u,
+                                        unsigned long long ticks = ENGINE_TIMEOUT_TICKS)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
         if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > ENGINE_TIMEOUT_TICKS) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) {
             __hip_atomic_store(abort_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -535,7 +538,7 @@ potrf_engine_kernel(EngineArgs e)
 __global__ void __launch_bounds__(64)
 engine_gate_kernel(unsigned *alive, unsigned *abort_word)
 {
-    if (threadIdx.x == 0) (void)wait_ge<false>(alive, 1u, abort_word, 0x600u);
+    if (threadIdx.x == 0) (void)wait_ge<false>(alive, 1u, abort_word, 0x600u, GATE_TIMEOUT_TICKS);
 }
 
 // ---------------------------------------------------------------------------
@@ -635,6 +638,14 @@ update_kernel(UpdArgs a)
         const unsigned ok = *share;
         __syncthreads();
         if (!ok) return;
+    }
+
+    else if (a.abort_word) {   // engine schedule, nothing to wait for: leave at once when the factorisation was given up
+        if (tid == 0) *share = __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned ab = *share;
+        __syncthreads();
+        if (ab) return;
     }
 
     const int nch = a.K / KC;

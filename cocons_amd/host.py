@@ -320,6 +320,13 @@ class CoconsFit:
                                                  E.shape[1], _p(E), _p(out)), "cocons_sim_cond_dense")
         return out
 
+    def engine_state(self):
+        """{"active": last completed operation ran on the engine schedule, "retries": hand-off time-outs so far (each
+        repeated once on the plain schedule), "last_abort": code of the last one} -- cocons_fit_engine_state."""
+        out = (ctypes.c_int * 3)()
+        _lib.check(self._L.cocons_fit_engine_state(self._h, out), "cocons_fit_engine_state")
+        return {"active": bool(out[0]), "retries": int(out[1]), "last_abort": int(out[2])}
+
     def profile_stages(self, theta_list, reps=3):
         """Stage timings (ms) from HIP events on the fit's stream; see cocons_fit_profile."""
         T = theta_table(theta_list)

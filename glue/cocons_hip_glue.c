@@ -61,10 +61,13 @@ static cocons_fit *fit_of(SEXP ptr)
 
 static SEXP status_value(int rc, SEXP value)     /* list(status, value) */
 {
+    /* `value` may be a fresh, unprotected allocation of the caller (Rf_ScalarReal(val)): protect it here, before
+     * the list is allocated -- that allocation can run the collector */
+    PROTECT(value);
     SEXP out = PROTECT(Rf_allocVector(VECSXP, 2));
-    SET_VECTOR_ELT(out, 0, Rf_ScalarInteger(rc));
     SET_VECTOR_ELT(out, 1, value);
-    UNPROTECT(1);
+    SET_VECTOR_ELT(out, 0, Rf_ScalarInteger(rc));
+    UNPROTECT(2);
     return out;
 }
 

@@ -203,25 +203,13 @@ int cocons_chol_solve(int n, const double *A, int nrhs, const double *rhs,
 int cocons_fit_profile(cocons_fit *fit, const double *theta, const double *mean,
                        int reps, double *ms);
 
-/* fp64 MFMA issue-rate probe: back-to-back v_mfma_f64_16x16x4_f64 on every SIMD with
- * `blocks_per_cu` 256-thread workgroups per CU; returns the sustained TFLOP/s.  Evidence
- * for the roofline peak the update kernel is priced against. */
-int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops);
-/* Extended probe: nacc (4 / 8 / 16) independent accumulators per wave, form 0 = v_mfma_f64_16x16x4_f64,
- * 1 = v_mfma_f64_4x4x4_4b_f64, 3 = the 4x4x4 form with sixteen accumulators fed from eight DISTINCT operand
- * registers (nacc ignored); `reps` bursts of `iters` loop iterations separated by idle gaps of gap_us
- * (0 = back to back).  out4[0] = TFLOP/s inside the bursts, [1] = clock the chip held inside the kernel
- * in GHz (s_memtime / s_memrealtime), [2] = shader cycles per MFMA instruction per wave, [3] = mean
- * burst duration in ms.  Tells issue rate per clock apart from the clock the chip sustains under load. */
-int cocons_mfma_f64_probe_ex(int blocks_per_cu, int nacc, int form, int iters, int gap_us, int reps, double *out4);
-/* companion: independent v_fma_f64 chains -- the fp64 vector rate the chip sustains */
-int cocons_vfma_f64_probe(int blocks_per_cu, double *tflops);
-
-/* Diagnostic: the device routine that replaces boost::math::cyl_bessel_k + tgamma + pow at
- * src/cocons_full.cpp:293-297 (:301-305 for u >= 706), evaluated pointwise:
- * out[i] = 2^(1-nu_i)/Gamma(nu_i) * u_i^nu_i * K_nu_i(u_i).  Pinned against the mpmath grid in
- * tests/golden/besselk_grid.json (host arrays in, host array out).                    */
-int cocons_debug_matern(int n, const double *nu, const double *u, double *out);
+/* State of the resident diagonal-block engine of a dense handle: out[0] = 1 if the last
+ * completed operation ran on the engine schedule (0: plain schedule -- small n, a band-limited taper fit, a batch
+ * slot, COCONS_ENGINE=0, or the back-off after a time-out), out[1] = hand-off time-outs in the life of the handle
+ * (each was answered by ONE repeat of that operation on the plain schedule, then 2, 4 ... 64 further operations
+ * stay on it before the engine is tried again), out[2] = the abort code of the last time-out (0 = none).  No
+ * reference counterpart: the observability of a mechanism the reference does not have.                       */
+int cocons_fit_engine_state(cocons_fit *fit, int *out3);
 
 /* ---- natively sharded evaluation across the GPUs of one node ----------------------
  * Sigma row blocks (= column panels of the lower factor kept here, 256 columns each) are dealt

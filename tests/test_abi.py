@@ -7,8 +7,8 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "cocons_hip.h")).read()
+def _declared(header="cocons_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(cocons_[a-z0-9_]+)\s*\(", text)))
 
@@ -23,6 +23,15 @@ def test_header_symbols_are_exported_and_bound():
         assert nm in _lib.SIGNATURES, "python binding lacks " + nm
     assert sorted(_lib.SIGNATURES) == names
     assert lib.cocons_abi_version() == 1
+    # the diagnostics live in a header of their own and are no part of the drop-in boundary
+    diag = _declared("cocons_hip_diag.h")
+    assert diag and not set(diag) & set(names)
+    for nm in diag:
+        assert hasattr(lib, nm), "missing export " + nm
+    assert sorted(_lib.DIAG_SIGNATURES) == diag
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    for nm in re.findall(r" T (cocons_[a-z0-9_]+)", exported):
+        assert nm in names or nm in diag, "exported but declared in no header: " + nm
 
 
 def test_no_oracle_or_torch_in_product_library():

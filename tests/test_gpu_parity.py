@@ -640,6 +640,51 @@ def test_taper_objective_vs_oracle(oracle, n, r):
     fit.close()
 
 
+def test_taper_handle_recovers_after_failed_evaluation(oracle):
+    """A band-limited taper handle must not depend on what an earlier evaluation left in the buffer: a NaN parameter and
+    a non-positive-definite one (each poisons every tile the factorisation touches) followed by a valid one on the SAME
+    handle -- what an optimiser does after GetNeg2loglikelihoodTaper(safe = TRUE) returned 1e6
+    (R/neg2loglikelihood.R:33-38) -- and a prediction, which regrows the buffer, followed by the objective."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n = 4000                                   # envelope of ~4 of 32 tile rows: odd tile columns exist inside it
+    locs, X, th, rng = _problem(n, seed=4700)
+    z = rng.standard_normal((n, 1))
+    ref_taper = _taper_pattern(locs, 0.06)
+    pp = wl.par_pos_full()
+    tv = wl.theta_vector_from_lists(th, pp)
+    lam = (0.0, 0.0, 0.0)
+    fit = ca.CoconsTaperFit(locs, X, z, wl.SMOOTH_LIMITS, *ref_taper)
+    want = oracle.GetNeg2loglikelihoodTaper(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+    first = ca.GetNeg2loglikelihoodTaper(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    assert abs(first - want) <= N2LL_RTOL * abs(want)
+    bad = tv.copy()
+    bad[0] = np.nan
+    assert ca.GetNeg2loglikelihoodTaper(bad, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit) == 1e6
+    again = ca.GetNeg2loglikelihoodTaper(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    assert again == first
+    # not positive definite: a huge negative nugget intercept cannot do it (nugget >= 0), a variance of -inf does:
+    # std.dev -> exp(-inf) = 0 on the whole diagonal
+    th_bad = {k: np.array(v, dtype=float).copy() for k, v in th.items()}
+    th_bad["std.dev"][0] = -np.inf
+    th_bad["nugget"][0] = -np.inf
+    with pytest.raises(ca.CholeskyError):
+        fit.neg2loglik_core(th_bad)
+    again = ca.GetNeg2loglikelihoodTaper(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    assert again == first
+    # a prediction with a large border reallocates the factorisation buffer; the objective afterwards is unchanged
+    m = 300
+    lp = rng.uniform(0, 1, size=(m, 2))
+    Xp = np.column_stack([np.ones(m), rng.standard_normal(m), rng.standard_normal(m)])
+    cip, rpp = _csr_within(lp, locs, 0.06)
+    entp = np.ones(cip.size)
+    fit.predict_core(th, lp, Xp, (cip, rpp, entp))
+    assert ca.GetNeg2loglikelihoodTaper(bad, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit) == 1e6
+    again = ca.GetNeg2loglikelihoodTaper(tv, pp, ref_taper, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    assert again == first
+    fit.close()
+
+
 def test_taper_predict_vs_oracle(oracle):
     """Sparse branch of cocoPredict (R/predict.R:216-283) on a taper handle against the CPU restatement: tapered
     cross-covariance rows as border of the tapered matrix, one prediction location without any neighbour (an empty
