@@ -74,6 +74,9 @@ SIGNATURES = {
     "cocons_multi_destroy": (None, [c_vp]),
     "cocons_multi_neg2loglik_dense": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
     "cocons_multi_predict_dense": (c_int, [c_vp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_dp, c_dp]),
+    "cocons_multi_neg2loglik_batch": (c_int, [c_vp, c_int, c_dp, c_dp, c_dp, ctypes.POINTER(c_int)]),
+    "cocons_multi_comm_ranks": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "cocons_fit_comm_info": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "cocons_shard_begin": (c_int, [c_vp, c_dp, c_dp, c_int, c_int]),
     "cocons_shard_panel_factor": (c_int, [c_vp, c_int]),
     "cocons_shard_panel_buffer": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(ctypes.c_longlong)]),

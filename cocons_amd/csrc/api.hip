@@ -138,6 +138,12 @@ struct RcclApi {
     ncclResult_t (*GroupStart)();
     ncclResult_t (*GroupEnd)();
     const char *(*GetErrorString)(ncclResult_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *);
+    ncclResult_t (*CommAbort)(ncclComm_t);
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
 };
 
 static RcclApi *rccl_api()
@@ -182,6 +188,12 @@ static RcclApi *rccl_api()
         RSYM(GroupStart, "ncclGroupStart")
         RSYM(GroupEnd, "ncclGroupEnd")
         RSYM(GetErrorString, "ncclGetErrorString")
+        RSYM(CommCount, "ncclCommCount")
+        RSYM(CommUserRank, "ncclCommUserRank")
+        RSYM(CommCuDevice, "ncclCommCuDevice")
+        RSYM(CommAbort, "ncclCommAbort")
+        RSYM(Send, "ncclSend")
+        RSYM(Recv, "ncclRecv")
 #undef RSYM
         state = 1;
     }
@@ -220,6 +232,7 @@ struct cocons_fit {
     double *dloc;            // LOCP_FIELDS x npad
     double *dA;
     double *dinv;            // 2 x 8 x 256
+    double *dwinv;           // 2 x 128 x 128: the engine's W = L^-1 of the two current diagonal tiles (launch_panel's operand)
     int *dinfo;
     double *dout;            // reductions
     double *hout;            // pinned mirror
@@ -237,8 +250,12 @@ struct cocons_fit {
     hipEvent_t ev[8];
     hipStream_t stream2;          // stream the resident diagonal-tile engine is launched on
     hipEvent_t ev_eng;            // orders the engine launch behind the reset of its flag words
+    hipStream_t stream3;          // panel stream of the engine schedule: the solves below a diagonal block run here, beside
+                                  // the tail of the trailing update that produced their input (see factorize)
+    hipEvent_t ev_panel[2];       // panel of block t done (by block parity): the next trailing update waits for it
     unsigned *dflags;             // flags_cap words each: in[t], out[t], xr[t] (see launch_potrf_engine); 64: the alive word;
-                                  // flags_cap: tile counters of the trailing updates
+                                  // flags_cap: tile counters of the trailing updates; flags_cap: near[t], finished tiles of
+                                  // the next panel's columns (launch_update's near)
     int flags_cap;
     bool engine_ok;               // false: this handle never uses the resident engine (batch slots, band-limited taper fits)
     bool engine_live;             // the engine of the NEXT factorize call is already launched (engine_start)
@@ -308,8 +325,9 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         hipSetDevice(f->device);
         if (f->stream) hipStreamSynchronize(f->stream);
         if (f->stream2) hipStreamSynchronize(f->stream2);
+        if (f->stream3) hipStreamSynchronize(f->stream3);
         hipFree(f->dX); hipFree(f->dlocs); hipFree(f->dz); hipFree(f->dxb); hipFree(f->dloc);
-        hipFree(f->dA); hipFree(f->dinv); hipFree(f->dinfo); hipFree(f->dout);
+        hipFree(f->dA); hipFree(f->dinv); hipFree(f->dwinv); hipFree(f->dinfo); hipFree(f->dout);
         hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad); hipFree(f->dred);
         if (f->xbuf_own) { hipFree(f->xbuf[0]); hipFree(f->xbuf[1]); }
         hipHostFree(f->hout); hipHostFree(f->hinfo);
@@ -325,6 +343,8 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->slots) { for (auto c : *f->slots) cocons_fit_destroy(c); delete f->slots; f->slots = nullptr; }
         if (f->unsorted) { cocons_fit_destroy(f->unsorted); f->unsorted = nullptr; }
         if (f->stream2) hipStreamDestroy(f->stream2);
+        if (f->stream3) hipStreamDestroy(f->stream3);
+        for (auto &e : f->ev_panel) if (e) hipEventDestroy(e);
         if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     }
     delete f->h_locs; delete f->h_X; delete f->h_z;
@@ -451,6 +471,8 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     CK(hipStreamSynchronize(f->stream));      // the staging vectors above go out of scope
     CK(hipMalloc(&f->dloc, (size_t)LOCP_FIELDS * f->npad * sizeof(double)));
     CK(hipMalloc(&f->dinv, 2 * 8 * 256 * sizeof(double)));
+    CK(hipMalloc(&f->dwinv, 2 * (size_t)TILE * TILE * sizeof(double)));
+    CK(hipMemsetAsync(f->dwinv, 0, 2 * (size_t)TILE * TILE * sizeof(double), f->stream));   // zero above the diagonal, for good
     CK(hipMalloc(&f->dinfo, 2 * sizeof(int)));      // [0] failing minor (atomicMin), [1] abort word of the engine hand-offs
     int nr_max = r + (q > p ? q : p);
     f->out_cap = (size_t)(1 + nr_max * nr_max) * (size_t)(f->nt + 2);
@@ -460,6 +482,8 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     for (auto &e : f->ev) CK(hipEventCreate(&e));
     CK(hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&f->ev_eng, hipEventDisableTiming));
+    CK(hipStreamCreateWithFlags(&f->stream3, hipStreamNonBlocking));
+    for (auto &e : f->ev_panel) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
 #undef CK
     return f;
@@ -647,6 +671,7 @@ extern "C" int cocons_fit_set_stream(cocons_fit *f, void *stream)
     // stream that is about to be destroyed
     HIPCHK(hipStreamSynchronize(f->stream));
     HIPCHK(hipStreamSynchronize(f->stream2));
+    HIPCHK(hipStreamSynchronize(f->stream3));
     if (f->own_stream) { HIPCHK(hipStreamDestroy(f->stream)); f->own_stream = false; }
     f->stream = (hipStream_t)stream;
     return 0;
@@ -812,25 +837,28 @@ static bool engine_enabled()
 
 // one trailing-update launch (tile columns [t0, t1) of the trapezoid below (t0, t0)), optionally
 // bracketed by timing events (profile runs): appended as (start, stop)
-static void timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int t0, int t1, hipStream_t s,
-                         std::vector<hipEvent_t> *ev_upd, unsigned *sig, int sig_tile, unsigned *queue = nullptr)
+static bool timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int t0, int t1, hipStream_t s,
+                         std::vector<hipEvent_t> *ev_upd, unsigned *sig, int sig_tile, unsigned *queue = nullptr,
+                         unsigned *near = nullptr, int near_tiles = 0, const UpdStrips *strips = nullptr)
 {
     const int mt = v.mt;
-    if (t1 <= t0) return;
+    if (t1 <= t0) return false;
     const int hb = band_hi(v, k);                       // band-limited: tile columns and rows [t0, hb), plus the rows [nt, mt)
     if (hb >= 0 && hb < t1) t1 = hb;
-    if (t1 <= t0) return;
+    if (t1 <= t0) return false;
     unsigned *abort_word = sig ? (unsigned *)(f->dinfo + 1) : nullptr;   // engine schedule: see update_kernel
+    hipEvent_t a = nullptr, b = nullptr;
     if (ev_upd) {
-        hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a, s);
-        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, abort_word, queue, hb, v.nt);
+    }
+    const bool took = launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, abort_word,
+                                    queue, hb, v.nt, near, near_tiles, strips);
+    if (ev_upd) {
         hipEventRecord(b, s);
         ev_upd->push_back(a); ev_upd->push_back(b);
-    } else {
-        launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, abort_word, queue, hb, v.nt);
     }
+    return took;
 }
 
 // algorithmic flops of the trailing update of block k (tile columns [t0, nt)): lower triangle of the
@@ -860,11 +888,12 @@ static int flags_reset(cocons_fit *f, int nt)
 {
     if (f->flags_cap < nt) {
         HIPCHK(hipStreamSynchronize(f->stream2));
+        HIPCHK(hipStreamSynchronize(f->stream3));
         if (f->dflags) { HIPCHK(hipFree(f->dflags)); f->dflags = nullptr; }
         f->flags_cap = round_up(nt + 8, 64);
-        HIPCHK(hipMalloc(&f->dflags, (4 * (size_t)f->flags_cap + 64) * sizeof(unsigned)));
+        HIPCHK(hipMalloc(&f->dflags, (5 * (size_t)f->flags_cap + 64) * sizeof(unsigned)));
     }
-    HIPCHK(hipMemsetAsync(f->dflags, 0, (4 * (size_t)f->flags_cap + 64) * sizeof(unsigned), f->stream));
+    HIPCHK(hipMemsetAsync(f->dflags, 0, (5 * (size_t)f->flags_cap + 64) * sizeof(unsigned), f->stream));
     return 0;
 }
 
@@ -874,6 +903,55 @@ static unsigned *tile_queue(cocons_fit *f, int k)
     static int dyn = -1;
     if (dyn < 0) { const char *e = getenv("COCONS_UPD_DYNAMIC"); dyn = e ? atoi(e) : 1; }
     return dyn ? f->dflags + 3 * (size_t)f->flags_cap + 64 + k / 2 : nullptr;
+}
+
+// COCONS_PANEL_MODE: how the panel below an engine-factored diagonal block is formed
+//   0 = three launches behind the trailing update: solve | in-panel update | solve (round 2);
+//   1 = one launch of GEMMs with the engine's tile inverses (launch_panel) behind the trailing update;
+//   2 (default) = the same GEMMs as TASKS of the trailing update that precedes them (launch_update's strips) wherever
+//       that update is long enough to hide the engine's chain behind its first tiles, mode 0 for the later, short blocks
+static int panel_mode()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("COCONS_PANEL_MODE");
+        v = e ? atoi(e) : 2;
+        if (v < 0 || v > 2) v = 2;
+        const char *m4 = getenv("COCONS_UPD_MFMA4");           // the alternative update kernel knows no strips
+        if (m4 && atoi(m4) != 0 && v == 2) v = 0;
+    }
+    return v;
+}
+
+// mode 2: tiles of the trailing update in front of the strips (time for the engine: ~2040 tiles run at once and take
+// ~75 us), and the fewest far tiles a block must have to carry its strips at all
+static int strip_lead()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("COCONS_STRIP_LEAD"); v = e ? atoi(e) : 3600; }
+    return v;
+}
+static int strip_min_far()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("COCONS_STRIP_MIN"); v = e ? atoi(e) : 3600; }
+    return v;
+}
+
+// first tile of the first block whose panel is NOT formed with the engine's tile inverses (the engine computes them
+// for the blocks before it only): mode 1 -> all blocks, mode 0 -> none, mode 2 -> while the update has enough far tiles
+static int panel_w_until(const FactorView &v)
+{
+    if (panel_mode() == 0 || v.hi) return 0;
+    if (panel_mode() == 1) return v.nt;
+    int t = 2;
+    for (; t < v.nt; t += 2) {
+        const int near_tiles = t + 1 < v.nt ? 2 : 1;
+        const long long H = 2LL * (v.mt - t), W = 2LL * (v.nt - t);
+        const long long total = W * H - W * (W - 1) / 2;
+        if (total - (long long)update_near_count(t, v.mt, near_tiles) < strip_min_far()) break;
+    }
+    return t;
 }
 
 static int engine_start(cocons_fit *f, const FactorView &v)
@@ -886,7 +964,7 @@ static int engine_start(cocons_fit *f, const FactorView &v)
     HIPCHK(hipEventRecord(f->ev_eng, M));
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
     launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
-                        f->dflags + 3 * (size_t)f->flags_cap, f->stream2);
+                        f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dwinv, panel_w_until(v));
     f->engine_live = true;
     return 0;
 }
@@ -945,24 +1023,57 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     f->engine_live = false;
     f->engine_used = true;
     unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
+    unsigned *near = f->dflags + 4 * (size_t)f->flags_cap + 64;
     unsigned *abort_word = (unsigned *)(f->dinfo + 1);
     launch_engine_gate(f->dflags + 3 * (size_t)f->flags_cap, abort_word, M);
     panel_ops(f, v, 0, M);
+    // The panel of block t (solve, in-panel update, solve: three short launches that use a fraction of the chip) runs on
+    // a stream of its own, P, held back by flags instead of by the end of the update U(k) that feeds it: U(k) stores the
+    // tiles of the panel's columns write-through and counts them in near[t]; once they are all there (they come first in
+    // U(k)'s tile order) P's gate opens and the panel kernels are placed as soon as U(k)'s retiring workgroups leave room --
+    // in the tail of U(k), where the chip drains anyway.  U(k+2) waits for the panel's event.  COCONS_PANEL_OVERLAP=0:
+    // everything in order on the main stream (the round-2 schedule).
+    static int overlap = -1;
+    if (overlap < 0) { const char *e = getenv("COCONS_PANEL_OVERLAP"); overlap = e ? atoi(e) : 0; }
+    hipStream_t P = overlap ? f->stream3 : M;
+    if (overlap) HIPCHK(hipStreamWaitEvent(P, f->ev_eng, 0));     // behind the reset of the flag words
+    const int w_until = panel_w_until(v);
     for (int k = 0; k + 2 < nt; k += 2) {
         const int t = k + 2;
         const bool two = t + 1 < nt;                 // the block has a second tile
         const int r0 = two ? t + 2 : t + 1;          // first tile row below the diagonal block
         if (ev_upd) count_update_flops(f, 2, t);
-        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k));
+        const int near_tiles = two ? 2 : 1;
         const int hb = band_hi(v, t);                // rows of block t's panel: [r0, hb) and the rows under the matrix
         const int br = hb >= 0 ? hb * TILE : -1, er = nt * TILE;
-        launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, mt * TILE, f->dinv + (size_t)(t & 1) * 2048, M,
-                         out + t, abort_word, br, er);
-        if (two) {
-            launch_update(v.A, v.lda, t * TILE, TILE, r0, mt, t + 1, t + 2, false, M, nullptr, -1, xr + t, abort_word,
-                          nullptr, hb, nt);
-            launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, r0 * TILE, mt * TILE,
-                             f->dinv + (size_t)((t + 1) & 1) * 2048, M, out + t + 1, abort_word, br, er);
+        const bool with_w = t < w_until;             // the engine publishes the inverses of this block's tiles
+        if (with_w && panel_mode() == 2) {
+            // the panel's strips are tasks of U(k) itself: nothing to launch behind it
+            UpdStrips us;
+            us.nstrips = (mt - r0) * 2; us.row0 = r0 * TILE; us.lead = strip_lead();
+            us.winv = f->dwinv; us.out = out; us.xr = xr;
+            if (!timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), near + t, near_tiles, &us))
+                launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, mt * TILE, f->dwinv, out, xr, abort_word, M);
+            continue;
+        }
+        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), overlap ? near + t : nullptr, near_tiles);
+        if (overlap) launch_flag_gate(near + t, update_near_count(t, mt, near_tiles), abort_word, 0x700u + t, P);
+        if (with_w) {
+            launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, mt * TILE, f->dwinv, out, xr, abort_word, P);
+        } else {
+            launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, mt * TILE, f->dinv + (size_t)(t & 1) * 2048, P,
+                             out + t, abort_word, br, er);
+            if (two) {
+                launch_update(v.A, v.lda, t * TILE, TILE, r0, mt, t + 1, t + 2, false, P, nullptr, -1, xr + t, abort_word,
+                              nullptr, hb, nt);
+                launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, r0 * TILE, mt * TILE,
+                                 f->dinv + (size_t)((t + 1) & 1) * 2048, P, out + t + 1, abort_word, br, er);
+            }
+        }
+        if (overlap) {
+            hipEvent_t ev = f->ev_panel[(t >> 1) & 1];
+            HIPCHK(hipEventRecord(ev, P));
+            HIPCHK(hipStreamWaitEvent(M, ev, 0));
         }
     }
     return 0;
@@ -1039,6 +1150,7 @@ static bool engine_retry(cocons_fit *f, int st)
     f->engine_live = false;
     f->engine_used = false;
     hipStreamSynchronize(f->stream2);
+    hipStreamSynchronize(f->stream3);
     return true;
 }
 
@@ -2441,6 +2553,81 @@ extern "C" int cocons_multi_predict_dense(cocons_multi *m, const double *theta, 
     for (auto &t : th) t.join();
     for (int d = 0; d < W; ++d)
         if (rcs[d] != 0) { g_err = errs[d]; return rcs[d]; }
+    return 0;
+}
+
+// Replica mode inside one process: the nb independent parameter points of one finite-difference gradient
+// (R/optim.R:256-259, 1 + 2P points) or of getHessian (R/getFunctions.R:979-1016) are dealt over the devices of the
+// handle -- point i goes to device i mod ndev -- and every device runs its share through cocons_neg2loglik_batch on
+// its own fit (own slots, own streams), driven by one host thread per device.  No collective: the evaluations are
+// independent, so the handle may list a device more than once.  thetas / means / values / status as
+// cocons_neg2loglik_batch.
+extern "C" int cocons_multi_neg2loglik_batch(cocons_multi *m, int nb, const double *thetas, const double *means,
+                                             double *values, int *status)
+{
+    if (!m || nb < 0 || (nb > 0 && (!thetas || !means || !values || !status)))
+        return fail(-1, "cocons_multi_neg2loglik_batch: bad argument");
+    const int W = m->ndev, p = m->fits[0]->p, tp = 6 * p;
+    for (int i = 0; i < nb; ++i) { values[i] = NAN; status[i] = -1; }
+    std::vector<int> rcs(W, 0);
+    std::vector<std::string> errs(W);
+    std::vector<std::thread> th;
+    for (int d = 0; d < W; ++d) {
+        const int cnt = nb > d ? (nb - d + W - 1) / W : 0;
+        if (cnt == 0) continue;
+        th.emplace_back([=, &rcs, &errs]() {
+            std::vector<double> T((size_t)cnt * tp), M((size_t)cnt * p), V(cnt);
+            std::vector<int> S(cnt);
+            for (int j = 0; j < cnt; ++j) {
+                const int i = d + j * W;
+                memcpy(&T[(size_t)j * tp], thetas + (size_t)i * tp, (size_t)tp * sizeof(double));
+                memcpy(&M[(size_t)j * p], means + (size_t)i * p, (size_t)p * sizeof(double));
+            }
+            rcs[d] = cocons_neg2loglik_batch(m->fits[d], cnt, T.data(), M.data(), V.data(), S.data());
+            if (rcs[d] != 0) errs[d] = g_err;          // g_err is thread-local
+            for (int j = 0; j < cnt; ++j) { values[d + j * W] = V[j]; status[d + j * W] = S[j]; }
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int d = 0; d < W; ++d)
+        if (rcs[d] != 0) { g_err = errs[d]; return rcs[d]; }
+    return 0;
+}
+
+// devices the communicators of a multi handle span (0: the handle has none -- a device is listed twice), and the
+// size RCCL itself reports for the communicator of the handle's first device (ncclCommCount)
+extern "C" int cocons_multi_comm_ranks(cocons_multi *m, int *ndev, int *rccl_count)
+{
+    if (!m) return fail(-1, "cocons_multi_comm_ranks: null handle");
+    if (ndev) *ndev = m->ndev;
+    int cnt = 0;
+    if (!m->comms.empty()) {
+        RcclApi *R = rccl_api();
+        if (!R) return -1;
+        NCCLCHK(R->CommCount(m->comms[0], &cnt));
+    }
+    if (rccl_count) *rccl_count = cnt;
+    return 0;
+}
+
+// the same for a fit that carries a communicator of its own (cocons_fit_comm_init): what ncclCommCount and
+// ncclCommUserRank / ncclCommCuDevice say -- the proof bench.py prints that RCCL saw N ranks on N devices
+extern "C" int cocons_fit_comm_info(cocons_fit *f, int *count, int *user_rank, int *device)
+{
+    if (!f) return fail(-1, "cocons_fit_comm_info: null handle");
+    int c = 0, u = -1, dv = -1;
+    if (f->coll_kind == 1 && f->comm) {
+        RcclApi *R = rccl_api();
+        if (!R) return -1;
+        NCCLCHK(R->CommCount(f->comm, &c));
+        NCCLCHK(R->CommUserRank(f->comm, &u));
+        NCCLCHK(R->CommCuDevice(f->comm, &dv));
+    } else if (f->coll_kind == 2) {
+        c = f->coll_world; u = f->coll_rank; dv = f->device;
+    }
+    if (count) *count = c;
+    if (user_rank) *user_rank = u;
+    if (device) *device = dv;
     return 0;
 }
 

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <vector>
 #include "kernels.h"
@@ -29,6 +30,9 @@ namespace cocons {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+// the same with the first operand negated: for the fp64 forms the instruction's blgp field holds NEG bits
+// (neg:[a,b,c]; bit 0 = first source), so D = C - A B costs no extra instruction
+#define MFMA64_NEGA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 1)
 
 __device__ __forceinline__ void blk_mma(d4 &acc, const d4 &P, const d4 &Q)
 {
@@ -170,27 +174,43 @@ __device__ __forceinline__ void potrf16_step(d4 &D, double (&Q)[4], int lane, in
     double a11 = rdlane(ds, 4 * S + 1 + 16), a21 = rdlane(ds, 4 * S + 2 + 16), a31 = rdlane(ds, 4 * S + 3 + 16);
     double a22 = rdlane(ds, 4 * S + 2 + 32), a32 = rdlane(ds, 4 * S + 3 + 32);
     double a33 = rdlane(ds, 4 * S + 3 + 48);
-    // 4x4 Cholesky (dpotf2 order) -- identical on every lane.  Pivots through
-    // rsqrt_pivot(): l = sqrt(a) and r = 1/l from one v_rsq_f64 seed (short dependent chain;
-    // this loop is pure latency).
+    // 4x4 Cholesky, identical on every lane.  This loop is pure latency (one wave, every operation waits for the one
+    // before), so it is arranged for the shortest dependent chain rather than for the fewest operations: the pivots
+    // d_j come from the outer-product (Schur complement) form with RECIPROCALS on the chain,
+    //     d1 = a11 - a10^2 / d0,   u21 = a21 - a20 a10 / d0, ...        (rcp + two Newton steps: 5 operations)
+    // and the square roots l_jj = sqrt(d_j), r_j = 1 / l_jj of d0, d1, d2 are refined BESIDE that chain (independent
+    // instruction streams share the one wave's issue slots); only d3's follows it.  Chain: 3 x 6 + 12 operations instead
+    // of 4 x 14.  l_ij = u_ij r_j with u the Schur-complement entries: the factor of the same matrix, rounded in a
+    // different order than dpotf2's a_ij - sum l_ik l_jk (both backward stable; the results differ in the last place).
+    auto rcp_ref = [](double a) {
+        double y = __builtin_amdgcn_rcp(a);
+        y = fma(fma(-a, y, 1.0), y, y);
+        y = fma(fma(-a, y, 1.0), y, y);
+        return y;
+    };
     if (!(a00 > 0.0) && fail == 0) fail = 4 * S + 1;
-    double l00, r0;
-    rsqrt_pivot(a00, l00, r0);
-    double l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
-    double t11 = fma(-l10, l10, a11);
+    const double e0 = rcp_ref(a00);
+    const double g10 = a10 * e0, g20 = a20 * e0, g30 = a30 * e0;         // a_i0 / d0
+    const double t11 = fma(-a10, g10, a11);
+    const double u21 = fma(-a20, g10, a21), u31 = fma(-a30, g10, a31);
+    const double s22 = fma(-a20, g20, a22), v32 = fma(-a30, g20, a32), s33 = fma(-a30, g30, a33);
     if (!(t11 > 0.0) && fail == 0) fail = 4 * S + 2;
-    double l11, r1;
-    rsqrt_pivot(t11, l11, r1);
-    double l21 = fma(-l20, l10, a21) * r1, l31 = fma(-l30, l10, a31) * r1;
-    double t22 = fma(-l21, l21, fma(-l20, l20, a22));
+    const double e1 = rcp_ref(t11);
+    const double h21 = u21 * e1, h31 = u31 * e1;                          // u_i1 / d1
+    const double t22 = fma(-u21, h21, s22);
+    const double u32 = fma(-u31, h21, v32), w33 = fma(-u31, h31, s33);
     if (!(t22 > 0.0) && fail == 0) fail = 4 * S + 3;
-    double l22, r2;
-    rsqrt_pivot(t22, l22, r2);
-    double l32 = fma(-l31, l21, fma(-l30, l20, a32)) * r2;
-    double t33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a33)));
+    const double e2 = rcp_ref(t22);
+    const double t33 = fma(-u32, u32 * e2, w33);
     if (!(t33 > 0.0) && fail == 0) fail = 4 * S + 4;
-    double l33, r3;
+    double l00, r0, l11, r1, l22, r2, l33, r3;
+    rsqrt_pivot(a00, l00, r0);
+    rsqrt_pivot(t11, l11, r1);
+    rsqrt_pivot(t22, l22, r2);
     rsqrt_pivot(t33, l33, r3);
+    const double l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
+    const double l21 = u21 * r1, l31 = u31 * r1;
+    const double l32 = u32 * r2;
     // inverse of the 4x4 factor
     double m00 = r0, m11 = r1, m22 = r2, m33 = r3;
     double m10 = -(l10 * m00) * r1;
@@ -452,7 +472,55 @@ struct EngineArgs {
     unsigned *in, *out, *xr; // per-tile flag words
     unsigned *abort_word;
     unsigned *alive;         // raised once the workgroup is resident (see engine_gate_kernel)
+    double *winv;            // 2 x 128 x 128 doubles (parity of the tile index; zero outside the lower triangle):
+                             // W = L^-1 of each diagonal tile, published before out[t] (see panel_kernel)
+    int w_until;             // ... for the blocks that start at a tile t < w_until (the others: no inverse, no cost)
 };
+
+// W = L^-1 of the 128 x 128 tile whose factor (block-packed) and Q operands (all eight diagonal blocks) are in LDS:
+// the strip solve of the engine applied to the identity -- wave w takes rows 16 w .. of I, X = I L^-T = W^T, an upper
+// triangular strip -- stored transposed, write-through, column-major with leading dimension 128.  168 MFMAs on the
+// longest strip (wave 0), ~5 us; the explicit inverse of a TRIANGULAR tile costs the solve that uses it a forward error
+// of eps cond(L) = eps sqrt(cond(Sigma block)), far inside the eps cond(Sigma) any Cholesky of Sigma carries.
+__device__ __noinline__ void engine_tile_inverse(double *W, int wave, int lane)
+{
+    // (out of line: inlined twice into the engine it pushed the kernel past its registers.  The LDS image is reached
+    // through the kernel's dynamic-LDS symbol, so the reads stay ds_read -- a pointer argument would make them flat.)
+    extern __shared__ double smem[];
+    const double *S = smem, *QALL = smem + 37 * 256;
+    d4 B[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) B[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int a = lane & 15, kq = lane >> 4;
+    d4 I16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) I16[r] = (a == 4 * r + kq) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < wave) continue;                      // wave-uniform: the strip is zero left of its diagonal block
+        if (j == wave) B[j] = I16;
+        d4 L = lds_blk(S + (j * (j + 1) / 2 + j) * 256, lane);
+        double Q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Q[s] = QALL[j * 256 + s * 64 + lane];
+        trsm16(B[j], L, Q);
+        d4 NX = -B[j];
+#pragma unroll
+        for (int jj = j + 1; jj < 8; ++jj) {
+            d4 Lb = lds_blk(S + (jj * (jj + 1) / 2 + j) * 256, lane);
+            blk_mma(B[jj], NX, Lb);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < wave) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int wr = 16 * j + 4 * r + kq, wc = 16 * wave + a;      // W(wr, wc) = W^T(wc, wr)
+            store_wt(W + wr + wc * TILE, wr >= wc ? B[j][r] : 0.0);
+        }
+    }
+}
 
 __global__ void __launch_bounds__(512)
 potrf_engine_kernel(EngineArgs e)
@@ -471,6 +539,8 @@ potrf_engine_kernel(EngineArgs e)
         __syncthreads();
         if (*okp == 0) return;
         potrf_tile_body<true>(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem, QALL);
+        __syncthreads();
+        if (t < e.w_until) engine_tile_inverse(e.winv + (size_t)(t & 1) * TILE * TILE, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t);
@@ -524,7 +594,9 @@ potrf_engine_kernel(EngineArgs e)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // X in LDS is dead; the tile is re-read from memory
-        potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, nullptr);
+        potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, t < e.w_until ? QALL : nullptr);
+        __syncthreads();
+        if (t < e.w_until) engine_tile_inverse(e.winv + (size_t)((t + 1) & 1) * TILE * TILE, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t + 1);
@@ -593,6 +665,184 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsig
 }
 
 // ---------------------------------------------------------------------------
+// Panel of a 256-column block under the engine schedule, as GEMMs.  The engine publishes, with the factor L of each
+// diagonal tile, its inverse W = L^-1 (engine_tile_inverse); then for the rows below the diagonal block
+//     X0 = B0 W(t)^T          (the solve with tile t)
+//     B1 -= X0 X(t+1,t)^T     (in-panel update; X(t+1,t) is the engine's)
+//     X1 = B1 W(t+1)^T        (the solve with tile t + 1)
+// are products without any dependent chain, and one workgroup per 64-row strip runs all three on the trailing update's
+// inner loop and footprint (4 waves x 32 x 32, K chunks of 8 through 20 KB of LDS, 64 registers): ONE launch instead of
+// three, a fraction of their time, and small enough to sit beside update workgroups.  In place: the 64-column halves of
+// a solve are formed right to left (the left half only reads columns the right half did not write).
+// Before each stage one lane waits for the engine's word (out[t] covers W(t); bounded like every wait), then an
+// acquire: W and X(t+1,t) arrive by write-through stores from another CU.
+struct PanelArgs {
+    double *A; size_t lda;
+    int c0;                  // first column of tile t
+    int two;                 // the block has a second tile
+    int row0;                // first row; workgroup b takes rows row0 + 64 b ..
+    const double *w0, *w1;   // W(t), W(t+1): 128 x 128, column-major, leading dimension 128, zero above the diagonal
+    unsigned *out0, *xr0, *out1, *abort_word;
+};
+
+// acc (+/-)= I(rows, 0..K) J(cols, 0..K)^T streamed through LDS in chunks of KC columns (the trailing update's inner
+// loop); gI / gJ point at the first row of the operand tiles, column 0; ends behind a barrier: LDS free, every wave done.
+template <int TM, int KC, bool NEG>
+__device__ __forceinline__ void panel_stream(d4 (&acc)[TM / 32][TM / 32], const double *gI, size_t ldi, const double *gJ,
+                                             size_t ldj, int K, double *sIb, double *sJb, int wi, int wj)
+{
+    constexpr int LDT = TM + 16, NB = TM / 32, TPC = 256 / KC, RPT = TM / TPC;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int t2 = 64 * (2 * wj + wi) + lane;
+    const int kc = t2 / TPC, rg = (t2 % TPC) * RPT;
+    const int ro = (lane >> 4) * LDT + (lane & 15);
+    gI += (size_t)rg + (size_t)kc * ldi;
+    gJ += (size_t)rg + (size_t)kc * ldj;
+    const int nch = K / KC;
+    d2 stI[RPT / 2], stJ[RPT / 2];
+#pragma unroll
+    for (int v = 0; v < RPT / 2; ++v) {
+        stI[v] = *(const d2 *)(gI + 2 * v);
+        stJ[v] = *(const d2 *)(gJ + 2 * v);
+    }
+#pragma unroll
+    for (int v = 0; v < RPT / 2; ++v) {
+        *(d2 *)(sIb + kc * LDT + rg + 2 * v) = stI[v];
+        *(d2 *)(sJb + kc * LDT + rg + 2 * v) = stJ[v];
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < nch) {
+            const double *pI = gI + (size_t)(ch + 1) * KC * ldi;
+            const double *pJ = gJ + (size_t)(ch + 1) * KC * ldj;
+#pragma unroll
+            for (int v = 0; v < RPT / 2; ++v) {
+                stI[v] = *(const d2 *)(pI + 2 * v);
+                stJ[v] = *(const d2 *)(pJ + 2 * v);
+            }
+        }
+        const double *bI = sIb + cur * (KC * LDT) + ro + (TM / 2) * wi;
+        const double *bJ = sJb + cur * (KC * LDT) + ro + (TM / 2) * wj;
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) {
+            double pi_[NB], pj_[NB];
+#pragma unroll
+            for (int x = 0; x < NB; ++x) {
+                pi_[x] = bI[s * 4 * LDT + 16 * x];
+                pj_[x] = bJ[s * 4 * LDT + 16 * x];
+            }
+#pragma unroll
+            for (int x = 0; x < NB; ++x)
+#pragma unroll
+                for (int y = 0; y < NB; ++y)
+                    acc[x][y] = NEG ? MFMA64_NEGA(pj_[y], pi_[x], acc[x][y]) : MFMA64(pj_[y], pi_[x], acc[x][y]);
+        }
+        if (ch + 1 < nch) {
+#pragma unroll
+            for (int v = 0; v < RPT / 2; ++v) {
+                *(d2 *)(sIb + (cur ^ 1) * (KC * LDT) + kc * LDT + rg + 2 * v) = stI[v];
+                *(d2 *)(sJb + (cur ^ 1) * (KC * LDT) + kc * LDT + rg + 2 * v) = stJ[v];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One strip = 64 rows below the diagonal block: the three stages, each behind its wait.  sIb / sJb: the two operand
+// rings (2 x KC x (TM + 16) doubles each), share: a word of LDS no staging store touches.  near / near_need: the strip's
+// input comes from the trailing update that is still running (the strip is a task INSIDE that launch): wait until its
+// near counter says the panel's columns are complete.  Returns false when the factorisation was given up.
+template <int TM, int KC>
+__device__ __forceinline__ bool panel_strip(const PanelArgs &a, int strip, double *sIb, double *sJb, unsigned *share,
+                                            int wave, unsigned *near, unsigned near_need)
+{
+    constexpr int NB = TM / 32;
+    const int tid = threadIdx.x;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int row0 = a.row0 + TM * strip;
+    const unsigned ldab = 8u * (unsigned)a.lda;
+
+    // stages: 0, 1 = solve with tile t (right half, left half); 2, 3 = in-panel update of the halves of tile t + 1;
+    // 4, 5 = solve with tile t + 1 (right half, left half)
+    const int nstage = a.two ? 6 : 2;
+#pragma unroll 1
+    for (int st = 0; st < nstage; ++st) {
+        if (st == 0 || st == 2 || st == 4) {
+            unsigned *w = st == 0 ? a.out0 : (st == 2 ? a.xr0 : a.out1);
+            if (tid == 0) {
+                bool ok = true;
+                if (st == 0 && near) ok = wait_ge<false>(near, near_need, a.abort_word, 0x700u);
+                *share = (ok && wait_ge(w, 1u, a.abort_word, 0x300u + st)) ? 1u : 0u;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned ok = *share;
+            __syncthreads();
+            if (!ok) return false;
+        }
+        const bool upd = st == 2 || st == 3;
+        const int h = upd ? st - 2 : 1 - (st & 1);                       // 64-column half of the tile
+        const int ctile = st < 2 ? a.c0 : a.c0 + TILE;                   // tile the stage writes
+        const int col = ctile + TM * h;
+        // the wave's 32 x 32 part of the 64 x 64 tile at (row0, col): a scalar base and one per-lane offset
+        double *Cb = a.A + (size_t)(row0 + (TM / 2) * wi) + (size_t)(col + (TM / 2) * wj) * a.lda;
+        int lane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        const unsigned cvo = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldab;
+        d4 acc[NB][NB];
+        if (upd) {
+#pragma unroll
+            for (int x = 0; x < NB; ++x)
+#pragma unroll
+                for (int y = 0; y < NB; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[x][y][r] = *(const double *)((const char *)(Cb + 16 * x) + (cvo + (unsigned)(16 * y + 4 * r) * ldab));
+            panel_stream<TM, KC, true>(acc, a.A + (size_t)row0 + (size_t)a.c0 * a.lda, a.lda,
+                                       a.A + (size_t)col + (size_t)a.c0 * a.lda, a.lda, TILE, sIb, sJb, wi, wj);
+        } else {
+#pragma unroll
+            for (int x = 0; x < NB; ++x)
+#pragma unroll
+                for (int y = 0; y < NB; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+            const double *W = st < 2 ? a.w0 : a.w1;
+            panel_stream<TM, KC, false>(acc, a.A + (size_t)row0 + (size_t)ctile * a.lda, a.lda, W + TM * h, TILE,
+                                        TM * (h + 1), sIb, sJb, wi, wj);
+        }
+        unsigned cve = cvo;
+        asm volatile("" : "+v"(cve));
+#pragma unroll
+        for (int x = 0; x < NB; ++x)
+#pragma unroll
+            for (int y = 0; y < NB; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *(double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldab)) = acc[x][y][r];
+        // a later stage of THIS workgroup reads these bytes back (as operand or as C): drain, then a barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    return true;
+}
+
+// The panel as a launch of its own (one workgroup per strip means one wave per SIMD and nobody to hide a memory round
+// trip behind: the chunks are KC = 32 columns deep -- 32 MFMAs per wave, 2048 pipe cycles, cover the load of the next
+// chunk -- which takes 80 KB of LDS and 32 staging registers; with at most one workgroup per CU that costs nothing).
+template <int TM, int KC>
+__global__ void __launch_bounds__(256)
+panel_kernel(PanelArgs a)
+{
+    constexpr int LDT = TM + 16;
+    extern __shared__ double panel_smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    (void)panel_strip<TM, KC>(a, blockIdx.x, panel_smem, panel_smem + 2 * KC * LDT, (unsigned *)(panel_smem + TM), wave,
+                              nullptr, 0u);
+}
+
+// ---------------------------------------------------------------------------
 // Trailing update: C(ti,tj) -= P(ti,:) P(tj,:)^T over K panel columns.  TM x TM tiles, 4 waves x
 // (TM/2 x TM/2); instantiated with TM = 64 (each wave 2 x 2 MFMA blocks, up to 8 workgroups per CU).
 // Operand tiles stream through LDS in chunks of KC panel columns (KC = 8: 20 KB), register-staged
@@ -611,6 +861,14 @@ struct UpdArgs {
     unsigned *queue; unsigned ntiles;  // dynamic tile order (lower_only launches): shared counter, zero at launch; tiles in all
     int Hb, ext0;                  // rows: local tile rows < Hb count from ti0 (tj0 when lower_only), the others from ext0
                                    // (band-limited factorisation: band rows, then the right-hand-side rows)
+    unsigned *near; int near_tj0, near_w;   // panel hand-off: every tile in the 64-wide columns [near_tj0, near_tj0 + near_w)
+                                   // -- the NEXT panel's columns -- is stored write-through and then adds 1 to *near, so
+                                   // that the panel kernels (another stream) can start while this launch is still running
+    // panel strips as tasks of THIS launch (lower_only launches): positions [strip_pos, strip_pos + nstrips) of the 1-D task
+    // order are the 64-row strips of the next panel (panel_strip; pan describes it, near_need = what *near counts up to),
+    // everything else a tile; ntiles then counts tiles AND strips
+    int nstrips; unsigned strip_pos, near_need;
+    PanelArgs pan;
 };
 
 // ROLE only names the instantiation (0 = trailing update, 1 = in-panel / sharded update) so that
@@ -671,6 +929,22 @@ update_kernel(UpdArgs a)
         const int kc = t2 / TPC, rg = (t2 % TPC) * RPT;
         const int ro = (lane >> 4) * LDT + (lane & 15);
         int ti, tj;
+        if (a.nstrips > 0 && L >= a.strip_pos && L < a.strip_pos + (unsigned)a.nstrips) {
+            // a strip of the next panel: its input -- the near tiles of this launch, the engine's tiles -- is complete
+            // or on its way (the strips sit behind the near tiles in the task order, far enough for the engine)
+            __builtin_amdgcn_s_setprio(0);
+            if (!panel_strip<TM, KC>(a.pan, (int)(L - a.strip_pos), &sI[0][0], &sJ[0][0], share, wave, a.near, a.near_need))
+                return;
+            if (!a.queue) break;
+            if (t2 == 0)
+                *share = gridDim.x + __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            L = (unsigned)__builtin_amdgcn_readfirstlane((int)*share);
+            __syncthreads();
+            if (L >= a.ntiles) break;
+            continue;
+        }
+        const unsigned Lt = (a.nstrips > 0 && L >= a.strip_pos) ? L - (unsigned)a.nstrips : L;     // position among the tiles
         if (a.lower_only) {
             // 1-D order over the tiles (ti >= tj) of the trapezoid, column by column: column j (0-based
             // from tj0) holds H - j tiles and starts at j H - j (j-1)/2.  Bisection in integers: L is
@@ -678,11 +952,11 @@ update_kernel(UpdArgs a)
             int lo = 0, hi = a.W - 1;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
-                if (mid * a.H - mid * (mid - 1) / 2 <= (int)L) lo = mid; else hi = mid - 1;
+                if (mid * a.H - mid * (mid - 1) / 2 <= (int)Lt) lo = mid; else hi = mid - 1;
             }
             const int j = lo;
             tj = a.tj0 + j;
-            const int til = j + ((int)L - (j * a.H - j * (j - 1) / 2));
+            const int til = j + ((int)Lt - (j * a.H - j * (j - 1) / 2));
             ti = til < a.Hb ? a.tj0 + til : a.ext0 + (til - a.Hb);
         } else {
             const int til = blockIdx.x;
@@ -693,6 +967,9 @@ update_kernel(UpdArgs a)
         // does this tile lie inside the diagonal block the engine is waiting for?
         const int sig_Ti = (ti * TM) / TILE - a.sig_tile, sig_Tj = (tj * TM) / TILE - a.sig_tile;
         const bool sig_wg = a.sig != nullptr && sig_Ti >= 0 && sig_Ti <= 1 && sig_Tj >= 0 && sig_Tj <= sig_Ti;
+        // ... or in the columns of the next panel, whose solve (another stream) starts as soon as all of them are done?
+        const bool near_wg = a.near != nullptr && tj >= a.near_tj0 && tj < a.near_tj0 + a.near_w;
+        const bool wt_wg = sig_wg || near_wg;
         // the engine's whole chain starts when these ten tiles are done: let them win the issue arbitration on
         // their CU (beside seven other workgroups a tile takes ~70 us, alone ~10)
         if (sig_wg) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
@@ -701,11 +978,23 @@ update_kernel(UpdArgs a)
         const double *gJ = a.P + (size_t)(tj * TM + rg) + (size_t)kc * a.ldp;
         d2 stI[RPT / 2], stJ[RPT / 2];
 
+        // The accumulators START as the C tile (loaded here, together with the first operand chunk) and the products are
+        // subtracted by the MFMA itself (negated first operand): the tile ends with sixteen stores -- no load, no
+        // subtraction, and none of the four dependent memory round trips a read-modify-write epilogue had.
+        // (addresses = a wave-uniform base, kept in scalar registers, plus ONE 32-bit per-lane offset: sixteen 64-bit
+        // per-lane addresses would not fit the kernel's 64 registers)
+        double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi) + (size_t)(tj * TM + (TM / 2) * wj) * a.ldc;
+        const unsigned ldcb = 8u * (unsigned)a.ldc;                                          // bytes, all of these
+        const unsigned cvo = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldcb;
         d4 acc[NB][NB];
 #pragma unroll
         for (int x = 0; x < NB; ++x)
 #pragma unroll
-            for (int y = 0; y < NB; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int y = 0; y < NB; ++y) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[x][y][r] = *(const double *)((const char *)(Cb + 16 * x) + (cvo + (unsigned)(16 * y + 4 * r) * ldcb));
+            }
 
 #pragma unroll
         for (int v = 0; v < RPT / 2; ++v) {
@@ -743,7 +1032,7 @@ update_kernel(UpdArgs a)
 #pragma unroll
                 for (int x = 0; x < NB; ++x)
 #pragma unroll
-                    for (int y = 0; y < NB; ++y) acc[x][y] = MFMA64(pj_[y], pi_[x], acc[x][y]);
+                    for (int y = 0; y < NB; ++y) acc[x][y] = MFMA64_NEGA(pj_[y], pi_[x], acc[x][y]);
             }
             if (ch + 1 < nch) {
 #pragma unroll
@@ -755,36 +1044,35 @@ update_kernel(UpdArgs a)
             __syncthreads();
         }
         // next tile: asked for now (not earlier: a tile reserved while another is being worked on is a tile
-        // an idle workgroup cannot take at the end of the launch), read after the epilogue that hides the round trip
+        // an idle workgroup cannot take at the end of the launch), read after the stores that hide the round trip
         unsigned Lnext = 0;
         if (a.queue && t2 == 0)
             Lnext = gridDim.x + __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // C -= acc, one accumulator block (4 elements) at a time: loads first, then the stores (written as
-        // `*p -= acc` the compiler must assume that a store aliases the next load and serialises the memory
-        // round trips; all sixteen at once would cost the 8th wave per SIMD in registers)
-        double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi + (lane & 15)) +
-                     (size_t)(tj * TM + (TM / 2) * wj + (lane >> 4)) * a.ldc;
+        // (the store offsets are re-derived from a laundered copy: kept from the loads they would live through the whole
+        // K loop and spill)
+        unsigned cve = cvo;
+        asm volatile("" : "+v"(cve));
 #pragma unroll
         for (int x = 0; x < NB; ++x)
 #pragma unroll
             for (int y = 0; y < NB; ++y) {
-                double *p = Cb + 16 * x + (size_t)(16 * y) * a.ldc;
-                d4 cv;
+                if (wt_wg) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cv[r] = p[(size_t)(4 * r) * a.ldc];
-                cv -= acc[x][y];
-                if (sig_wg) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) store_wt(p + (size_t)(4 * r) * a.ldc, cv[r]);
+                    for (int r = 0; r < 4; ++r)
+                        store_wt((double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)), acc[x][y][r]);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) p[(size_t)(4 * r) * a.ldc] = cv[r];
+                    for (int r = 0; r < 4; ++r)
+                        *(double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)) = acc[x][y][r];
                 }
             }
-        if (sig_wg) {
+        if (wt_wg) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t2 == 0) signal_add(a.sig + a.sig_tile + sig_Ti);
+            if (t2 == 0) {
+                if (sig_wg) signal_add(a.sig + a.sig_tile + sig_Ti);
+                if (near_wg) signal_add(a.near);
+            }
         }
         if (!a.queue) break;
         if (t2 == 0) *share = Lnext;
@@ -794,6 +1082,22 @@ update_kernel(UpdArgs a)
         // (the next write to the word comes after the barriers of the next tile, which no wave passes before
         // all have read it here)
     }
+}
+
+void launch_panel(double *A, size_t lda, int t, int two, int r0, int r1, const double *winv,
+                  unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s)
+{
+    const int nb = (r1 - r0) / 64;
+    if (nb <= 0) return;
+    PanelArgs a;
+    a.A = A; a.lda = lda; a.c0 = t * TILE; a.two = two; a.row0 = r0;
+    a.w0 = winv + (size_t)(t & 1) * TILE * TILE;
+    a.w1 = winv + (size_t)((t + 1) & 1) * TILE * TILE;
+    a.out0 = out + t; a.xr0 = xr + t; a.out1 = out + t + 1; a.abort_word = abort_word;
+    constexpr int KC = 32;
+    const size_t shm = 4 * (size_t)KC * (64 + 16) * sizeof(double);      // 81,920 B of dynamic LDS (> the 64 KB default)
+    (void)hipFuncSetAttribute((const void *)panel_kernel<64, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL((panel_kernel<64, KC>), dim3(nb), dim3(256), shm, s, a);
 }
 
 // ---------------------------------------------------------------------------
@@ -1110,12 +1414,13 @@ void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s)
 }
 
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
-                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s)
+                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
+                         double *winv, int w_until)
 {
     if (t0 >= nt) return;
     EngineArgs e;
     e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
-    e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive;
+    e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive; e.winv = winv; e.w_until = winv ? w_until : 0;
     // 136 KB: the 128 KB LDS copy of X plus the flag word; leaves room for ONE update workgroup beside the
     // engine.  (Asking for all 160 KB measured 7 % slower trailing updates chip-wide while the engine was
     // resident; 76 .. 152 KB did not.)
@@ -1145,17 +1450,21 @@ static bool upd_form4()
     return form4 != 0;
 }
 
-void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
+bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig, int sig_tile,
-                        unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0)
+                        unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
+                        unsigned *near, int near_tiles, const UpdStrips *strips)
 {
     // tile rows [ti0, ti1), or -- band-limited -- [ti0, band_hi) and [ext0, ti1)
     const bool band = band_hi >= 0;
     const int rows_band = (band ? band_hi : ti1) - ti0, rows_ext = band ? ti1 - ext0 : 0;
-    if (rows_band + rows_ext <= 0 || rows_band < 0 || rows_ext < 0 || tj1 <= tj0 || K <= 0) return;
+    if (rows_band + rows_ext <= 0 || rows_band < 0 || rows_ext < 0 || tj1 <= tj0 || K <= 0) return false;
     UpdArgs a;
     a.queue = nullptr; a.ntiles = 0;
+    a.near = near; a.near_tj0 = 2 * tj0; a.near_w = 2 * near_tiles;
+    a.nstrips = 0; a.strip_pos = 0; a.near_need = 0;
+    memset(&a.pan, 0, sizeof a.pan);
     a.Hb = 2 * rows_band; a.ext0 = 2 * ext0;
     a.C = A; a.ldc = lda; a.P = P; a.ldp = ldp; a.K = K;
     a.lower_only = lower_only ? 1 : 0;
@@ -1173,17 +1482,33 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
         else {
             const long long H = 2LL * (rows_band + rows_ext), W = 2LL * (tj1 - tj0);
             a.H = (int)H; a.W = (int)W;
-            const long long total = W * H - W * (W - 1) / 2;
+            long long total = W * H - W * (W - 1) / 2;
+            static int slots = 0;
+            if (!slots) {
+                int dev = 0, cus = 256;
+                hipGetDevice(&dev);
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                slots = 8 * cus;
+            }
+            // (a strip waits for tiles of this launch: every workgroup must be resident or draw its tasks in order)
+            if (strips && strips->nstrips > 0 && near && !band && world == 1 && !upd_form4() &&
+                (queue || total + strips->nstrips <= slots - 8)) {
+                // the next panel's strips ride in this launch, `lead` tiles behind the near tiles (time for the engine)
+                const long long nnear = (long long)update_near_count(ti0, ti1, near_tiles);
+                long long pos = nnear + strips->lead;
+                if (pos > total) pos = total;
+                a.nstrips = strips->nstrips; a.strip_pos = (unsigned)pos; a.near_need = (unsigned)nnear;
+                a.pan.A = A; a.pan.lda = lda; a.pan.c0 = tj0 * TILE; a.pan.two = near_tiles > 1 ? 1 : 0;
+                a.pan.row0 = strips->row0;
+                a.pan.w0 = strips->winv + (size_t)(tj0 & 1) * TILE * TILE;
+                a.pan.w1 = strips->winv + (size_t)((tj0 + 1) & 1) * TILE * TILE;
+                a.pan.out0 = strips->out + tj0; a.pan.xr0 = strips->xr + tj0; a.pan.out1 = strips->out + tj0 + 1;
+                a.pan.abort_word = abort_word;
+                total += a.nstrips;
+            }
             grid = dim3((unsigned)total, 1);
             if (queue && world == 1 && !upd_form4()) {
                 // dynamic tile order: as many workgroups as the chip holds (8 per CU), tiles off *queue (zero now)
-                static int slots = 0;
-                if (!slots) {
-                    int dev = 0, cus = 256;
-                    hipGetDevice(&dev);
-                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-                    slots = 8 * cus;
-                }
                 // (one CU's worth fewer: the engine owns a CU, and a workgroup that is not resident from the
                 // start would take its first, static tile late)
                 if (total > slots) {
@@ -1205,14 +1530,37 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
         if (trailing) hipLaunchKernelGGL((update4_kernel<0>), grid, dim3(256), 4 * 8192, s, a);
         else hipLaunchKernelGGL((update4_kernel<1>), grid, dim3(256), 4 * 8192, s, a);
     }
+    return a.nstrips > 0;
 }
 
-void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
+bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig, int sig_tile,
-                   unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0)
+                   unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
+                   unsigned *near, int near_tiles, const UpdStrips *strips)
 {
-    launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile,
-                       wait_word, abort_word, queue, band_hi, ext0);
+    return launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile,
+                              wait_word, abort_word, queue, band_hi, ext0, near, near_tiles, strips);
+}
+
+// tiles of 64 x 64 in the first `near_tiles` (128-wide) tile columns of the trapezoid launch_update(..., lower_only, ti0 ==
+// tj0, rows up to ti1) covers: what *near counts up to
+unsigned update_near_count(int ti0, int ti1, int near_tiles)
+{
+    const int H = 2 * (ti1 - ti0), W = 2 * near_tiles;
+    return (unsigned)(W * H - W * (W - 1) / 2);
+}
+
+// one lane that waits until *word >= need (bounded: sets the abort word on a time-out): holds a stream back until
+// the producers of another, still running launch have delivered
+__global__ void __launch_bounds__(64)
+flag_gate_kernel(unsigned *word, unsigned need, unsigned *abort_word, unsigned code)
+{
+    if (threadIdx.x == 0) (void)wait_ge<false>(word, need, abort_word, code);
+}
+
+void launch_flag_gate(unsigned *word, unsigned need, unsigned *abort_word, unsigned code, hipStream_t s)
+{
+    hipLaunchKernelGGL(flag_gate_kernel, dim3(1), dim3(64), 0, s, word, need, abort_word, code);
 }
 
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,

@@ -98,8 +98,18 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
 //   xr[t]    raised to 1 when X = A(t+1,t) L(t)^-T is published.
 // abort_word: set by any party whose bounded wait ran out; everybody leaves when it is non-zero.
 //   alive    raised by the engine once it is resident; launch_engine_gate(alive, ...) holds a stream until then
+// winv != NULL: 2 x 128 x 128 doubles, zero at launch outside what the engine writes -- the engine also publishes
+//   W = L^-1 of every diagonal tile there (by tile parity, column-major, ld 128) BEFORE it raises out[tile]: the operand
+//   of launch_panel
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
-                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s);
+                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
+                         double *winv = nullptr, int w_until = 0);     // W only for blocks starting at a tile < w_until
+// Panel of the 256-column block at tile t under the engine schedule, ONE launch: rows [r0, r1) (multiples of 64) of
+// tile columns t and (two != 0) t + 1:   X0 = B0 W(t)^T ;  B1 -= X0 X(t+1,t)^T ;  X1 = B1 W(t+1)^T  -- the panel solve as
+// three small GEMMs per 64-row strip on the update kernel's inner loop and footprint (no dependent chain).  Each
+// stage first waits for the engine's word: out[t] (factor and W of tile t), xr[t] (X(t+1,t)), out[t+1].
+void launch_panel(double *A, size_t lda, int t, int two, int r0, int r1, const double *winv,
+                  unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s);
 void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s);
 // rows [r0, r1) x cols [c0, c0+128):  X <- X * L(c0)^{-T}, L read from A(c0,c0).
 // wait_word != NULL: the tile comes from the engine -- every workgroup first waits for *wait_word >= 1
@@ -112,19 +122,35 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
 // wait_word: an operand tile comes from the engine -- every workgroup first waits for *wait_word >= 1.
 // queue: a device word that is ZERO when the launch starts -- the launch then takes about as many workgroups
 // as the chip holds and they draw the tiles of the trapezoid from that counter (lower_only launches).
-void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
+// Strips of the NEXT panel as tasks of a trailing-update launch (launch_update's `strips`, with `near`): the 64-row strips
+// from row0 on, nstrips of them, the block's panel as launch_panel computes it, taken by the launch's workgroups `lead`
+// tiles behind the near tiles.  winv / out / xr as for launch_panel.
+struct UpdStrips {
+    int nstrips, row0, lead;
+    const double *winv;
+    unsigned *out, *xr;
+};
+// (returns true when `strips` were taken into the launch; false: the caller forms the panel itself, e.g. launch_panel)
+bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig = nullptr, int sig_tile = -1,
                    unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
-                   int band_hi = -1, int ext0 = 0);      // band_hi >= 0: tile rows [ti0, band_hi) and [ext0, ti1)
+                   int band_hi = -1, int ext0 = 0,       // band_hi >= 0: tile rows [ti0, band_hi) and [ext0, ti1)
+                   unsigned *near = nullptr, int near_tiles = 0, const UpdStrips *strips = nullptr);
+// near / near_tiles (lower_only launches): the tiles in the first near_tiles tile columns -- the next panel -- are stored
+// write-through and each adds 1 to *near when done; update_near_count() says how many there are.  A stream that has
+// passed launch_flag_gate(near, count, ...) may read them although the update launch is still running.
+unsigned update_near_count(int ti0, int ti1, int near_tiles);
+void launch_flag_gate(unsigned *word, unsigned need, unsigned *abort_word, unsigned code, hipStream_t s);
 // like launch_update but the (i,k) and (j,k) operands come from a separate packed
 // panel buffer P (ldp rows, row index = global row), used by the sharded path.
 // (ptiles, world, rank): when world > 1 only tile columns tj with (tj / ptiles) % world == rank
 // are updated (block-cyclic panel ownership).
-void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
+bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig = nullptr, int sig_tile = -1,
                         unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
-                        int band_hi = -1, int ext0 = 0);
+                        int band_hi = -1, int ext0 = 0, unsigned *near = nullptr, int near_tiles = 0,
+                        const UpdStrips *strips = nullptr);
 
 
 // reductions: out[0] = sum_{i<n} log(A(i,i)); out[1 + a*nr + b] = sum_{c<n} A(row0+a,c) A(row0+b,c)

@@ -87,6 +87,14 @@ class ShardedFit(CoconsFit):
         _lib.check(self._L.cocons_fit_comm_init(self._h, world, rank, ctypes.cast(idb, ctypes.c_void_p)),
                    "cocons_fit_comm_init")
 
+    def comm_info(self):
+        """{"count": ncclCommCount, "rank": ncclCommUserRank, "device": ncclCommCuDevice} of this fit's communicator
+        (world / rank / device for a caller-provided transport; count 0 without collectives)."""
+        c, u, d = ctypes.c_int(0), ctypes.c_int(-1), ctypes.c_int(-1)
+        _lib.check(self._L.cocons_fit_comm_info(self._h, ctypes.byref(c), ctypes.byref(u), ctypes.byref(d)),
+                   "cocons_fit_comm_info")
+        return {"count": c.value, "rank": u.value, "device": d.value}
+
     def init_host_transport(self, dist, rank, world, group=None):
         """Tests: serve the library's broadcast / all-reduce hooks with `dist` (gloo) through host memory."""
         import torch
@@ -149,6 +157,26 @@ class MultiFit:
         _lib.check(self._L.cocons_multi_neg2loglik_dense(self._h, _p(T), _p(mean), ctypes.byref(val), _p(parts)),
                    "cocons_multi_neg2loglik_dense")
         return val.value, parts
+
+    def neg2loglik_batch_core(self, theta_lists):
+        """Independent evaluations dealt over the handle's devices (replica mode, cocons_multi_neg2loglik_batch):
+        (values, status) like CoconsFit.neg2loglik_batch_core."""
+        nb = len(theta_lists)
+        T = np.ascontiguousarray(np.stack([theta_table(t) for t in theta_lists], axis=0)) if nb else np.zeros((0, 6, self.p))
+        M = np.ascontiguousarray(np.stack([np.asarray(t["mean"], dtype=np.float64) for t in theta_lists], axis=0)) \
+            if nb else np.zeros((0, self.p))
+        vals = np.zeros(nb)
+        st = np.zeros(nb, dtype=np.int32)
+        _lib.check(self._L.cocons_multi_neg2loglik_batch(self._h, nb, _p(T), _p(M), _p(vals),
+                                                         st.ctypes.data_as(ctypes.POINTER(ctypes.c_int))),
+                   "cocons_multi_neg2loglik_batch")
+        return vals, st
+
+    def comm_ranks(self):
+        """(devices of the handle, ncclCommCount of its communicators; 0 = none)."""
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._L.cocons_multi_comm_ranks(self._h, ctypes.byref(a), ctypes.byref(b)), "cocons_multi_comm_ranks")
+        return a.value, b.value
 
     def predict_core(self, theta_list, locs_pred, x_covariates_pred, z_col=0):
         """(stochastic, quadform) of cocoPredict's dense core, the prediction locations split over the devices."""

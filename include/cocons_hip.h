@@ -253,6 +253,19 @@ int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *theta, const do
 int cocons_multi_predict_dense(cocons_multi *m, const double *theta, const double *mean, int z_col,
                                int m_pred, const double *locs_pred, const double *X_pred,
                                double *stochastic, double *quadform);
+/* Replica mode inside ONE process: the nb independent parameter points of a finite-difference
+ * gradient (R/optim.R:256-259, 1 + 2P points) or of getHessian (R/getFunctions.R:979-1016) dealt over the devices
+ * of the handle (point i on device i mod ndev), every device running its share through cocons_neg2loglik_batch on its
+ * own fit; no collective, so the handle may list a device more than once.  Arguments as cocons_neg2loglik_batch. */
+int cocons_multi_neg2loglik_batch(cocons_multi *m, int nb, const double *thetas, const double *means,
+                                  double *values, int *status);
+/* What the communicators really span: *ndev = devices of the handle, *rccl_count = ncclCommCount of its first
+ * communicator (0: no communicator -- a device is listed twice).                                                  */
+int cocons_multi_comm_ranks(cocons_multi *m, int *ndev, int *rccl_count);
+/* The same for a fit with collectives of its own (cocons_fit_comm_init / cocons_fit_set_collectives): ncclCommCount,
+ * ncclCommUserRank, ncclCommCuDevice (or the caller-provided world / rank and the fit's device).  bench.py prints
+ * them for every rank.                                                                                            */
+int cocons_fit_comm_info(cocons_fit *fit, int *count, int *user_rank, int *device);
 
 /* ---- column-panel sharded evaluation, step by step (the building blocks of the above; kept public for
  * callers that bring their own schedule, and used by the CPU tests of the schedule) --------------------

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "shared_gpu: several processes use the GPU at once (engine time-outs allowed)")
 
 
 @pytest.fixture(scope="session")
@@ -22,3 +23,40 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _engine_never_times_out(request):
+    """Every fit handle a GPU test creates is checked at the end of the test: the resident diagonal-block engine must not
+    have timed out (cocons_fit_engine_state: retries == 0) -- a silent fall-back to the plain schedule would otherwise
+    pass every parity test.  Tests that SHARE the GPU between processes are exempt (marker `shared_gpu`)."""
+    if request.node.get_closest_marker("gpu") is None or request.node.get_closest_marker("shared_gpu") is not None:
+        yield
+        return
+    from cocons_amd import host
+    made = []
+    orig_init, orig_taper_init, orig_close = host.CoconsFit.__init__, host.CoconsTaperFit.__init__, host.CoconsFit.close
+
+    def init(self, *a, **k):
+        orig_init(self, *a, **k)
+        made.append(self)
+
+    def taper_init(self, *a, **k):
+        orig_taper_init(self, *a, **k)
+        made.append(self)
+
+    retries = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            retries.append(self.engine_state()["retries"])
+        orig_close(self)
+
+    host.CoconsFit.__init__, host.CoconsTaperFit.__init__, host.CoconsFit.close = init, taper_init, close
+    try:
+        yield
+        for f in made:
+            f.close()
+    finally:
+        host.CoconsFit.__init__, host.CoconsTaperFit.__init__, host.CoconsFit.close = orig_init, orig_taper_init, orig_close
+    assert all(r == 0 for r in retries), "engine hand-off time-outs in this test: %r" % retries

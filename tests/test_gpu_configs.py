@@ -243,6 +243,7 @@ def _shard_worker(rank, world, port, g, out_dir, predict_first=False):
     dist.destroy_process_group()
 
 
+@pytest.mark.shared_gpu
 @pytest.mark.parametrize("world,g,predict_first", [(2, 40, False), (3, 50, False), (4, 15, False), (2, 40, True),
                                                    (2, 100, False)])
 def test_native_sharded_evaluation_shared_gpu(tmp_path, world, g, predict_first):
@@ -337,6 +338,7 @@ def _c5_problem():
     return locs, X, th, z, lp, Xp
 
 
+@pytest.mark.shared_gpu
 def test_c5_predict_split_two_ranks(tmp_path):
     """C5 as BASELINE states it: n_train = m_pred = 8192 with the prediction locations split over
     2 ranks (cocons_amd.shard.sharded_predict_core with real fit handles; both ranks share this
@@ -371,3 +373,104 @@ def test_c5_predict_split_native_multi_handle():
     st1, qf1 = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS).predict_core(th, lp, Xp)
     assert np.max(np.abs(st - st1)) <= 1e-10 * np.max(np.abs(st1))
     assert np.max(np.abs(qf - qf1)) <= 1e-10 * np.max(np.abs(qf1))
+
+
+def _optim_worker(rank, world, port, g, nevals, out_dir):
+    """One of cocoOptim's worker processes (R/optim.R:117-121, :234-259): its own library instance and its own fit
+    handle on device 0, evaluating the objective at its share of the parameter points while the other workers do the
+    same on the same GPU."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import time
+    import torch                      # noqa: F401
+    import torch.distributed as dist
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    locs, X, th, z = _grid_problem(g)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, device=0)
+    fit.neg2loglik_core(th)                         # first call: allocations, code load
+    dist.barrier()                                  # every worker starts its evaluations at the same time
+    t0 = time.perf_counter()
+    vals = []
+    for e in range(nevals):
+        t = {k: np.array(v, dtype=float).copy() for k, v in th.items()}
+        t["std.dev"][1] += 0.01 * (rank * nevals + e)          # every point of every worker is a different theta
+        vals.append(fit.neg2loglik_core(t)[0])
+    wall = time.perf_counter() - t0
+    st = fit.engine_state()
+    np.save(os.path.join(out_dir, "worker%d.npy" % rank),
+            np.array(vals + [st["retries"], st["last_abort"], 1.0 if st["active"] else 0.0, wall]))
+    dist.barrier()
+    fit.close()
+    dist.destroy_process_group()
+
+
+def test_multi_handle_replica_batch(oracle):
+    """Replica mode for one R process (R/optim.R:256-259, R/getFunctions.R:979-1016): the points of a
+    finite-difference gradient dealt over the devices of a multi handle -- here the device list [0, 0], two fits with
+    their own slots on the one GPU, driven by two host threads -- against single evaluations and the CPU oracle."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    from cocons_amd.shard import MultiFit
+    locs, X, th, z = _grid_problem(40)
+    pts = []
+    for i in range(9):
+        t = {k: np.array(v, dtype=float).copy() for k, v in th.items()}
+        t["scale"][1] += 0.02 * i
+        t["mean"] = np.array([0.1 * i, 0.0, -0.05])
+        pts.append(t)
+    bad = {k: np.array(v, dtype=float).copy() for k, v in th.items()}
+    bad["nugget"][0] = -800.0
+    bad["std.dev"][0], bad["scale"][0] = 0.0, 30.0
+    pts.insert(4, bad)                                        # a point whose Sigma is not positive definite
+    mf = MultiFit(locs, X, z, wl.SMOOTH_LIMITS, devices=[0, 0])
+    assert mf.comm_ranks() == (2, 0)                          # no communicator over a repeated device, none needed
+    vals, st = mf.neg2loglik_batch_core(pts)
+    mf.close()
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    for i, t in enumerate(pts):
+        if i == 4:
+            assert st[i] > 0 and np.isnan(vals[i])
+            continue
+        assert st[i] == 0
+        one = fit.neg2loglik_core(t)[0]                       # (engine schedule; the batch slots run the plain one)
+        assert abs(vals[i] - one) <= 1e-12 * abs(one)
+        if i in (0, 7):                                       # the CPU restatement of the same core (no penalty)
+            S = oracle.cov_rns(t, locs, X, wl.SMOOTH_LIMITS)
+            info, ld, quad, _ = oracle.chol_ld(S, (z - X @ t["mean"]).reshape(-1, 1))
+            want = z.size * math.log(2 * math.pi) + 2 * ld + float(quad[0])
+            assert abs(vals[i] - want) <= 1e-8 * abs(want)
+    fit.close()
+
+
+@pytest.mark.shared_gpu
+def test_worker_processes_share_one_gpu(tmp_path):
+    """The reference's own calling pattern on the HIP path: `ncores` worker PROCESSES (here 3), each with a handle of
+    its own on the one device, evaluating concurrently at n = 4096 (R/optim.R:117-121, 234-259).  Every value must
+    equal the single-process value; each process's engine needs a CU to itself while the others' updates fill the
+    chip, so hand-off time-outs are allowed here -- each costs one repeat on the plain schedule and is counted.  The
+    per-process count and wall time are printed (and recorded in DESIGN.md)."""
+    import torch.multiprocessing as mp
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    world, g, nevals = 3, 64, 10
+    mp.spawn(_optim_worker, args=(world, _free_port(), g, nevals, str(tmp_path)), nprocs=world, join=True)
+    locs, X, th, z = _grid_problem(g)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    import time
+    t0 = time.perf_counter()
+    for rank in range(world):
+        res = np.load(os.path.join(str(tmp_path), "worker%d.npy" % rank))
+        for e in range(nevals):
+            t = {k: np.array(v, dtype=float).copy() for k, v in th.items()}
+            t["std.dev"][1] += 0.01 * (rank * nevals + e)
+            want = fit.neg2loglik_core(t)[0]
+            assert abs(res[e] - want) <= 1e-10 * abs(want), (rank, e)
+        print("worker %d: %d evaluations in %.1f ms, engine time-outs %d (last code 0x%x), engine active at the end: %d"
+              % (rank, nevals, 1e3 * res[nevals + 3], int(res[nevals]), int(res[nevals + 1]), int(res[nevals + 2])))
+    single = time.perf_counter() - t0
+    print("the same %d evaluations from ONE process, one after the other: %.1f ms" % (world * nevals, 1e3 * single))
+    assert fit.engine_state()["retries"] == 0            # alone on the device the engine never times out
+    fit.close()

@@ -790,6 +790,26 @@ def test_device_matern_large_argument_branch_vs_mpmath():
     assert rel.max() < 1e-13, (rel.max(), nu[ok][rel.argmax()], u[ok][rel.argmax()])
 
 
+def test_device_matern_large_orders_vs_mpmath():
+    """Orders beyond what the Hankel branch is validated for (nu > 3.5; smooth_limits are the user's) stay on the
+    continued fraction for every u: against 40-digit mpmath at nu up to 15, u from 2 to 300."""
+    import mpmath as mp
+    from cocons_amd import _lib
+    mp.mp.dps = 40
+    rng = np.random.default_rng(78)
+    nu = np.concatenate([rng.uniform(3.5, 15.0, 300), [3.5, 3.5000001, 8.0, 15.0, 15.0, 12.25]])
+    u = np.concatenate([rng.uniform(2.0, 60.0, 200), rng.uniform(60.0, 300.0, 100), [20.0, 20.0, 20.0, 20.0, 45.0, 19.9]])
+    want = np.array([float(mp.power(2, 1 - mp.mpf(a)) / mp.gamma(mp.mpf(a)) * mp.power(mp.mpf(b), mp.mpf(a)) *
+                           mp.besselk(mp.mpf(a), mp.mpf(b))) for a, b in zip(nu, u)])
+    out = np.empty_like(u)
+    L = _lib.load()
+    _lib.check(L.cocons_debug_matern(u.size, nu.ctypes.data_as(_lib.c_dp), u.ctypes.data_as(_lib.c_dp),
+                                     out.ctypes.data_as(_lib.c_dp)), "cocons_debug_matern")
+    ok = want > 1e-290
+    rel = np.abs(out[ok] - want[ok]) / want[ok]
+    assert rel.max() < 2e-13, (rel.max(), nu[ok][rel.argmax()], u[ok][rel.argmax()])
+
+
 def test_alternative_update_kernel_in_subprocess():
     """The 4x4x4-MFMA trailing-update kernel (COCONS_UPD_MFMA4=1, an alternative kept beside the default)
     through the same parity checks as the default: Cholesky vs long-double truth and -2 loglik vs the CPU
