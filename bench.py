@@ -186,6 +186,20 @@ def main():
         def step():
             return fit.neg2loglik_core(th)[0]
 
+    # N > 1, sharded: what RCCL itself says about the communicator of every rank (ncclCommCount / UserRank / CuDevice)
+    comm = None
+    if shard_mode:
+        mine = fit.comm_info()
+        mine["rank_env"], mine["local_rank"], mine["pid"] = rank, local_rank, os.getpid()
+        allinfo = [None] * world
+        dist.all_gather_object(allinfo, mine, group=ctl)
+        comm = {"transport": "gloo host transport (rehearsal)" if rehearsal else "RCCL",
+                "rccl_ranks": int(allinfo[0]["count"]), "ranks": allinfo,
+                "distinct_devices": len({(a["device"]) for a in allinfo})}
+        if not rehearsal and (comm["rccl_ranks"] != world or comm["distinct_devices"] != world):
+            sys.exit("bench.py: RCCL reports %d ranks on %d distinct devices, expected %d"
+                     % (comm["rccl_ranks"], comm["distinct_devices"], world))
+
     val = None
     for _ in range(args.warmup):
         val = step()
@@ -198,6 +212,12 @@ def main():
     evals = args.steps * (world if (world > 1 and not shard_mode) else 1)
     evals_per_s = evals / dt
     ms_per_step = 1e3 * dt / args.steps
+    # did the timed handle run on the schedule it claims?  (a hand-off time-out repeats the evaluation on the plain
+    # schedule and is counted: cocons_fit_engine_state)
+    es = fit.engine_state()
+    engine = {"engine_active": es["active"], "engine_retries": es["retries"], "engine_last_abort": es["last_abort"],
+              "switches": {k: os.environ.get(k) for k in ("COCONS_ENGINE", "COCONS_PANEL_MODE", "COCONS_UPD_DYNAMIC",
+                                                         "COCONS_UPD_MFMA4") if os.environ.get(k) is not None}}
 
     # extra (N>1, sharded mode): the replica mode on the same ranks -- every rank evaluates its
     # own theta with its own fit, no collective in the data path ("weak" scaling).
@@ -380,6 +400,8 @@ def main():
             "cholesky_frac": round(chol_tf / FP64_MFMA_PEAK_TFLOPS, 4),
             "cholesky_note": "n^3/3 flop / cholesky_ms of ONE GPU (stages_ms); bordered factorisation incl. the solve",
             "stages_ms": stages,
+            "engine": engine,
+            "comm": comm,
             "neg2loglik": val,
             "throughput_inflight": inflight,
             "throughput_batch_api": batch,

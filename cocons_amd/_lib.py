@@ -99,6 +99,7 @@ DIAG_SIGNATURES = {
     "cocons_vfma_f64_probe": (c_int, [c_int, c_dp]),
     "cocons_debug_matern": (c_int, [c_int, c_dp, c_dp, c_dp]),
     "cocons_corun_probe": (c_int, [c_int, c_int, c_int, c_int, c_dp]),
+    "cocons_debug_tune": (c_int, [ctypes.c_char_p, c_int]),
 }
 
 

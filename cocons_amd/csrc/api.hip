@@ -823,17 +823,52 @@ static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
     }
 }
 
+// Schedule switches: read from the environment once per process, and settable afterwards through cocons_debug_tune (the
+// diagnostics header) so that variants can be timed in alternation inside ONE process on ONE device.
+struct Tunables {
+    int engine = 1;          // COCONS_ENGINE: 1 = diagonal blocks are factored by the resident engine beside the updates
+    int panel_mode = 2;      // COCONS_PANEL_MODE, see panel_mode()
+    int strip_lead = 3600;   // COCONS_STRIP_LEAD
+    int strip_min = 3600;    // COCONS_STRIP_MIN
+    int overlap = 0;         // COCONS_PANEL_OVERLAP
+    int upd_dynamic = 1;     // COCONS_UPD_DYNAMIC
+    bool init = false;
+};
+static Tunables &tun()
+{
+    static Tunables t;
+    if (!t.init) {
+        auto rd = [](const char *name, int &v) { const char *e = getenv(name); if (e) v = atoi(e); };
+        rd("COCONS_ENGINE", t.engine);
+        rd("COCONS_PANEL_MODE", t.panel_mode);
+        rd("COCONS_STRIP_LEAD", t.strip_lead);
+        rd("COCONS_STRIP_MIN", t.strip_min);
+        rd("COCONS_PANEL_OVERLAP", t.overlap);
+        rd("COCONS_UPD_DYNAMIC", t.upd_dynamic);
+        if (t.panel_mode < 0 || t.panel_mode > 2) t.panel_mode = 2;
+        t.init = true;
+    }
+    return t;
+}
+
+extern "C" int cocons_debug_tune(const char *name, int value)
+{
+    if (!name) return fail(-1, "cocons_debug_tune: null name");
+    Tunables &t = tun();
+    std::string k(name);
+    if (k == "engine") t.engine = value;
+    else if (k == "panel_mode") t.panel_mode = value;
+    else if (k == "strip_lead") t.strip_lead = value;
+    else if (k == "strip_min") t.strip_min = value;
+    else if (k == "overlap") t.overlap = value;
+    else if (k == "upd_dynamic") t.upd_dynamic = value;
+    else return fail(-1, "cocons_debug_tune: unknown switch %s", name);
+    return 0;
+}
+
 // COCONS_ENGINE: 1 (default) = diagonal tiles are factored by the resident engine while the trailing
 // update runs; 0 = every kernel in order on one stream
-static bool engine_enabled()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("COCONS_ENGINE");
-        v = e ? atoi(e) : 1;
-    }
-    return v != 0;
-}
+static bool engine_enabled() { return tun().engine != 0; }
 
 // one trailing-update launch (tile columns [t0, t1) of the trapezoid below (t0, t0)), optionally
 // bracketed by timing events (profile runs): appended as (start, stop)
@@ -900,8 +935,7 @@ static int flags_reset(cocons_fit *f, int nt)
 // one tile counter per trailing update: see update_kernel's dynamic tile order (COCONS_UPD_DYNAMIC=0: static)
 static unsigned *tile_queue(cocons_fit *f, int k)
 {
-    static int dyn = -1;
-    if (dyn < 0) { const char *e = getenv("COCONS_UPD_DYNAMIC"); dyn = e ? atoi(e) : 1; }
+    const int dyn = tun().upd_dynamic;
     return dyn ? f->dflags + 3 * (size_t)f->flags_cap + 64 + k / 2 : nullptr;
 }
 
@@ -912,31 +946,17 @@ static unsigned *tile_queue(cocons_fit *f, int k)
 //       that update is long enough to hide the engine's chain behind its first tiles, mode 0 for the later, short blocks
 static int panel_mode()
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("COCONS_PANEL_MODE");
-        v = e ? atoi(e) : 2;
-        if (v < 0 || v > 2) v = 2;
-        const char *m4 = getenv("COCONS_UPD_MFMA4");           // the alternative update kernel knows no strips
-        if (m4 && atoi(m4) != 0 && v == 2) v = 0;
-    }
+    int v = tun().panel_mode;
+    static int m4 = -1;                                        // the alternative update kernel knows no strips
+    if (m4 < 0) { const char *e = getenv("COCONS_UPD_MFMA4"); m4 = e ? atoi(e) : 0; }
+    if (m4 != 0 && v == 2) v = 0;
     return v;
 }
 
 // mode 2: tiles of the trailing update in front of the strips (time for the engine: ~2040 tiles run at once and take
 // ~75 us), and the fewest far tiles a block must have to carry its strips at all
-static int strip_lead()
-{
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("COCONS_STRIP_LEAD"); v = e ? atoi(e) : 3600; }
-    return v;
-}
-static int strip_min_far()
-{
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("COCONS_STRIP_MIN"); v = e ? atoi(e) : 3600; }
-    return v;
-}
+static int strip_lead() { return tun().strip_lead; }
+static int strip_min_far() { return tun().strip_min; }
 
 // first tile of the first block whose panel is NOT formed with the engine's tile inverses (the engine computes them
 // for the blocks before it only): mode 1 -> all blocks, mode 0 -> none, mode 2 -> while the update has enough far tiles
@@ -1033,8 +1053,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     // U(k)'s tile order) P's gate opens and the panel kernels are placed as soon as U(k)'s retiring workgroups leave room --
     // in the tail of U(k), where the chip drains anyway.  U(k+2) waits for the panel's event.  COCONS_PANEL_OVERLAP=0:
     // everything in order on the main stream (the round-2 schedule).
-    static int overlap = -1;
-    if (overlap < 0) { const char *e = getenv("COCONS_PANEL_OVERLAP"); overlap = e ? atoi(e) : 0; }
+    const int overlap = tun().overlap;
     hipStream_t P = overlap ? f->stream3 : M;
     if (overlap) HIPCHK(hipStreamWaitEvent(P, f->ev_eng, 0));     // behind the reset of the flag words
     const int w_until = panel_w_until(v);
@@ -1175,6 +1194,7 @@ extern "C" int cocons_neg2loglik_dense(cocons_fit *f, const double *theta, const
     if (int rc = fit_check(f)) return rc;
     if (!theta || !mean || !sum_logliks) return fail(-1, "cocons_neg2loglik_dense: null argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_dense: fit has no z");
+    if (f->coll_kind < 0) return fail(-7, "cocons_neg2loglik_dense: the communicator of this fit was aborted after an error");
     if (f->coll_kind) return sharded_eval(f, theta, mean, sum_logliks, parts);    // (also with one rank: the caller asked for it)
     for (;;) {
         if (int rc = enqueue_eval(f, theta, mean, true, nullptr, 0, nullptr, false)) return rc;
@@ -2355,7 +2375,27 @@ static int shard_step_post(cocons_fit *f, int k, int np)
     return shard_apply_range(f, k, k + 1, -1);
 }
 
+static int sharded_eval_impl(cocons_fit *f, const double *theta, const double *mean, double *sum_logliks, double *parts);
+
+// A rank that fails in the middle of the schedule (HIP or RCCL error: status < 0) must not leave its peers blocked in
+// the next collective until a watchdog fires: it aborts its communicator, which makes the peers' pending RCCL calls
+// fail, and the handle refuses further sharded evaluations.  (status > 0 -- Sigma not positive definite -- is an
+// ordinary result that every rank reaches together.)
 static int sharded_eval(cocons_fit *f, const double *theta, const double *mean, double *sum_logliks, double *parts)
+{
+    const int rc = sharded_eval_impl(f, theta, mean, sum_logliks, parts);
+    if (rc < 0 && f->coll_kind == 1 && f->comm && f->coll_world > 1) {
+        const std::string keep = g_err;
+        RcclApi *R = rccl_api();
+        if (R) (void)R->CommAbort(f->comm);
+        f->comm = nullptr;
+        f->coll_kind = -1;                      // poisoned: see cocons_neg2loglik_dense
+        g_err = keep + " (communicator aborted)";
+    }
+    return rc;
+}
+
+static int sharded_eval_impl(cocons_fit *f, const double *theta, const double *mean, double *sum_logliks, double *parts)
 {
     const int rank = f->coll_rank, world = f->coll_world;
     if (int rc = cocons_shard_begin(f, theta, mean, rank, world)) return rc;

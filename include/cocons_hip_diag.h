@@ -37,6 +37,12 @@ int cocons_debug_matern(int n, const double *nu, const double *u, double *out);
  * runs, out4[2], out4[3] = their durations in ms -- do the matrix and the vector fp64 pipes run concurrently? */
 int cocons_corun_probe(int bpc_mfma, int bpc_vfma, int iters_mfma, int iters_vfma, double *out4);
 
+/* Schedule switches of the factorisation, settable at run time (the library reads the COCONS_* environment variables
+ * of the same meaning once per process): "engine", "panel_mode", "strip_lead", "strip_min", "overlap", "upd_dynamic".
+ * For timing variants in alternation inside one process (tools/ab_modes.py); results do not depend on them beyond the
+ * rounding of a different summation order.                                                                        */
+int cocons_debug_tune(const char *name, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,161 @@
+"""GPU parity tests at sizes where the ENGINE schedule runs (more than four 128-column tiles: the resident diagonal-block
+engine, the dynamic tile order, the GEMM panel) -- every entry point against the CPU oracle, which still finishes in
+seconds at n = 1024 ... 4096.  Closes the thin spots of the small-n tests (tests/test_gpu_parity.py run n = 260 ... 700,
+where the plain schedule is used).  The autouse fixture in conftest.py asserts that no hand-off timed out."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N2LL_RTOL = 1e-8
+
+
+def _grid(gx, gy=None):
+    from cocons_amd import workloads as wl
+    locs = wl.grid_locs(gx, gy)
+    sc = wl.design_from_locs(locs)
+    return locs, sc
+
+
+def test_c5_shifted_grid_n2048_vs_oracle(oracle):
+    """cocoPredict dense (R/predict.R:136-183) in the shape of BASELINE config C5 -- a grid, predictions on the grid shifted
+    by half a cell -- at n = m = 2048 against the CPU restatement: stochastic part and predictive variances."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, sc = _grid(64, 32)
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.3, -0.1, 0.2])
+    z = wl.synthetic_z(2048)
+    lp = locs + np.array([0.5 / 63, 0.5 / 31])
+    Xp = wl.design_from_locs(lp, sc["mean.vector"], sc["sd.vector"])["std.covs"]
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    got = ca.cocoPredict_dense(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS, z, fit=fit)
+    assert fit.engine_state()["active"]
+    want = oracle.cocoPredict_dense(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS, z)
+    assert np.allclose(got["systematic"], want["systematic"], rtol=1e-13, atol=0)
+    assert np.max(np.abs(got["stochastic"] - want["stochastic"])) < 1e-9 * np.max(np.abs(want["stochastic"]))
+    vg, vw = got["sd.pred"] ** 2, want["sd.pred"] ** 2
+    assert np.max(np.abs(vg - vw)) < 1e-11 * np.max(vw)
+
+
+def test_profile_and_reml_n4096_q3_vs_oracle(oracle):
+    """GetNeg2loglikelihoodProfile / ...REML (R/neg2loglikelihood.R:127-165, 241-291) on the 64 x 64 grid with q = 3
+    trend columns and two realisations: the bordered factorisation with r + q rows under the matrix on the engine
+    schedule, against the CPU restatement (chol2inv and the n x n P matrix there)."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n = 4096
+    locs, sc = _grid(64)
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    rng = np.random.default_rng(4096)
+    z = rng.standard_normal((n, 2)) + 0.5 + (X @ np.array([0.0, 0.4, -0.3]))[:, None]
+    pp = wl.par_pos_full()
+    tv = wl.theta_vector_from_lists(th, pp)
+    lam = (0.1, 0.0, 0.3)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, x_betas=X)
+    got = ca.GetNeg2loglikelihoodProfile(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam, fit=fit)
+    assert fit.engine_state()["active"]
+    want = oracle.GetNeg2loglikelihoodProfile(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam)
+    assert abs(got - want) <= N2LL_RTOL * abs(want)
+    got = ca.GetNeg2loglikelihoodREML(tv, pp, locs, X, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    want = oracle.GetNeg2loglikelihoodREML(tv, pp, locs, X, X, wl.SMOOTH_LIMITS, z, n, lam)
+    assert abs(got - want) <= N2LL_RTOL * abs(want)
+
+
+def test_cocoSim_conditional_n2048_m512_vs_oracle(oracle):
+    """cocoSim, conditional branch (R/sim.R:84-127), n = 2048 observed and m = 512 new locations: ONE joint Cholesky of order
+    2560 on the engine schedule against solve + Schur complement + chol + cocoPredict(type = 'mean') on the CPU."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    n, m = 2048, 512
+    rng = np.random.default_rng(2048)
+    locs = rng.uniform(0, 1, size=(n, 2))
+    sc = wl.design_from_locs(locs)
+    X = sc["std.covs"]
+    th = wl.theta_full(scale0=np.log(0.1))
+    th["mean"] = np.array([0.3, -0.2, 0.1])
+    lp = rng.uniform(0, 1, size=(m, 2))
+    Xp = wl.design_from_locs(lp, sc["mean.vector"], sc["sd.vector"])["std.covs"]
+    newdataset = np.column_stack([lp, rng.standard_normal((m, 2))])
+    z = rng.standard_normal(n)
+    E = rng.standard_normal((m, 4))
+    got = ca.cocoSim_cond_dense(th, locs, lp, newdataset, X, Xp, wl.SMOOTH_LIMITS, z, E)
+    want = oracle.cocoSim_cond_dense(th, locs, lp, newdataset, X, Xp, wl.SMOOTH_LIMITS, z, E)
+    assert got.shape == (m, 4)
+    assert np.max(np.abs(got - want)) < 1e-8 * np.max(np.abs(want))
+
+
+def test_fuzz_random_parameters_n1024_r3(oracle):
+    """12 random parameter sets (ranges 0.03 ... 0.6, nuggets 1e-4 ... 0.1, three pairs of smoothness limits, strong
+    covariate effects) at n = 1024 with r = 3 realisations: the engine schedule within the north-star tolerance of the
+    CPU path, or both sides agree that the Cholesky fails."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    rng = np.random.default_rng(1024)
+    n = 1024
+    locs = rng.uniform(0, 1, size=(n, 2))
+    X = wl.design_from_locs(locs)["std.covs"]
+    z = rng.standard_normal((n, 3))
+    pp = wl.par_pos_full()
+    worst, nfail, used_engine = 0.0, 0, 0
+    for it in range(12):
+        lim = [(0.5, 2.5), (0.3, 1.2), (1.0, 3.0)][it % 3]
+        th = wl.theta_full(scale0=np.log(rng.uniform(0.03, 0.6)))
+        for k in ("std.dev", "scale", "aniso", "tilt", "smooth"):
+            th[k] = th[k] + np.r_[0.0, rng.normal(0, 0.4, size=2)]
+        th["nugget"] = np.array([np.log(10 ** rng.uniform(-4, -1)), 0.0, 0.0])
+        tv = wl.theta_vector_from_lists(th, pp)
+        fit = ca.CoconsFit(locs, X, z, lim)
+        got = ca.GetNeg2loglikelihood(tv, pp, locs, X, lim, z, n, (0.1, 0.1, 0.1), fit=fit)
+        used_engine += int(fit.engine_state()["active"])
+        want = oracle.GetNeg2loglikelihood(tv, pp, locs, X, lim, z, n, (0.1, 0.1, 0.1))
+        if want == 1e6 or got == 1e6:
+            assert got == want, (it, got, want)
+            nfail += 1
+            continue
+        worst = max(worst, abs(got - want) / abs(want))
+    assert worst <= N2LL_RTOL, worst
+    assert nfail < 5 and used_engine == 12
+
+
+def test_taper_objective_n10000_vs_host_sparse_lu(oracle):
+    """GetNeg2loglikelihoodTaper (R/neg2loglikelihood.R:20-53) at n = 10 000 (the 100 x 100 grid, Wendland-1 taper of range
+    0.06, ~1 % dense): the band-limited factorisation on the device against a sparse LU (SuperLU) of the SAME tapered matrix
+    on the host, whose entries come from the CPU restatement of cov_rns_taper."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    g, delta = 100, 0.06
+    n = g * g
+    locs, sc = _grid(g)
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    z = wl.synthetic_z(n)
+    ci, rp, ent = [], [1], []
+    cell = {}
+    for i, (x, y) in enumerate(locs):
+        cell.setdefault((int(x / delta), int(y / delta)), []).append(i)
+    for i, (x, y) in enumerate(locs):
+        cx, cy = int(x / delta), int(y / delta)
+        cand = np.array(sorted(j for a in (-1, 0, 1) for b in (-1, 0, 1) for j in cell.get((cx + a, cy + b), [])))
+        d = np.sqrt(np.sum((locs[cand] - locs[i]) ** 2, axis=1))
+        keep = d <= delta
+        h = d[keep] / delta
+        ci.extend((cand[keep] + 1).tolist())
+        ent.extend(((1 - h) ** 4 * (4 * h + 1)).tolist())
+        rp.append(len(ci) + 1)
+    ci, rp, ent = np.array(ci, dtype=np.int32), np.array(rp, dtype=np.int32), np.array(ent)
+    fit = ca.CoconsTaperFit(locs, X, z, wl.SMOOTH_LIMITS, ci, rp, ent)
+    got, parts = fit.neg2loglik_core(th)
+    vals = ent * oracle.cov_rns_taper(th, locs, X, ci, rp, wl.SMOOTH_LIMITS)
+    S = sp.csr_matrix((vals, ci - 1, rp - 1), shape=(n, n)).tocsc()
+    lu = spl.splu(S, permc_spec="MMD_AT_PLUS_A", options=dict(SymmetricMode=True))
+    resid = z - X @ th["mean"]
+    quad = float(resid @ lu.solve(resid))
+    logdet = float(np.sum(np.log(np.abs(lu.U.diagonal()))))
+    want = n * np.log(2 * np.pi) + logdet + quad
+    assert abs(got - want) <= N2LL_RTOL * abs(want)
+    assert abs(2 * parts[0] - logdet) <= 1e-9 * abs(logdet) and abs(parts[1] - quad) <= 1e-8 * abs(quad)

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Time schedule variants of the factorisation in alternation inside ONE process on ONE device (the only comparison
+that means anything on this pool: boxes differ by several percent and so do separate runs on one box).
+
+    python tools/ab_modes.py [--n 10000] [--rounds 7] [--evals 10] "name:key=val,key=val" ...
+
+Each variant is a list of cocons_debug_tune settings applied before its turn; every round times `evals` sequential
+evaluations of every variant; the table gives median and minimum ms per evaluation over the rounds.  Values are checked
+against the first variant (relative 1e-10)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=10000)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--evals", type=int, default=10)
+    ap.add_argument("variants", nargs="+")
+    a = ap.parse_args()
+    import cocons_amd as ca
+    from cocons_amd import _lib, workloads as wl
+    L = _lib.load()
+    g = int(round(a.n ** 0.5))
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    th = wl.theta_full()
+    z = wl.synthetic_z(g * g)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    variants = []
+    for v in a.variants:
+        name, _, kv = v.partition(":")
+        sets = [(k.split("=")[0], int(k.split("=")[1])) for k in kv.split(",") if k]
+        variants.append((name, sets))
+    defaults = {"engine": 1, "panel_mode": 2, "strip_lead": 3600, "strip_min": 3600, "overlap": 0, "upd_dynamic": 1}
+
+    def apply(sets):
+        for k, val in defaults.items():
+            _lib.check(L.cocons_debug_tune(k.encode(), val), "tune")
+        for k, val in sets:
+            _lib.check(L.cocons_debug_tune(k.encode(), val), "tune")
+
+    times = {name: [] for name, _ in variants}
+    stages = {name: [] for name, _ in variants}
+    ref = None
+    for name, sets in variants:                       # warm-up + value check
+        apply(sets)
+        v = fit.neg2loglik_core(th)[0]
+        fit.neg2loglik_core(th)
+        if ref is None:
+            ref = v
+        assert abs(v - ref) <= 1e-10 * abs(ref), (name, v, ref)
+    for r in range(a.rounds):
+        for name, sets in variants:
+            apply(sets)
+            fit.neg2loglik_core(th)
+            t0 = time.perf_counter()
+            for _ in range(a.evals):
+                fit.neg2loglik_core(th)
+            times[name].append((time.perf_counter() - t0) / a.evals * 1e3)
+            st = fit.profile_stages(th, reps=2)
+            stages[name].append((st["assembly_ms"], st["cholesky_ms"], st["update_sum_ms"]))
+    print("n = %d, %d rounds x %d evaluations, engine retries %d" % (g * g, a.rounds, a.evals, fit.engine_state()["retries"]))
+    base = np.median(times[variants[0][0]])
+    for name, _ in variants:
+        t = np.array(times[name])
+        s = np.median(np.array(stages[name]), axis=0)
+        print("%-14s median %7.3f ms  min %7.3f  (%.1f evals/s, %+5.1f%% vs first)   asm %.3f chol %.3f updsum %.3f"
+              % (name, np.median(t), t.min(), 1e3 / np.median(t), (base / np.median(t) - 1) * 100, s[0], s[1], s[2]))
+
+
+if __name__ == "__main__":
+    main()
