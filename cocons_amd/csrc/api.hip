@@ -827,11 +827,12 @@ static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
 // diagnostics header) so that variants can be timed in alternation inside ONE process on ONE device.
 struct Tunables {
     int engine = 1;          // COCONS_ENGINE: 1 = diagonal blocks are factored by the resident engine beside the updates
-    int panel_mode = 2;      // COCONS_PANEL_MODE, see panel_mode()
+    int panel_mode = 0;      // COCONS_PANEL_MODE, see panel_mode()
     int strip_lead = 3600;   // COCONS_STRIP_LEAD
     int strip_min = 3600;    // COCONS_STRIP_MIN
     int overlap = 0;         // COCONS_PANEL_OVERLAP
     int upd_dynamic = 1;     // COCONS_UPD_DYNAMIC
+    int near_force = 0;      // (experiment) count the near tiles write-through although nobody waits for them
     bool init = false;
 };
 static Tunables &tun()
@@ -845,7 +846,7 @@ static Tunables &tun()
         rd("COCONS_STRIP_MIN", t.strip_min);
         rd("COCONS_PANEL_OVERLAP", t.overlap);
         rd("COCONS_UPD_DYNAMIC", t.upd_dynamic);
-        if (t.panel_mode < 0 || t.panel_mode > 2) t.panel_mode = 2;
+        if (t.panel_mode < 0 || t.panel_mode > 2) t.panel_mode = 0;
         t.init = true;
     }
     return t;
@@ -862,6 +863,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "strip_min") t.strip_min = value;
     else if (k == "overlap") t.overlap = value;
     else if (k == "upd_dynamic") t.upd_dynamic = value;
+    else if (k == "near_force") t.near_force = value;
     else return fail(-1, "cocons_debug_tune: unknown switch %s", name);
     return 0;
 }
@@ -940,10 +942,13 @@ static unsigned *tile_queue(cocons_fit *f, int k)
 }
 
 // COCONS_PANEL_MODE: how the panel below an engine-factored diagonal block is formed
-//   0 = three launches behind the trailing update: solve | in-panel update | solve (round 2);
+//   0 (default) = three launches behind the trailing update: solve | in-panel update | solve;
 //   1 = one launch of GEMMs with the engine's tile inverses (launch_panel) behind the trailing update;
-//   2 (default) = the same GEMMs as TASKS of the trailing update that precedes them (launch_update's strips) wherever
-//       that update is long enough to hide the engine's chain behind its first tiles, mode 0 for the later, short blocks
+//   2 = the same GEMMs as TASKS of the trailing update that precedes them (launch_update's strips);
+//   modes 1 and 2 only for the blocks whose update is long enough to hide the engine's longer chain (COCONS_STRIP_MIN far
+//   tiles), mode 0 for the later, short blocks.  Measured in alternation in one process at n = 10^4 (tools/ab_modes.py):
+//   mode 1 = mode 0 within 0.1 %, mode 2 +0.4 ... +1.4 % -- but mode 2 puts the panel's time into the update launches
+//   (their sum grows from 7.0 to 7.6 ms), so the default stays the schedule whose launches are what their name says.
 static int panel_mode()
 {
     int v = tun().panel_mode;
@@ -959,11 +964,11 @@ static int strip_lead() { return tun().strip_lead; }
 static int strip_min_far() { return tun().strip_min; }
 
 // first tile of the first block whose panel is NOT formed with the engine's tile inverses (the engine computes them
-// for the blocks before it only): mode 1 -> all blocks, mode 0 -> none, mode 2 -> while the update has enough far tiles
+// for the blocks before it only): mode 0 -> none, modes 1 and 2 -> while the update has enough far tiles (COCONS_STRIP_MIN;
+// 0 = all blocks): behind a short update the engine is the critical path and its inverse an extra ~10 us per block
 static int panel_w_until(const FactorView &v)
 {
     if (panel_mode() == 0 || v.hi) return 0;
-    if (panel_mode() == 1) return v.nt;
     int t = 2;
     for (; t < v.nt; t += 2) {
         const int near_tiles = t + 1 < v.nt ? 2 : 1;
@@ -1075,7 +1080,8 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
                 launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, mt * TILE, f->dwinv, out, xr, abort_word, M);
             continue;
         }
-        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), overlap ? near + t : nullptr, near_tiles);
+        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), (overlap || tun().near_force) ? near + t : nullptr,
+                     near_tiles);
         if (overlap) launch_flag_gate(near + t, update_near_count(t, mt, near_tiles), abort_word, 0x700u + t, P);
         if (with_w) {
             launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, mt * TILE, f->dwinv, out, xr, abort_word, P);
