@@ -833,6 +833,7 @@ struct Tunables {
     int overlap = 0;         // COCONS_PANEL_OVERLAP
     int upd_dynamic = 1;     // COCONS_UPD_DYNAMIC
     int near_force = 0;      // (experiment) count the near tiles write-through although nobody waits for them
+    int engine_fused = 1;    // COCONS_ENGINE_FUSED: the engine's fused pass over a diagonal block (potrf_block_fused)
     bool init = false;
 };
 static Tunables &tun()
@@ -846,6 +847,7 @@ static Tunables &tun()
         rd("COCONS_STRIP_MIN", t.strip_min);
         rd("COCONS_PANEL_OVERLAP", t.overlap);
         rd("COCONS_UPD_DYNAMIC", t.upd_dynamic);
+        rd("COCONS_ENGINE_FUSED", t.engine_fused);
         if (t.panel_mode < 0 || t.panel_mode > 2) t.panel_mode = 0;
         t.init = true;
     }
@@ -864,6 +866,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "overlap") t.overlap = value;
     else if (k == "upd_dynamic") t.upd_dynamic = value;
     else if (k == "near_force") t.near_force = value;
+    else if (k == "engine_fused") t.engine_fused = value;
     else return fail(-1, "cocons_debug_tune: unknown switch %s", name);
     return 0;
 }
@@ -989,7 +992,8 @@ static int engine_start(cocons_fit *f, const FactorView &v)
     HIPCHK(hipEventRecord(f->ev_eng, M));
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
     launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
-                        f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dwinv, panel_w_until(v));
+                        f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dwinv, panel_w_until(v),
+                        tun().engine_fused);
     f->engine_live = true;
     return 0;
 }

@@ -279,7 +279,8 @@ __constant__ int c_tri_ib[36] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5,
 // Also exports, per diagonal block, the Q operands (4 x 64 lanes) the panel solve needs.
 // qall (LDS, may be null): receives the Q operands of all eight diagonal blocks (8 x 256 doubles)
 // WT: the factor and the Q operands are published with write-through stores (engine)
-template <bool WT>
+// FROM_LDS: the image is already in LDS (the fused engine pass leaves tile t + 1 there): no load
+template <bool WT, bool FROM_LDS = false>
 __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, double *q_out, int *info, double *smem,
                                                 double *qall)
 {
@@ -290,7 +291,7 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
 #define SB(ib, kb) (S + ((ib) * ((ib) + 1) / 2 + (kb)) * 256)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    {   // 36 lower blocks, 18 per half-workgroup: every global load is issued before the
+    if (!FROM_LDS) {   // 36 lower blocks, 18 per half-workgroup: every global load is issued before the
         // first LDS store (one round trip instead of 36; matters when the chip is busy)
         const int i = tid & 15, k = (tid >> 4) & 15;
         const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
@@ -394,6 +395,236 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
 #undef SB
 }
 
+// ---------------------------------------------------------------------------
+// The engine's pass over a 256 x 256 diagonal block, FUSED: while wave 0 runs the pivot chain of tile t (the
+// factorisation of a 128 x 128 tile is one wave's dependent fp64 VALU chain; the matrix pipes of the CU idle beside
+// it), the other waves carry the tile below along, 16 columns behind:
+//     X = A(t+1,t) L(t)^-T      strip by strip (16 rows each, in registers), one 16-column block per step,
+//     A(t+1,t+1) -= X X^T        rank 16 per step, the 36 blocks in registers,
+// so that when tile t is factored, X is complete and tile t+1 is updated and sitting in registers: it goes to LDS and is
+// factored from there (no trip through memory).  Before: factor | solve 13 us | update 8 us | factor; now the solve and
+// the update cost what they add to the steps of the first factorisation.
+// Who does what: wave 0 = pivot wave (as in potrf_tile_body); wave 4 shares wave 0's SIMD and only helps with tile t
+// itself (fp64 MFMAs beside the pivot chain slow it: the DP units are shared); the six waves 1,2,3,5,6,7 hold the eight
+// strips (two of them two) and six blocks of tile t+1 each.
+// LDS (doubles): [0, 36*256) image of tile t | [36*256, 37*256) Q operands of the current diagonal block |
+//                [37*256, 45*256) X(:, jb), the eight 16 x 16 blocks of the current step.
+__device__ __forceinline__ int fused_hidx(int wave) { return wave == 0 || wave == 4 ? -1 : (wave < 4 ? wave - 1 : wave - 2); }
+// blocks of tile t+1 (packed index 0..35) by carrying wave: the two waves with two strips take 3 each (0..5), the four
+// others 8, 8, 7, 7 (6..35); a wave's i-th block (-1: none):
+__device__ __forceinline__ int fused_t2_block(int h, int i)
+{
+    return h < 2 ? (i < 3 ? 3 * h + i : -1) : ((6 + (h - 2) + 4 * i) < 36 ? 6 + (h - 2) + 4 * i : -1);
+}
+
+__device__ __forceinline__ void potrf_block_fused(double *A, size_t lda, int c0, double *q_out, int *info, double *smem)
+{
+    double *S = smem;
+    double *QS = smem + 36 * 256;
+    double *XS = smem + 37 * 256;
+#define SB(ib, kb) (S + ((ib) * ((ib) + 1) / 2 + (kb)) * 256)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c1 = c0 + TILE;
+    const int h = fused_hidx(wave);                   // 0..5 for the six carrying waves, -1 for waves 0 and 4
+    const bool two_strips = h == 0 || h == 1;
+
+    {   // image of tile t (as potrf_tile_body)
+        const int i = tid & 15, k = (tid >> 4) & 15;
+        const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
+        const double *src = A + (size_t)(c0 + i) + (size_t)(c0 + k) * lda;
+        double v[18];
+#pragma unroll
+        for (int t = 0; t < 18; ++t) {
+            const int bb = 2 * t + half;
+            const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+            v[t] = load_wt(src + (size_t)(16 * ib) + (size_t)(16 * kb) * lda);
+        }
+#pragma unroll
+        for (int t = 0; t < 18; ++t) {
+            const int bb = 2 * t + half;
+            const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+            SB(ib, kb)[k * 16 + i] = v[t];
+        }
+    }
+    // What this wave carries, in ONE pool of 19 blocks (152 registers; the roles differ by wave but the registers are the
+    // kernel's):  R[0..7] = its strip of A(t+1,t);  R[8..15] = its second strip (waves h = 0, 1) or eight blocks of
+    // A(t+1,t+1) (the others);  R[16..18] = three blocks of A(t+1,t+1) (waves h = 0, 1).
+    d4 R[19];
+    if (h >= 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) R[j] = glb_blk_wt(A, lda, c1 + 16 * h, c0 + 16 * j, lane);
+        if (two_strips) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) R[8 + j] = glb_blk_wt(A, lda, c1 + 16 * (h + 6), c0 + 16 * j, lane);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int bb = fused_t2_block(h, i);
+                const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+                R[16 + i] = glb_blk_wt(A, lda, c1 + 16 * ib, c1 + 16 * kb, lane);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int bb = fused_t2_block(h, i);
+                if (bb >= 0) {
+                    const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+                    R[8 + i] = glb_blk_wt(A, lda, c1 + 16 * ib, c1 + 16 * kb, lane);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        d4 D = lds_blk(S, lane);
+        double Q[4];
+        int f = potrf16_regs(D, Q, lane);
+        if (f && lane == 0) atomicMin(info, c0 + f);
+        lds_blk_store(S, lane, D);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            QS[s * 64 + lane] = Q[s];
+            store_wt(q_out + s * 64 + lane, Q[s]);
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        // T: the blocks of tile t below the diagonal block, one per wave -- and column block jb of every strip
+        if (jb < 7 && jb + 1 + wave < 8) {
+            const int ib = jb + 1 + wave;
+            d4 L = lds_blk(SB(jb, jb), lane);
+            double Q[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Q[s] = QS[s * 64 + lane];
+            double *blk = SB(ib, jb);
+            d4 B = lds_blk(blk, lane);
+            trsm16(B, L, Q);
+            lds_blk_store(blk, lane, B);
+        }
+        if (h >= 0) {
+            d4 L = lds_blk(SB(jb, jb), lane);
+            double Q[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Q[s] = QS[s * 64 + lane];
+            trsm16(R[jb], L, Q);
+            lds_blk_store(XS + h * 256, lane, R[jb]);
+            if (two_strips) {
+                trsm16(R[8 + jb], L, Q);
+                lds_blk_store(XS + (h + 6) * 256, lane, R[8 + jb]);
+            }
+        }
+        __syncthreads();
+        // S: tile t's own update (wave 0: next diagonal block, then its factorisation) -- and the strips' and tile t+1's
+        if (jb < 7) {
+            if (wave == 0) {
+                const int nb = jb + 1;
+                d4 P = lds_blk(SB(nb, jb), lane);
+                double *blk = SB(nb, nb);
+                d4 acc = lds_blk(blk, lane);
+                d4 NP = -P;
+                blk_mma(acc, NP, P);
+                double Q[4];
+                int f = potrf16_regs(acc, Q, lane);
+                if (f && lane == 0) atomicMin(info, c0 + 16 * nb + f);
+                lds_blk_store(blk, lane, acc);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    QS[s * 64 + lane] = Q[s];
+                    store_wt(q_out + nb * 256 + s * 64 + lane, Q[s]);
+                }
+            } else {
+                int cnt = 0;
+                for (int ib = jb + 1; ib < 8; ++ib) {
+                    for (int kb = jb + 1; kb <= ib; ++kb) {
+                        if (ib == jb + 1) continue;            // (jb+1,jb+1) belongs to wave 0
+                        if ((cnt++ % 7) + 1 != wave) continue;
+                        d4 P = lds_blk(SB(ib, jb), lane);
+                        d4 Qk = lds_blk(SB(kb, jb), lane);
+                        double *blk = SB(ib, kb);
+                        d4 acc = lds_blk(blk, lane);
+                        P = -P;
+                        blk_mma(acc, P, Qk);
+                        lds_blk_store(blk, lane, acc);
+                    }
+                }
+            }
+        }
+        if (h >= 0) {
+            {
+                d4 NX = -R[jb];
+#pragma unroll
+                for (int jj = jb + 1; jj < 8; ++jj) {
+                    d4 Lb = lds_blk(SB(jj, jb), lane);
+                    blk_mma(R[jj], NX, Lb);
+                }
+            }
+            if (two_strips) {
+                d4 NX = -R[8 + jb];
+#pragma unroll
+                for (int jj = jb + 1; jj < 8; ++jj) {
+                    d4 Lb = lds_blk(SB(jj, jb), lane);
+                    blk_mma(R[8 + jj], NX, Lb);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int bb = fused_t2_block(h, i);
+                    const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+                    d4 P = lds_blk(XS + ib * 256, lane);
+                    d4 Qk = lds_blk(XS + kb * 256, lane);
+                    P = -P;
+                    blk_mma(R[16 + i], P, Qk);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int bb = fused_t2_block(h, i);
+                    if (bb >= 0) {
+                        const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+                        d4 P = lds_blk(XS + ib * 256, lane);
+                        d4 Qk = lds_blk(XS + kb * 256, lane);
+                        P = -P;
+                        blk_mma(R[8 + i], P, Qk);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // tile t and X go out (write-through); tile t+1 takes tile t's place in LDS
+    {
+        const int i = tid & 15, k = (tid >> 4) & 15, half = tid >> 8;
+        double *dst = A + (size_t)(c0 + i) + (size_t)(c0 + k) * lda;
+        int b = 0;
+        for (int ib = 0; ib < 8; ++ib)
+            for (int kb = 0; kb <= ib; ++kb, ++b)
+                if ((b & 1) == half) store_wt(dst + (size_t)(16 * ib) + (size_t)(16 * kb) * lda, SB(ib, kb)[k * 16 + i]);
+    }
+    if (h >= 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) glb_blk_store_wt(A, lda, c1 + 16 * h, c0 + 16 * j, lane, R[j]);
+        if (two_strips) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) glb_blk_store_wt(A, lda, c1 + 16 * (h + 6), c0 + 16 * j, lane, R[8 + j]);
+        }
+    }
+    __syncthreads();                        // every wave has read its part of tile t's image
+    if (h >= 0) {
+        if (two_strips) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) lds_blk_store(S + fused_t2_block(h, i) * 256, lane, R[16 + i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int bb = fused_t2_block(h, i);
+                if (bb >= 0) lds_blk_store(S + bb * 256, lane, R[8 + i]);
+            }
+        }
+    }
+#undef SB
+}
+
 __global__ void __launch_bounds__(512)
 potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
 {
@@ -475,6 +706,7 @@ struct EngineArgs {
     double *winv;            // 2 x 128 x 128 doubles (parity of the tile index; zero outside the lower triangle):
                              // W = L^-1 of each diagonal tile, published before out[t] (see panel_kernel)
     int w_until;             // ... for the blocks that start at a tile t < w_until (the others: no inverse, no cost)
+    int fused;               // blocks without W take the fused pass (potrf_block_fused)
 };
 
 // W = L^-1 of the 128 x 128 tile whose factor (block-packed) and Q operands (all eight diagonal blocks) are in LDS:
@@ -534,6 +766,24 @@ potrf_engine_kernel(EngineArgs e)
     const size_t lda = e.lda;
     if (tid == 0) __hip_atomic_store(e.alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int t = e.t0; t < e.nt; t += 2) {
+        if (e.fused && t + 1 < e.nt && t >= e.w_until) {
+            // one fused pass over the 256 x 256 block (potrf_block_fused), then tile t + 1 straight from LDS
+            if (tid == 0)
+                *okp = (wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t) &&
+                        wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t)) ? 1 : 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (*okp == 0) return;
+            potrf_block_fused(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) { signal_add(e.out + t); signal_add(e.xr + t); }
+            potrf_tile_body<true, true>(A, lda, (t + 1) * TILE, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, nullptr);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) signal_add(e.out + t + 1);
+            continue;
+        }
         if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1415,12 +1665,12 @@ void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s)
 
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
-                         double *winv, int w_until)
+                         double *winv, int w_until, int fused)
 {
     if (t0 >= nt) return;
     EngineArgs e;
     e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
-    e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive; e.winv = winv; e.w_until = winv ? w_until : 0;
+    e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive; e.winv = winv; e.w_until = winv ? w_until : 0; e.fused = fused;
     // 136 KB: the 128 KB LDS copy of X plus the flag word; leaves room for ONE update workgroup beside the
     // engine.  (Asking for all 160 KB measured 7 % slower trailing updates chip-wide while the engine was
     // resident; 76 .. 152 KB did not.)

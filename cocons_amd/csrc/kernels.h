@@ -103,7 +103,8 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
 //   of launch_panel
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
-                         double *winv = nullptr, int w_until = 0);     // W only for blocks starting at a tile < w_until
+                         double *winv = nullptr, int w_until = 0,      // W only for blocks starting at a tile < w_until
+                         int fused = 1);   // the other blocks: strip solve and tile update folded into the first tile's factorisation
 // Panel of the 256-column block at tile t under the engine schedule, ONE launch: rows [r0, r1) (multiples of 64) of
 // tile columns t and (two != 0) t + 1:   X0 = B0 W(t)^T ;  B1 -= X0 X(t+1,t)^T ;  X1 = B1 W(t+1)^T  -- the panel solve as
 // three small GEMMs per 64-row strip on the update kernel's inner loop and footprint (no dependent chain).  Each
