@@ -272,6 +272,9 @@ struct cocons_fit {
     double *d_tval;               // taper entries (constant)
     std::vector<int> *taper_hi;   // envelope of the (reordered) pattern per tile column: see FactorView::hi
     int *d_thi; int taper_maxband; // device copy of taper_hi and max_c (hi[c] - c)
+    int skew;                     // > 0: the factorisation buffer is PACKED (kernels.h band_index): every tile column keeps
+                                  // `skew` (= taper_maxband) tile rows from its diagonal tile down plus the rows under the
+                                  // matrix -- O(n x bandwidth) doubles instead of n^2
     std::vector<int> *taper_inv;  // position of the caller's observation i in the handle's order (reverse Cuthill-McKee)
     // collectives of the natively sharded evaluation (see "native sharded evaluation" below)
     int coll_kind;                // 0 none, 1 RCCL communicator, 2 caller-provided transport
@@ -309,7 +312,7 @@ static int fit_alloc_matrix(cocons_fit *f, int rhs_rows)
     if (f->dA && cap <= f->rhs_cap) return 0;
     if (f->dA) { HIPCHK(hipFree(f->dA)); f->dA = nullptr; }
     f->rhs_cap = cap;
-    f->lda = (size_t)f->npad + cap;
+    f->lda = (size_t)(f->skew > 0 ? f->skew * TILE : f->npad) + cap;
     HIPCHK(hipMalloc(&f->dA, f->lda * (size_t)f->npad * sizeof(double)));
     // never-written parts must not hold NaN bit patterns: a band-limited factorisation only clears its envelope, and
     // 0 * garbage must stay 0 whatever the allocator hands back
@@ -354,7 +357,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
 
 static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *locs,
                                    const double *X, const double *z, const double *x_betas,
-                                   const double *smooth_limits, int device, bool allow_sort)
+                                   const double *smooth_limits, int device, bool allow_sort, bool defer_matrix = false)
 {
     if (n <= 0 || p <= 0 || p > COCONS_P_MAX || r < 0 || q < 0 || !locs || !X || !smooth_limits ||
         (r > 0 && !z) || (q > 0 && !x_betas)) {
@@ -482,9 +485,10 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     for (auto &e : f->ev) CK(hipEventCreate(&e));
     CK(hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&f->ev_eng, hipEventDisableTiming));
-    CK(hipStreamCreateWithFlags(&f->stream3, hipStreamNonBlocking));
-    for (auto &e : f->ev_panel) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
+    // (stream3 / ev_panel -- the panel stream of the overlap experiment -- are created on first use: every stream a process
+    // holds competes for the few hardware queues, and a third stream per handle halved the throughput of the batch slots)
+    // (a taper handle allocates its buffer once the envelope of its pattern is known: packed, it is a fraction of n^2)
+    if (!defer_matrix && fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
 #undef CK
     return f;
 }
@@ -592,7 +596,7 @@ extern "C" cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double
         }
         prp[i + 1] = w2 + 1;
     }
-    cocons_fit *f = fit_create_impl(n, p, r, 0, pl.data(), pX.data(), pz.data(), nullptr, smooth_limits, device, false);
+    cocons_fit *f = fit_create_impl(n, p, r, 0, pl.data(), pX.data(), pz.data(), nullptr, smooth_limits, device, false, true);
     if (!f) return nullptr;
     // envelope per tile column: row i of the factor is non-zero from its first stored column on
     f->taper_hi = new std::vector<int>(f->nt, 0);
@@ -627,8 +631,12 @@ extern "C" cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double
             hi = h2;
             f->taper_maxband = 0;
             for (int c = 0; c < f->nt; ++c) if (hi[c] - c > f->taper_maxband) f->taper_maxband = hi[c] - c;
+            // packed band storage unless switched off (COCONS_TAPER_PACKED=0: the dense n x n buffer, only its band used)
+            const char *pk = getenv("COCONS_TAPER_PACKED");
+            if (!(pk && atoi(pk) == 0) && f->taper_maxband < f->nt) f->skew = f->taper_maxband;
         }
     }
+    if (fit_alloc_matrix(f, r + p) != 0) { cocons_fit_destroy(f); return nullptr; }
     // the device keeps the lower triangle of the pattern only (the upper half is never evaluated)
     {
         int w2 = 0;
@@ -671,7 +679,7 @@ extern "C" int cocons_fit_set_stream(cocons_fit *f, void *stream)
     // stream that is about to be destroyed
     HIPCHK(hipStreamSynchronize(f->stream));
     HIPCHK(hipStreamSynchronize(f->stream2));
-    HIPCHK(hipStreamSynchronize(f->stream3));
+    if (f->stream3) HIPCHK(hipStreamSynchronize(f->stream3));
     if (f->own_stream) { HIPCHK(hipStreamDestroy(f->stream)); f->own_stream = false; }
     f->stream = (hipStream_t)stream;
     return 0;
@@ -732,11 +740,11 @@ static int assemble_sigma_taper(cocons_fit *f, const double *theta)
     launch_loc_params(la, f->stream);
     // zero what the factorisation will read: the tiles inside the envelope (the rows under the matrix are written in
     // full by the right-hand-side kernel), or the whole buffer when the factorisation is not band-limited
-    if (f->d_thi) launch_band_zero(f->dA, f->lda, f->d_thi, f->nt, f->taper_maxband, f->stream);
+    if (f->d_thi) launch_band_zero(f->dA, f->lda, f->d_thi, f->nt, f->taper_maxband, f->stream, f->skew);
     else HIPCHK(hipMemsetAsync(f->dA, 0, f->lda * (size_t)f->npad * sizeof(double), f->stream));
     launch_taper(ms.mode, false, f->n, f->taper_nnz, f->d_tci, f->d_trp, f->dloc, f->npad, f->dloc, f->npad,
-                 ms.nu_fixed, nullptr, f->stream, f->d_tval, f->dA, f->lda, 0);
-    launch_pad_identity(f->dA, f->lda, f->n, f->npad, f->stream);
+                 ms.nu_fixed, nullptr, f->stream, f->d_tval, f->dA, f->lda, 0, f->skew, f->npad);
+    launch_pad_identity(f->dA, f->lda, f->n, f->npad, f->stream, f->skew);
     return 0;
 }
 
@@ -757,6 +765,7 @@ static void assemble_rhs(cocons_fit *f, const double *mean, bool use_trend, cons
     if (use_trend) for (int i = 0; i < f->p; ++i) ra.mean[i] = mean[i];
     ra.src = f->dz; ra.lds = f->n;
     ra.out = f->dA; ra.ld = f->lda;
+    ra.skew = f->skew; ra.npad = f->npad;
     ra.row0 = f->npad; ra.nrows = f->r;
     ra.nrows_zero = (nxb > 0) ? 0 : f->rhs_act - f->r;
     ra.col0 = col0; ra.ncols_out = col1;
@@ -784,6 +793,7 @@ struct FactorView {
     int nt, mt;
     const int *hi = nullptr;   // band-limited factorisation (taper handles): hi[c] = one past the last tile row of tile
                                // column c that can be non-zero in the factor (envelope of the pattern); nullptr = dense
+    int skew = 0;              // > 0: A is a packed band buffer (kernels.h band_index) of `skew` tile rows per tile column
 };
 
 static FactorView main_view(cocons_fit *f)
@@ -791,6 +801,7 @@ static FactorView main_view(cocons_fit *f)
     FactorView v;
     v.A = f->dA; v.lda = f->lda; v.nt = f->nt; v.mt = f->nt + f->rhs_act / TILE;
     v.hi = (f->taper_hi && !f->taper_hi->empty()) ? f->taper_hi->data() : nullptr;
+    v.skew = f->skew;
     return v;
 }
 
@@ -928,7 +939,7 @@ static int flags_reset(cocons_fit *f, int nt)
 {
     if (f->flags_cap < nt) {
         HIPCHK(hipStreamSynchronize(f->stream2));
-        HIPCHK(hipStreamSynchronize(f->stream3));
+        if (f->stream3) HIPCHK(hipStreamSynchronize(f->stream3));
         if (f->dflags) { HIPCHK(hipFree(f->dflags)); f->dflags = nullptr; }
         f->flags_cap = round_up(nt + 8, 64);
         HIPCHK(hipMalloc(&f->dflags, (5 * (size_t)f->flags_cap + 64) * sizeof(unsigned)));
@@ -1028,14 +1039,18 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
             // (4.71 -> 4.53 ms at n = 10^4)
             // (row bound = the column's OWN envelope hi[k] -- per 256-block, monotone, >= k + 1 --, not band_hi(): for an
             // odd k that is the NEXT block's bound, beyond what band_zero_kernel clears in column k)
+            // (packed band buffer: the kernels that stay inside tile column k address it by global indices through a
+            // shifted base, where the rows under the matrix start at row (k + skew) * 128 -- kernels.h band_base)
             for (int k = 0; k < nt; ++k) {
                 const int hb = v.hi[k] < nt ? v.hi[k] : nt;
                 double *q = f->dinv + (size_t)(k & 1) * 2048;
-                launch_potrf_tile(v.A, v.lda, k * TILE, q, f->dinfo, M);
-                launch_trsm_tile(v.A, v.lda, k * TILE, (k + 1) * TILE, mt * TILE, q, M, nullptr, nullptr, hb * TILE, nt * TILE);
+                double *Ak = band_base(v.A, k, v.skew);
+                const int e0 = v.skew ? k + v.skew : nt, e1 = e0 + (mt - nt);      // tile rows under the matrix
+                launch_potrf_tile(Ak, v.lda, k * TILE, q, f->dinfo, M);
+                launch_trsm_tile(Ak, v.lda, k * TILE, (k + 1) * TILE, e1 * TILE, q, M, nullptr, nullptr, hb * TILE, e0 * TILE);
                 if (k + 1 < nt)
                     launch_update(v.A, v.lda, k * TILE, TILE, k + 1, mt, k + 1, hb < nt ? hb : nt, true, M, nullptr, -1,
-                                  nullptr, nullptr, nullptr, hb, nt);
+                                  nullptr, nullptr, nullptr, hb, nt, nullptr, 0, nullptr, v.skew);
             }
             return 0;
         }
@@ -1063,6 +1078,10 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     // in the tail of U(k), where the chip drains anyway.  U(k+2) waits for the panel's event.  COCONS_PANEL_OVERLAP=0:
     // everything in order on the main stream (the round-2 schedule).
     const int overlap = tun().overlap;
+    if (overlap && !f->stream3) {
+        HIPCHK(hipStreamCreateWithFlags(&f->stream3, hipStreamNonBlocking));
+        for (auto &e : f->ev_panel) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     hipStream_t P = overlap ? f->stream3 : M;
     if (overlap) HIPCHK(hipStreamWaitEvent(P, f->ev_eng, 0));     // behind the reset of the flag words
     const int w_until = panel_w_until(v);
@@ -1135,7 +1154,7 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
     if (stage_events) hipEventRecord(f->ev[1], f->stream);
     if (int rc = factorize(f, main_view(f), ev_upd)) return rc;
     if (stage_events) hipEventRecord(f->ev[2], f->stream);
-    launch_finalize(f->dA, f->lda, f->n, f->npad, nrhs, f->dout, f->stream);
+    launch_finalize(f->dA, f->lda, f->n, f->npad, nrhs, f->dout, f->stream, f->skew, f->npad);
     HIPCHK(hipMemcpyAsync(f->hout, f->dout, (size_t)(1 + nrhs * nrhs) * sizeof(double),
                           hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, f->stream));
@@ -1179,7 +1198,7 @@ static bool engine_retry(cocons_fit *f, int st)
     f->engine_live = false;
     f->engine_used = false;
     hipStreamSynchronize(f->stream2);
-    hipStreamSynchronize(f->stream3);
+    if (f->stream3) hipStreamSynchronize(f->stream3);
     return true;
 }
 
@@ -1247,8 +1266,10 @@ static cocons_fit *clone_for_slot(cocons_fit *f)
         return cocons_fit_create(f->n, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
                                  f->smooth_limits, f->device);
     cocons_fit *c = fit_create_impl(f->n, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
-                                    f->smooth_limits, f->device, false);      // h_* of a taper handle are in ITS order
+                                    f->smooth_limits, f->device, false, true);      // h_* of a taper handle are in ITS order
     if (!c) return nullptr;
+    c->skew = f->skew;                        // the same (packed) buffer layout as the original
+    if (fit_alloc_matrix(c, f->r + f->p) != 0) { cocons_fit_destroy(c); return nullptr; }
     const size_t nnz = (size_t)f->taper_nnz;
     bool ok = hipMalloc(&c->d_tci, nnz * sizeof(int)) == hipSuccess &&
               hipMalloc(&c->d_trp, (size_t)(f->n + 1) * sizeof(int)) == hipSuccess &&
@@ -1842,6 +1863,7 @@ extern "C" int cocons_predict_taper(cocons_fit *f, const double *theta, const do
             for (int i = 0; i < p; ++i) ra.mean[i] = mean[i];
             ra.src = f->dz + (size_t)z_col * n; ra.lds = n;
             ra.out = f->dA; ra.ld = f->lda; ra.row0 = f->npad; ra.nrows = 1;
+            ra.skew = f->skew; ra.npad = f->npad;
             ra.nrows_zero = f->rhs_act - 1;
             ra.col0 = 0; ra.ncols_out = f->npad;
             launch_rhs_rows(ra, s);
@@ -1859,9 +1881,9 @@ extern "C" int cocons_predict_taper(cocons_fit *f, const double *theta, const do
             lo.n = n; lo.X = f->dX; lo.ldx = n; lo.locs = f->dlocs; lo.ldl = n; lo.out = f->dloc; lo.stride = f->npad;
             launch_loc_params(lo, s);                                   // (after the entries of S were computed: stream order)
             launch_taper(MODE_GEOM, true, m, nnz_pred, dci, drp, f->dlocp, m, f->dloc, f->npad, 0.0, nullptr, s,
-                         dtv, f->dA, f->lda, f->npad + 1);
+                         dtv, f->dA, f->lda, f->npad + 1, f->skew, f->npad);
             factorize(f, main_view(f), nullptr);
-            launch_row_reduce(f->dA, f->lda, n, f->npad, f->npad + 1, m, f->dstoch, f->dquad, f->dred, s);
+            launch_row_reduce(f->dA, f->lda, n, f->npad, f->npad + 1, m, f->dstoch, f->dquad, f->dred, s, f->skew, f->npad);
             hipMemcpyAsync(stochastic, f->dstoch, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s);
             hipMemcpyAsync(quadform, f->dquad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s);
             hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, s);

@@ -199,10 +199,10 @@ rhs_rows_kernel(RhsArgs a)
     for (int k = 0; k < a.nrows; ++k) {
         double v = 0.0;
         if (c < a.n) v = a.src[c + (size_t)k * a.lds] - trend;
-        a.out[(size_t)(a.row0 + k) + (size_t)c * a.ld] = v;
+        a.out[band_index(a.row0 + k, c, a.ld, a.skew, a.npad)] = v;
     }
     for (int k = a.nrows; k < a.nrows + a.nrows_zero; ++k)
-        a.out[(size_t)(a.row0 + k) + (size_t)c * a.ld] = 0.0;
+        a.out[band_index(a.row0 + k, c, a.ld, a.skew, a.npad)] = 0.0;
 }
 
 // Sparse/taper covariance entries (src/cocons_taper.cpp): one thread per stored entry of the CSR pattern
@@ -219,6 +219,7 @@ struct TaperArgs {
     // factorisation buffer instead of out[] -- the lower triangle A(ii, jj), jj <= ii, of the symmetric pattern (the
     // upper entries are not even evaluated), or, PRED, row row0 + ii of the rows under the matrix
     const double *tapv; double *A; size_t lda; int row0;
+    int skew, npad;          // packed band target (band_index); 0 = dense
 };
 
 template <int MODE, bool PRED>
@@ -237,16 +238,17 @@ taper_kernel(TaperArgs a)
     double v;
     if (!PRED && ii == jj) v = a.rows[ii + 11 * a.stride_rows];
     else v = taper_value_idx<MODE, PRED>(a.rows, a.stride_rows, ii, a.cols, a.stride, jj, a.nu_fixed);
-    if (a.A) a.A[(size_t)((PRED ? a.row0 : 0) + ii) + (size_t)jj * a.lda] = a.tapv[w] * v;
+    if (a.A) a.A[band_index((PRED ? a.row0 : 0) + ii, jj, a.lda, a.skew, a.npad)] = a.tapv[w] * v;
     else a.out[w] = v;
 }
 
 void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const int *rp, const double *rows,
                   size_t stride_rows, const double *cols, size_t stride, double nu_fixed, double *out, hipStream_t s,
-                  const double *tapv, double *A, size_t lda, int row0)
+                  const double *tapv, double *A, size_t lda, int row0, int skew, int npad)
 {
     if (nnz <= 0) return;
     TaperArgs a;
+    a.skew = skew; a.npad = npad;
     a.nrows = nrows; a.nnz = nnz; a.ci = ci; a.rp = rp; a.rows = rows; a.stride_rows = stride_rows;
     a.cols = cols; a.stride = stride; a.nu_fixed = nu_fixed; a.out = out;
     a.tapv = tapv; a.A = A; a.lda = lda; a.row0 = row0;
@@ -262,33 +264,34 @@ void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const 
 
 // Zero the tiles of a band-limited factorisation buffer: tile column c, tile rows c .. hi[c]-1 (whole 128 x 128 tiles,
 // the upper part of the diagonal tile included: the tile factorisation loads full 16 x 16 diagonal blocks).
-__global__ void band_zero_kernel(double *A, size_t lda, const int *hi, int nt)
+__global__ void band_zero_kernel(double *A, size_t lda, const int *hi, int nt, int skew)
 {
     const int c = blockIdx.x, rt = c + blockIdx.y;
     if (rt >= hi[c]) return;
-    double *p = A + (size_t)rt * 128 + (size_t)c * 128 * lda;
+    double *p = A + (size_t)(skew ? rt - c : rt) * 128 + (size_t)c * 128 * lda;
     for (int e = threadIdx.x; e < 128 * 64; e += blockDim.x) {       // 2 doubles per step
         const int col = e >> 6, r2 = (e & 63) * 2;
         *(double2 *)(p + r2 + (size_t)col * lda) = make_double2(0.0, 0.0);
     }
 }
 
-void launch_band_zero(double *A, size_t lda, const int *d_hi, int nt, int max_band, hipStream_t s)
+void launch_band_zero(double *A, size_t lda, const int *d_hi, int nt, int max_band, hipStream_t s, int skew)
 {
     if (nt <= 0 || max_band <= 0) return;
-    hipLaunchKernelGGL(band_zero_kernel, dim3(nt, max_band), dim3(256), 0, s, A, lda, d_hi, nt);
+    hipLaunchKernelGGL(band_zero_kernel, dim3(nt, max_band), dim3(256), 0, s, A, lda, d_hi, nt, skew);
 }
 
 // identity on the padding diagonal n .. npad-1 of a taper handle's buffer (its tiles were zeroed)
-__global__ void pad_identity_kernel(double *A, size_t lda, int n, int npad)
+__global__ void pad_identity_kernel(double *A, size_t lda, int n, int npad, int skew)
 {
     const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npad) A[(size_t)i + (size_t)i * lda] = 1.0;
+    if (i < npad) A[band_index(i, i, lda, skew, npad)] = 1.0;
 }
 
-void launch_pad_identity(double *A, size_t lda, int n, int npad, hipStream_t s)
+void launch_pad_identity(double *A, size_t lda, int n, int npad, hipStream_t s, int skew)
 {
-    if (npad > n) hipLaunchKernelGGL(pad_identity_kernel, dim3((npad - n + 255) / 256), dim3(256), 0, s, A, lda, n, npad);
+    if (npad > n)
+        hipLaunchKernelGGL(pad_identity_kernel, dim3((npad - n + 255) / 256), dim3(256), 0, s, A, lda, n, npad, skew);
 }
 
 // Selected rows of the dense covariance (or of cov2cor of it) without ever forming the n x n matrix: what

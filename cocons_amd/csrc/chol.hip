@@ -174,43 +174,30 @@ __device__ __forceinline__ void potrf16_step(d4 &D, double (&Q)[4], int lane, in
     double a11 = rdlane(ds, 4 * S + 1 + 16), a21 = rdlane(ds, 4 * S + 2 + 16), a31 = rdlane(ds, 4 * S + 3 + 16);
     double a22 = rdlane(ds, 4 * S + 2 + 32), a32 = rdlane(ds, 4 * S + 3 + 32);
     double a33 = rdlane(ds, 4 * S + 3 + 48);
-    // 4x4 Cholesky, identical on every lane.  This loop is pure latency (one wave, every operation waits for the one
-    // before), so it is arranged for the shortest dependent chain rather than for the fewest operations: the pivots
-    // d_j come from the outer-product (Schur complement) form with RECIPROCALS on the chain,
-    //     d1 = a11 - a10^2 / d0,   u21 = a21 - a20 a10 / d0, ...        (rcp + two Newton steps: 5 operations)
-    // and the square roots l_jj = sqrt(d_j), r_j = 1 / l_jj of d0, d1, d2 are refined BESIDE that chain (independent
-    // instruction streams share the one wave's issue slots); only d3's follows it.  Chain: 3 x 6 + 12 operations instead
-    // of 4 x 14.  l_ij = u_ij r_j with u the Schur-complement entries: the factor of the same matrix, rounded in a
-    // different order than dpotf2's a_ij - sum l_ik l_jk (both backward stable; the results differ in the last place).
-    auto rcp_ref = [](double a) {
-        double y = __builtin_amdgcn_rcp(a);
-        y = fma(fma(-a, y, 1.0), y, y);
-        y = fma(fma(-a, y, 1.0), y, y);
-        return y;
-    };
+    // 4x4 Cholesky (dpotf2 order) -- identical on every lane.  Pivots through
+    // rsqrt_pivot(): l = sqrt(a) and r = 1/l from one v_rsq_f64 seed (short dependent chain;
+    // this loop is pure latency).
     if (!(a00 > 0.0) && fail == 0) fail = 4 * S + 1;
-    const double e0 = rcp_ref(a00);
-    const double g10 = a10 * e0, g20 = a20 * e0, g30 = a30 * e0;         // a_i0 / d0
-    const double t11 = fma(-a10, g10, a11);
-    const double u21 = fma(-a20, g10, a21), u31 = fma(-a30, g10, a31);
-    const double s22 = fma(-a20, g20, a22), v32 = fma(-a30, g20, a32), s33 = fma(-a30, g30, a33);
-    if (!(t11 > 0.0) && fail == 0) fail = 4 * S + 2;
-    const double e1 = rcp_ref(t11);
-    const double h21 = u21 * e1, h31 = u31 * e1;                          // u_i1 / d1
-    const double t22 = fma(-u21, h21, s22);
-    const double u32 = fma(-u31, h21, v32), w33 = fma(-u31, h31, s33);
-    if (!(t22 > 0.0) && fail == 0) fail = 4 * S + 3;
-    const double e2 = rcp_ref(t22);
-    const double t33 = fma(-u32, u32 * e2, w33);
-    if (!(t33 > 0.0) && fail == 0) fail = 4 * S + 4;
-    double l00, r0, l11, r1, l22, r2, l33, r3;
+    double l00, r0;
     rsqrt_pivot(a00, l00, r0);
+    double l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
+    double t11 = fma(-l10, l10, a11);
+    if (!(t11 > 0.0) && fail == 0) fail = 4 * S + 2;
+    double l11, r1;
     rsqrt_pivot(t11, l11, r1);
+    double l21 = fma(-l20, l10, a21) * r1, l31 = fma(-l30, l10, a31) * r1;
+    double t22 = fma(-l21, l21, fma(-l20, l20, a22));
+    if (!(t22 > 0.0) && fail == 0) fail = 4 * S + 3;
+    double l22, r2;
     rsqrt_pivot(t22, l22, r2);
+    double l32 = fma(-l31, l21, fma(-l30, l20, a32)) * r2;
+    double t33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a33)));
+    if (!(t33 > 0.0) && fail == 0) fail = 4 * S + 4;
+    double l33, r3;
     rsqrt_pivot(t33, l33, r3);
-    const double l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
-    const double l21 = u21 * r1, l31 = u31 * r1;
-    const double l32 = u32 * r2;
+    // (An outer-product form with reciprocals on the dependent chain and the square roots refined beside it -- 3 x 6 + 12
+    // dependent operations instead of 4 x 14 -- was measured in round 3: SLOWER, 4.54 -> 4.72 ms on the taper path, whose
+    // time is half tile factorisations: one wave issues in order, and the variant has a quarter more instructions.)
     // inverse of the 4x4 factor
     double m00 = r0, m11 = r1, m22 = r2, m33 = r3;
     double m10 = -(l10 * m00) * r1;
@@ -754,6 +741,9 @@ __device__ __noinline__ void engine_tile_inverse(double *W, int wave, int lane)
     }
 }
 
+// FUSED / WINV: which paths the instantiation contains at all (each alternative costs the others registers: with
+// everything in one kernel the spills reached the pivot chains of the plain path)
+template <bool FUSED, bool WINV>
 __global__ void __launch_bounds__(512)
 potrf_engine_kernel(EngineArgs e)
 {
@@ -766,7 +756,7 @@ potrf_engine_kernel(EngineArgs e)
     const size_t lda = e.lda;
     if (tid == 0) __hip_atomic_store(e.alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int t = e.t0; t < e.nt; t += 2) {
-        if (e.fused && t + 1 < e.nt && t >= e.w_until) {
+        if (FUSED && t + 1 < e.nt && t >= e.w_until) {
             // one fused pass over the 256 x 256 block (potrf_block_fused), then tile t + 1 straight from LDS
             if (tid == 0)
                 *okp = (wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t) &&
@@ -790,7 +780,7 @@ potrf_engine_kernel(EngineArgs e)
         if (*okp == 0) return;
         potrf_tile_body<true>(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem, QALL);
         __syncthreads();
-        if (t < e.w_until) engine_tile_inverse(e.winv + (size_t)(t & 1) * TILE * TILE, wave, lane);
+        if (WINV && t < e.w_until) engine_tile_inverse(e.winv + (size_t)(t & 1) * TILE * TILE, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t);
@@ -844,9 +834,9 @@ potrf_engine_kernel(EngineArgs e)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // X in LDS is dead; the tile is re-read from memory
-        potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, t < e.w_until ? QALL : nullptr);
+        potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, (WINV && t < e.w_until) ? QALL : nullptr);
         __syncthreads();
-        if (t < e.w_until) engine_tile_inverse(e.winv + (size_t)((t + 1) & 1) * TILE * TILE, wave, lane);
+        if (WINV && t < e.w_until) engine_tile_inverse(e.winv + (size_t)((t + 1) & 1) * TILE * TILE, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t + 1);
@@ -1119,11 +1109,16 @@ struct UpdArgs {
     // everything else a tile; ntiles then counts tiles AND strips
     int nstrips; unsigned strip_pos, near_need;
     PanelArgs pan;
+    int skew, kblk;                // packed band buffer (kernels.h band_index): C and P are its unshifted base, the operand
+                                   // panel is tile column kblk; rows then count from each tile column's own diagonal tile
 };
 
 // ROLE only names the instantiation (0 = trailing update, 1 = in-panel / sharded update) so that
 // profiler summaries keep the dominant trailing launches apart from the narrow ones
-template <int TM, int KC, int ROLE>
+// STRIPS: the instantiation that can take panel strips as tasks (a.nstrips); the plain one must not even contain that path --
+// with it the kernel needs a few bytes of scratch per lane, and a kernel with scratch runs measurably slower and no longer
+// side by side with itself on other streams (batch slots: 590 -> 310 evaluations/s on the taper path)
+template <int TM, int KC, int ROLE, bool STRIPS = false>
 __global__ void __launch_bounds__(256, 8)
 update_kernel(UpdArgs a)
 {
@@ -1179,7 +1174,7 @@ update_kernel(UpdArgs a)
         const int kc = t2 / TPC, rg = (t2 % TPC) * RPT;
         const int ro = (lane >> 4) * LDT + (lane & 15);
         int ti, tj;
-        if (a.nstrips > 0 && L >= a.strip_pos && L < a.strip_pos + (unsigned)a.nstrips) {
+        if (STRIPS && a.nstrips > 0 && L >= a.strip_pos && L < a.strip_pos + (unsigned)a.nstrips) {
             // a strip of the next panel: its input -- the near tiles of this launch, the engine's tiles -- is complete
             // or on its way (the strips sit behind the near tiles in the task order, far enough for the engine)
             __builtin_amdgcn_s_setprio(0);
@@ -1194,7 +1189,7 @@ update_kernel(UpdArgs a)
             if (L >= a.ntiles) break;
             continue;
         }
-        const unsigned Lt = (a.nstrips > 0 && L >= a.strip_pos) ? L - (unsigned)a.nstrips : L;     // position among the tiles
+        const unsigned Lt = (STRIPS && a.nstrips > 0 && L >= a.strip_pos) ? L - (unsigned)a.nstrips : L;     // position among the tiles
         if (a.lower_only) {
             // 1-D order over the tiles (ti >= tj) of the trapezoid, column by column: column j (0-based
             // from tj0) holds H - j tiles and starts at j H - j (j-1)/2.  Bisection in integers: L is
@@ -1224,27 +1219,30 @@ update_kernel(UpdArgs a)
         // their CU (beside seven other workgroups a tile takes ~70 us, alone ~10)
         if (sig_wg) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 
-        const double *gI = a.P + (size_t)(ti * TM + rg) + (size_t)kc * a.ldp;
-        const double *gJ = a.P + (size_t)(tj * TM + rg) + (size_t)kc * a.ldp;
+        // rows: global, or -- packed band buffer -- local to the tile column they are read from / written to
+        int rowI_P = ti * TM, rowJ_P = tj * TM, rowI_C = ti * TM;
+        if (a.skew) {
+            const bool ext = ti >= a.ext0;                          // a row under the matrix
+            const int under = a.skew * TILE + (ti - a.ext0) * TM;
+            rowI_P = ext ? under : ti * TM - TILE * a.kblk;
+            rowJ_P = tj * TM - TILE * a.kblk;
+            rowI_C = ext ? under : ti * TM - TILE * ((tj * TM) / TILE);
+        }
+        const double *gI = a.P + (size_t)(rowI_P + rg) + (size_t)kc * a.ldp;
+        const double *gJ = a.P + (size_t)(rowJ_P + rg) + (size_t)kc * a.ldp;
         d2 stI[RPT / 2], stJ[RPT / 2];
 
-        // The accumulators START as the C tile (loaded here, together with the first operand chunk) and the products are
-        // subtracted by the MFMA itself (negated first operand): the tile ends with sixteen stores -- no load, no
-        // subtraction, and none of the four dependent memory round trips a read-modify-write epilogue had.
-        // (addresses = a wave-uniform base, kept in scalar registers, plus ONE 32-bit per-lane offset: sixteen 64-bit
-        // per-lane addresses would not fit the kernel's 64 registers)
-        double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi) + (size_t)(tj * TM + (TM / 2) * wj) * a.ldc;
+        // (Loading C into the accumulators at the START of the tile and subtracting in the MFMA -- neg:[1,0,0] -- so that the
+        // tile ends with stores only was measured in round 3 on one box against this form: SLOWER, the 39 trailing launches
+        // 6.65 -> 6.95 ms; sixteen more loads in flight at the start of every tile cost more than the epilogue's round trips.)
+        double *Cb = a.C + (size_t)(rowI_C + (TM / 2) * wi) + (size_t)(tj * TM + (TM / 2) * wj) * a.ldc;
         const unsigned ldcb = 8u * (unsigned)a.ldc;                                          // bytes, all of these
         const unsigned cvo = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldcb;
         d4 acc[NB][NB];
 #pragma unroll
         for (int x = 0; x < NB; ++x)
 #pragma unroll
-            for (int y = 0; y < NB; ++y) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[x][y][r] = *(const double *)((const char *)(Cb + 16 * x) + (cvo + (unsigned)(16 * y + 4 * r) * ldcb));
-            }
+            for (int y = 0; y < NB; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
 
 #pragma unroll
         for (int v = 0; v < RPT / 2; ++v) {
@@ -1282,7 +1280,7 @@ update_kernel(UpdArgs a)
 #pragma unroll
                 for (int x = 0; x < NB; ++x)
 #pragma unroll
-                    for (int y = 0; y < NB; ++y) acc[x][y] = MFMA64_NEGA(pj_[y], pi_[x], acc[x][y]);
+                    for (int y = 0; y < NB; ++y) acc[x][y] = MFMA64(pj_[y], pi_[x], acc[x][y]);
             }
             if (ch + 1 < nch) {
 #pragma unroll
@@ -1298,22 +1296,28 @@ update_kernel(UpdArgs a)
         unsigned Lnext = 0;
         if (a.queue && t2 == 0)
             Lnext = gridDim.x + __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (the store offsets are re-derived from a laundered copy: kept from the loads they would live through the whole
-        // K loop and spill)
+        // C -= acc, one accumulator block (4 elements) at a time: loads first, then the stores (written as
+        // `*p -= acc` the compiler must assume that a store aliases the next load and serialises the memory
+        // round trips; all sixteen at once would cost the 8th wave per SIMD in registers)
         unsigned cve = cvo;
         asm volatile("" : "+v"(cve));
 #pragma unroll
         for (int x = 0; x < NB; ++x)
 #pragma unroll
             for (int y = 0; y < NB; ++y) {
+                d4 cv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cv[r] = *(const double *)((const char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb));
+                cv -= acc[x][y];
                 if (wt_wg) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        store_wt((double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)), acc[x][y][r]);
+                        store_wt((double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)), cv[r]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        *(double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)) = acc[x][y][r];
+                        *(double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)) = cv[r];
                 }
             }
         if (wt_wg) {
@@ -1552,18 +1556,18 @@ __device__ __forceinline__ double block_sum(double v, double *red)
 // block b < nr*nr: Gram entry (b / nr, b % nr) over columns [c0,c1) and < n;
 // block nr*nr: sum of log of the diagonal over the same columns.
 __global__ void __launch_bounds__(256)
-finalize_kernel(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr, double *out)
+finalize_kernel(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr, double *out, int skew, int npad)
 {
     __shared__ double red[4];
     const int b = blockIdx.x;
     const int hi = c1 < n ? c1 : n;
     double s = 0.0;
     if (b == nr * nr) {
-        for (int c = c0 + threadIdx.x; c < hi; c += blockDim.x) s += log(A[(size_t)c + (size_t)c * lda]);
+        for (int c = c0 + threadIdx.x; c < hi; c += blockDim.x) s += log(A[band_index(c, c, lda, skew, npad)]);
     } else {
         const int ra = row0 + b / nr, rb = row0 + b % nr;
         for (int c = c0 + threadIdx.x; c < hi; c += blockDim.x)
-            s += A[(size_t)ra + (size_t)c * lda] * A[(size_t)rb + (size_t)c * lda];
+            s += A[band_index(ra, c, lda, skew, npad)] * A[band_index(rb, c, lda, skew, npad)];
     }
     s = block_sum(s, red);
     if (threadIdx.x == 0) out[b == nr * nr ? 0 : 1 + b] = s;
@@ -1575,7 +1579,7 @@ finalize_kernel(const double *A, size_t lda, int c0, int c1, int n, int row0, in
 // stage 2: the chunks of one row summed in ascending order.
 __global__ void __launch_bounds__(256)
 row_reduce_kernel(const double *A, size_t lda, int n, int rowy, int row0, int m,
-                  double *scratch, int cchunk)
+                  double *scratch, int cchunk, int skew, int npad)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cb = blockIdx.y * cchunk;
@@ -1583,8 +1587,8 @@ row_reduce_kernel(const double *A, size_t lda, int n, int rowy, int row0, int m,
     if (i >= m) return;
     double s = 0.0, q = 0.0;
     for (int c = cb; c < ce; ++c) {
-        double v = A[(size_t)(row0 + i) + (size_t)c * lda];
-        double y = A[(size_t)rowy + (size_t)c * lda];
+        double v = A[band_index(row0 + i, c, lda, skew, npad)];
+        double y = A[band_index(rowy, c, lda, skew, npad)];
         s = fma(v, y, s);
         q = fma(v, v, q);
     }
@@ -1676,8 +1680,14 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
     // resident; 76 .. 152 KB did not.)
     size_t shm = 136 * 1024;
     { const char *x = getenv("COCONS_ENGINE_LDS"); if (x && (size_t)atol(x) >= shm) shm = (size_t)atol(x); }
-    (void)hipFuncSetAttribute((const void *)potrf_engine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(potrf_engine_kernel, dim3(1), dim3(512), shm, s, e);
+    const bool w = e.w_until > 0, fu = fused != 0;
+    const void *k = w ? (fu ? (const void *)potrf_engine_kernel<true, true> : (const void *)potrf_engine_kernel<false, true>)
+                      : (fu ? (const void *)potrf_engine_kernel<true, false> : (const void *)potrf_engine_kernel<false, false>);
+    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (w && fu) hipLaunchKernelGGL((potrf_engine_kernel<true, true>), dim3(1), dim3(512), shm, s, e);
+    else if (w) hipLaunchKernelGGL((potrf_engine_kernel<false, true>), dim3(1), dim3(512), shm, s, e);
+    else if (fu) hipLaunchKernelGGL((potrf_engine_kernel<true, false>), dim3(1), dim3(512), shm, s, e);
+    else hipLaunchKernelGGL((potrf_engine_kernel<false, false>), dim3(1), dim3(512), shm, s, e);
 }
 
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
@@ -1704,7 +1714,7 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig, int sig_tile,
                         unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
-                        unsigned *near, int near_tiles, const UpdStrips *strips)
+                        unsigned *near, int near_tiles, const UpdStrips *strips, int skew, int kblk)
 {
     // tile rows [ti0, ti1), or -- band-limited -- [ti0, band_hi) and [ext0, ti1)
     const bool band = band_hi >= 0;
@@ -1715,6 +1725,7 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     a.near = near; a.near_tj0 = 2 * tj0; a.near_w = 2 * near_tiles;
     a.nstrips = 0; a.strip_pos = 0; a.near_need = 0;
     memset(&a.pan, 0, sizeof a.pan);
+    a.skew = skew; a.kblk = kblk;
     a.Hb = 2 * rows_band; a.ext0 = 2 * ext0;
     a.C = A; a.ldc = lda; a.P = P; a.ldp = ldp; a.K = K;
     a.lower_only = lower_only ? 1 : 0;
@@ -1773,8 +1784,9 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     // COCONS_UPD_MFMA4=1 selects the 4x4x4 kernel: its instruction peaks at 76 TFLOP/s, but at a 32x32
     // tile per wave, one barrier per 32 instructions and 5 waves per SIMD the kernel around it lands
     // where the default does (what it needs next)
-    if (!upd_form4()) {
-        if (trailing) hipLaunchKernelGGL((update_kernel<64, 8, 0>), grid, dim3(256), 0, s, a);
+    if (!upd_form4() || skew) {     // (the alternative kernel knows no packed band buffer)
+        if (a.nstrips > 0) hipLaunchKernelGGL((update_kernel<64, 8, 0, true>), grid, dim3(256), 0, s, a);
+        else if (trailing) hipLaunchKernelGGL((update_kernel<64, 8, 0>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((update_kernel<64, 8, 1>), grid, dim3(256), 0, s, a);
     } else {
         if (trailing) hipLaunchKernelGGL((update4_kernel<0>), grid, dim3(256), 4 * 8192, s, a);
@@ -1786,10 +1798,10 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
 bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig, int sig_tile,
                    unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
-                   unsigned *near, int near_tiles, const UpdStrips *strips)
+                   unsigned *near, int near_tiles, const UpdStrips *strips, int skew)
 {
     return launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile,
-                              wait_word, abort_word, queue, band_hi, ext0, near, near_tiles, strips);
+                              wait_word, abort_word, queue, band_hi, ext0, near, near_tiles, strips, skew, k0 / TILE);
 }
 
 // tiles of 64 x 64 in the first `near_tiles` (128-wide) tile columns of the trapezoid launch_update(..., lower_only, ti0 ==
@@ -1816,12 +1828,12 @@ void launch_flag_gate(unsigned *word, unsigned need, unsigned *abort_word, unsig
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
                           double *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(256), 0, s, A, lda, c0, c1, n, row0, nr, out);
+    hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(256), 0, s, A, lda, c0, c1, n, row0, nr, out, 0, 0);
 }
 
-void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s)
+void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s, int skew, int npad)
 {
-    launch_finalize_cols(A, lda, 0, n, n, row0, nr, out, s);
+    hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(256), 0, s, A, lda, 0, n, n, row0, nr, out, skew, npad);
 }
 
 size_t row_reduce_scratch_doubles(int n, int m)
@@ -1830,12 +1842,12 @@ size_t row_reduce_scratch_doubles(int n, int m)
 }
 
 void launch_row_reduce(const double *A, size_t lda, int n, int rowy, int row0, int m,
-                       double *stoch, double *quad, double *scratch, hipStream_t s)
+                       double *stoch, double *quad, double *scratch, hipStream_t s, int skew, int npad)
 {
     if (m <= 0) return;
     const int cchunk = 256, nchunks = (n + cchunk - 1) / cchunk;
     hipLaunchKernelGGL(row_reduce_kernel, dim3((m + 255) / 256, nchunks), dim3(256), 0, s,
-                       A, lda, n, rowy, row0, m, scratch, cchunk);
+                       A, lda, n, rowy, row0, m, scratch, cchunk, skew, npad);
     hipLaunchKernelGGL(row_reduce_final_kernel, dim3((m + 255) / 256), dim3(256), 0, s,
                        scratch, m, nchunks, stoch, quad);
 }

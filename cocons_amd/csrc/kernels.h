@@ -62,6 +62,7 @@ struct RhsArgs {
     int row0, nrows;       // nrows source rows, written at out rows row0..
     int nrows_zero;        // further rows (row0+nrows ..) cleared to zero
     int col0, ncols_out;   // column range [col0, ncols_out)
+    int skew, npad;        // packed band target (band_index): 0 = dense
 };
 
 void launch_loc_params(const LocArgs &a, hipStream_t s);
@@ -71,12 +72,13 @@ void launch_rhs_rows(const RhsArgs &a, hipStream_t s);
 // entries of the sparse/taper covariance for a CSR pattern (1-based indices, device arrays)
 void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const int *rp, const double *rows,
                   size_t stride_rows, const double *cols, size_t stride, double nu_fixed, double *out, hipStream_t s,
-                  const double *tapv = nullptr, double *A = nullptr, size_t lda = 0, int row0 = 0);   // A: dense target, see TaperArgs
+                  const double *tapv = nullptr, double *A = nullptr, size_t lda = 0, int row0 = 0,    // A: dense target, see TaperArgs
+                  int skew = 0, int npad = 0);                                                       // packed band target (band_index)
 // rows idx[0..nidx) of the dense covariance (cor != 0: of cov2cor of it); out row b at out + b * n
 // zero the tiles inside the envelope (d_hi: device copy of FactorView::hi; max_band = max over c of hi[c] - c)
-void launch_band_zero(double *A, size_t lda, const int *d_hi, int nt, int max_band, hipStream_t s);
+void launch_band_zero(double *A, size_t lda, const int *d_hi, int nt, int max_band, hipStream_t s, int skew = 0);
 // identity on the padding diagonal of a taper handle's buffer
-void launch_pad_identity(double *A, size_t lda, int n, int npad, hipStream_t s);
+void launch_pad_identity(double *A, size_t lda, int n, int npad, hipStream_t s, int skew = 0);
 void launch_cov_rows(int mode, int n, int nidx, const int *idx, const double *loc, size_t stride, double gr,
                      double nu_fixed, int cor, double *out, hipStream_t s);
 // out[i] = 2^(1-nu)/Gamma(nu) u^nu K_nu(u) by the device routine of the pair kernels (diagnostic)
@@ -84,6 +86,22 @@ void launch_matern_points(int n, const double *nu, const double *x, double *out,
 
 // ---- factorisation (chol.hip) -------------------------------------------------
 constexpr int TILE = 128;          // tile edge of the blocked factorisation
+
+// Packed band storage of a band-limited factorisation (taper handles): tile column c (128 columns) keeps only the rows
+// the factor can touch -- `skew` tile rows from its diagonal tile down, then the rows under the matrix -- so the leading
+// dimension is skew * 128 + (rows under the matrix) instead of the matrix order, and element (i, j) sits at
+//     i_local + j * ld,   i_local = i - 128 (j / 128)  for a row of the matrix (i < npad),
+//                                   skew * 128 + (i - npad)  for a row under it.
+// skew = 0: the ordinary dense layout.  Kernels that work inside ONE tile column get a shifted base pointer
+// (band_base) and keep their global row indices; the rows under the matrix then start at row (c + skew) * 128.
+__host__ __device__ inline size_t band_index(int i, int j, size_t ld, int skew, int npad)
+{
+    if (skew == 0) return (size_t)i + (size_t)j * ld;
+    const int il = i < npad ? i - TILE * (j / TILE) : skew * TILE + (i - npad);
+    return (size_t)il + (size_t)j * ld;
+}
+// base pointer with which tile column c of a packed band buffer is addressed by GLOBAL row and column indices
+inline double *band_base(double *A, int c, int skew) { return skew ? A - (ptrdiff_t)TILE * c : A; }
 
 // Factor the 128x128 diagonal tile at (c0,c0) in place (lower), write the inverses of
 // its eight 16x16 diagonal blocks to dinv (8*256 doubles).  info: atomicMin of the
@@ -136,7 +154,8 @@ bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int t
                    bool lower_only, hipStream_t s, unsigned *sig = nullptr, int sig_tile = -1,
                    unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
                    int band_hi = -1, int ext0 = 0,       // band_hi >= 0: tile rows [ti0, band_hi) and [ext0, ti1)
-                   unsigned *near = nullptr, int near_tiles = 0, const UpdStrips *strips = nullptr);
+                   unsigned *near = nullptr, int near_tiles = 0, const UpdStrips *strips = nullptr,
+                   int skew = 0);          // packed band buffer (band_index; with band_hi / ext0): A is its unshifted base
 // near / near_tiles (lower_only launches): the tiles in the first near_tiles tile columns -- the next panel -- are stored
 // write-through and each adds 1 to *near when done; update_near_count() says how many there are.  A stream that has
 // passed launch_flag_gate(near, count, ...) may read them although the update launch is still running.
@@ -151,11 +170,12 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
                         int ptiles, int world, int rank, unsigned *sig = nullptr, int sig_tile = -1,
                         unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
                         int band_hi = -1, int ext0 = 0, unsigned *near = nullptr, int near_tiles = 0,
-                        const UpdStrips *strips = nullptr);
+                        const UpdStrips *strips = nullptr, int skew = 0, int kblk = 0);
 
 
 // reductions: out[0] = sum_{i<n} log(A(i,i)); out[1 + a*nr + b] = sum_{c<n} A(row0+a,c) A(row0+b,c)
-void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s);
+void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s,
+                     int skew = 0, int npad = 0);          // packed band source (band_index)
 // partial version over columns [c0,c1) accumulating into out (atomic adds), sharded path
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
                           double *out, hipStream_t s);
@@ -163,7 +183,7 @@ void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, in
 // deterministic two-stage reduction; scratch must hold row_reduce_scratch_doubles(n, m) doubles
 size_t row_reduce_scratch_doubles(int n, int m);
 void launch_row_reduce(const double *A, size_t lda, int n, int rowy, int row0, int m,
-                       double *stoch, double *quad, double *scratch, hipStream_t s);
+                       double *stoch, double *quad, double *scratch, hipStream_t s, int skew = 0, int npad = 0);
 
 // Y = L E + trend (lower factor L in A), E n x nsim, Y n x nsim
 void launch_trmm_lower(const double *A, size_t lda, int n, const double *E, int lde, int nsim,

@@ -685,6 +685,37 @@ def test_taper_handle_recovers_after_failed_evaluation(oracle):
     fit.close()
 
 
+def test_taper_packed_band_buffer_equals_dense_buffer(monkeypatch):
+    """A band-limited taper handle keeps its factorisation buffer PACKED (every 128-column tile column stores its envelope
+    rows and the rows under the matrix: O(n x bandwidth) doubles); COCONS_TAPER_PACKED=0 keeps the dense n x n buffer and
+    only uses its band.  Same kernels, same order of operations: objective, parts and the sparse prediction are identical."""
+    import cocons_amd as ca
+    n, m = 3000, 200
+    locs, X, th, rng = _problem(n, seed=3100)
+    z = rng.standard_normal((n, 2))
+    ref_taper = _taper_pattern(locs, 0.07)
+    lp = rng.uniform(0, 1, size=(m, 2))
+    Xp = np.column_stack([np.ones(m), rng.standard_normal(m), rng.standard_normal(m)])
+    cip, rpp = _csr_within(lp, locs, 0.07)
+    entp = np.empty(cip.size)
+    for i in range(m):
+        w0, w1 = rpp[i] - 1, rpp[i + 1] - 1
+        d = np.sqrt(np.sum((locs[cip[w0:w1] - 1] - lp[i]) ** 2, axis=1))
+        entp[w0:w1] = _wendland1(d, 0.07)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("COCONS_TAPER_PACKED", flag)
+        fit = ca.CoconsTaperFit(locs, X, z, wl_limits(), *ref_taper)
+        v, parts = fit.neg2loglik_core(th)
+        st, qf = fit.predict_core(th, lp, Xp, (cip, rpp, entp))
+        v2, _ = fit.neg2loglik_core(th)                      # after the prediction regrew the rows under the matrix
+        res[flag] = (v, parts, st, qf, v2)
+        fit.close()
+    assert res["1"][0] == res["0"][0] and np.array_equal(res["1"][1], res["0"][1])
+    assert np.array_equal(res["1"][2], res["0"][2]) and np.array_equal(res["1"][3], res["0"][3])
+    assert res["1"][4] == res["1"][0] and res["0"][4] == res["0"][0]
+
+
 def test_taper_predict_vs_oracle(oracle):
     """Sparse branch of cocoPredict (R/predict.R:216-283) on a taper handle against the CPU restatement: tapered
     cross-covariance rows as border of the tapered matrix, one prediction location without any neighbour (an empty

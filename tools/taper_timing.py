@@ -56,7 +56,7 @@ dtb = time.perf_counter() - t0
 print("batch of %d independent evaluations: %.1f evals/s (all ok: %s)" % (nb, nb / dtb, bool(np.all(st == 0))))
 # context: a sparse direct factorisation of the same matrix on this host's CPU (scipy / SuperLU, one thread's worth of
 # work; spam's supernodal Cholesky is not available here and would be roughly 2x cheaper than an LU)
-if n > 12000 and not (len(sys.argv) > 3 and sys.argv[3] == "cpu"):
+if n > 12000 and not (len(sys.argv) > 3 and sys.argv[3] == "cpu") or (len(sys.argv) > 3 and sys.argv[3] == "nocpu"):
     sys.exit(0)
 try:
     import scipy.sparse as sp
