@@ -844,7 +844,7 @@ struct Tunables {
     int overlap = 0;         // COCONS_PANEL_OVERLAP
     int upd_dynamic = 1;     // COCONS_UPD_DYNAMIC
     int near_force = 0;      // (experiment) count the near tiles write-through although nobody waits for them
-    int engine_fused = 1;    // COCONS_ENGINE_FUSED: the engine's fused pass over a diagonal block (potrf_block_fused)
+    int engine_fused = 0;    // COCONS_ENGINE_FUSED: the engine's fused pass over a diagonal block (potrf_block_fused)
     bool init = false;
 };
 static Tunables &tun()
@@ -878,6 +878,8 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "upd_dynamic") t.upd_dynamic = value;
     else if (k == "near_force") t.near_force = value;
     else if (k == "engine_fused") t.engine_fused = value;
+    else if (k == "upd_waves") set_update_waves(value);
+    else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
     else return fail(-1, "cocons_debug_tune: unknown switch %s", name);
     return 0;
 }

@@ -1118,13 +1118,18 @@ struct UpdArgs {
 // STRIPS: the instantiation that can take panel strips as tasks (a.nstrips); the plain one must not even contain that path --
 // with it the kernel needs a few bytes of scratch per lane, and a kernel with scratch runs measurably slower and no longer
 // side by side with itself on other streams (batch slots: 590 -> 310 evaluations/s on the taper path)
-template <int TM, int KC, int ROLE, bool STRIPS = false>
-__global__ void __launch_bounds__(256, 8)
+// NW: waves per workgroup.  4 (KC = 8): each wave a quarter of the tile, 8 workgroups per CU.  8 (KC = 16, 512 threads):
+// each wave an eighth (32 x 16), 4 workgroups per CU -- the same waves per SIMD, the same work per wave and barrier, but a
+// tile is finished in half the time, so the launch drains for half as long at its end.
+template <int TM, int KC, int ROLE, bool STRIPS = false, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, 8)
 update_kernel(UpdArgs a)
 {
     constexpr int LDT = TM + 16;   // lanes l and l+16 land 128 B apart mod 256 -> conflict-free b64 reads
-    constexpr int NB = TM / 32;    // 16x16 blocks per wave and dimension
-    constexpr int TPC = 256 / KC;  // threads per panel column
+    constexpr int WY = NW / 2;     // wave grid 2 x WY: a wave's share is TM/2 rows x TM/WY columns
+    constexpr int NB = TM / 32;    // 16x16 blocks per wave along the rows
+    constexpr int NBY = TM / WY / 16;   // ... and along the columns
+    constexpr int TPC = 64 * NW / KC;   // threads per panel column
     constexpr int RPT = TM / TPC;  // rows staged per thread and side
     __shared__ double sI[2][KC * LDT];
     __shared__ double sJ[2][KC * LDT];
@@ -1235,14 +1240,14 @@ update_kernel(UpdArgs a)
         // (Loading C into the accumulators at the START of the tile and subtracting in the MFMA -- neg:[1,0,0] -- so that the
         // tile ends with stores only was measured in round 3 on one box against this form: SLOWER, the 39 trailing launches
         // 6.65 -> 6.95 ms; sixteen more loads in flight at the start of every tile cost more than the epilogue's round trips.)
-        double *Cb = a.C + (size_t)(rowI_C + (TM / 2) * wi) + (size_t)(tj * TM + (TM / 2) * wj) * a.ldc;
+        double *Cb = a.C + (size_t)(rowI_C + (TM / 2) * wi) + (size_t)(tj * TM + (TM / WY) * wj) * a.ldc;
         const unsigned ldcb = 8u * (unsigned)a.ldc;                                          // bytes, all of these
         const unsigned cvo = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldcb;
-        d4 acc[NB][NB];
+        d4 acc[NB][NBY];
 #pragma unroll
         for (int x = 0; x < NB; ++x)
 #pragma unroll
-            for (int y = 0; y < NB; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int y = 0; y < NBY; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
 
 #pragma unroll
         for (int v = 0; v < RPT / 2; ++v) {
@@ -1268,19 +1273,18 @@ update_kernel(UpdArgs a)
                 }
             }
             const double *bI = &sI[cur][ro + (TM / 2) * wi];
-            const double *bJ = &sJ[cur][ro + (TM / 2) * wj];
+            const double *bJ = &sJ[cur][ro + (TM / WY) * wj];
 #pragma unroll
             for (int s = 0; s < KC / 4; ++s) {
-                double pi_[NB], pj_[NB];
+                double pi_[NB], pj_[NBY];
 #pragma unroll
-                for (int x = 0; x < NB; ++x) {
-                    pi_[x] = bI[s * 4 * LDT + 16 * x];
-                    pj_[x] = bJ[s * 4 * LDT + 16 * x];
-                }
+                for (int x = 0; x < NB; ++x) pi_[x] = bI[s * 4 * LDT + 16 * x];
+#pragma unroll
+                for (int y = 0; y < NBY; ++y) pj_[y] = bJ[s * 4 * LDT + 16 * y];
 #pragma unroll
                 for (int x = 0; x < NB; ++x)
 #pragma unroll
-                    for (int y = 0; y < NB; ++y) acc[x][y] = MFMA64(pj_[y], pi_[x], acc[x][y]);
+                    for (int y = 0; y < NBY; ++y) acc[x][y] = MFMA64(pj_[y], pi_[x], acc[x][y]);
             }
             if (ch + 1 < nch) {
 #pragma unroll
@@ -1304,7 +1308,7 @@ update_kernel(UpdArgs a)
 #pragma unroll
         for (int x = 0; x < NB; ++x)
 #pragma unroll
-            for (int y = 0; y < NB; ++y) {
+            for (int y = 0; y < NBY; ++y) {
                 d4 cv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -1702,6 +1706,13 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
                        nb1, ext_r0);
 }
 
+// waves per workgroup of the trailing update (COCONS_UPD_WAVES: 4 or 8, see update_kernel's NW)
+static int upd_waves = -1;
+static long long upd_w8_max_tiles = -1;      // 8-wave workgroups only for launches of at most this many tiles (0 = all)
+void set_update_waves(int nw) { upd_waves = nw == 8 ? 8 : 4; }
+void set_update_w8_max_tiles(int ntiles) { upd_w8_max_tiles = ntiles < 0 ? 0 : ntiles; }
+
+
 // COCONS_UPD_MFMA4=1 selects the 4x4x4 kernel for the updates (static tile order only)
 static bool upd_form4()
 {
@@ -1720,6 +1731,9 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     const bool band = band_hi >= 0;
     const int rows_band = (band ? band_hi : ti1) - ti0, rows_ext = band ? ti1 - ext0 : 0;
     if (rows_band + rows_ext <= 0 || rows_band < 0 || rows_ext < 0 || tj1 <= tj0 || K <= 0) return false;
+    if (upd_waves < 0) { const char *e = getenv("COCONS_UPD_WAVES"); set_update_waves(e ? atoi(e) : 8); }
+    if (upd_w8_max_tiles < 0) { const char *e = getenv("COCONS_UPD_W8_MAX_TILES"); set_update_w8_max_tiles(e ? atoi(e) : 3500); }
+    bool use_w8 = false;
     UpdArgs a;
     a.queue = nullptr; a.ntiles = 0;
     a.near = near; a.near_tj0 = 2 * tj0; a.near_w = 2 * near_tiles;
@@ -1772,9 +1786,13 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
                 // dynamic tile order: as many workgroups as the chip holds (8 per CU), tiles off *queue (zero now)
                 // (one CU's worth fewer: the engine owns a CU, and a workgroup that is not resident from the
                 // start would take its first, static tile late)
-                if (total > slots) {
+                const bool w8 = upd_waves == 8 && K >= 2 * TILE && a.nstrips == 0 && !skew &&
+                                (upd_w8_max_tiles == 0 || total <= upd_w8_max_tiles);
+                use_w8 = w8;
+                const int cap = w8 ? slots / 2 - 4 : slots - 8;       // resident workgroups: 4 or 8 per CU, one CU's worth fewer
+                if (total > cap + (w8 ? 4 : 8)) {
                     a.queue = queue; a.ntiles = (unsigned)total;
-                    grid = dim3((unsigned)(slots - 8), 1);
+                    grid = dim3((unsigned)cap, 1);
                 }
             }
         }
@@ -1786,6 +1804,9 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     // where the default does (what it needs next)
     if (!upd_form4() || skew) {     // (the alternative kernel knows no packed band buffer)
         if (a.nstrips > 0) hipLaunchKernelGGL((update_kernel<64, 8, 0, true>), grid, dim3(256), 0, s, a);
+        else if (trailing && use_w8 && a.lower_only)
+            hipLaunchKernelGGL((update_kernel<64, 16, 0, false, 8>), grid, dim3(512), 0, s, a);
+
         else if (trailing) hipLaunchKernelGGL((update_kernel<64, 8, 0>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((update_kernel<64, 8, 1>), grid, dim3(256), 0, s, a);
     } else {

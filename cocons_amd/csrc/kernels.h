@@ -160,6 +160,10 @@ bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int t
 // write-through and each adds 1 to *near when done; update_near_count() says how many there are.  A stream that has
 // passed launch_flag_gate(near, count, ...) may read them although the update launch is still running.
 unsigned update_near_count(int ti0, int ti1, int near_tiles);
+// waves per workgroup of the trailing-update kernel: 4 (default) or 8 (512 threads, KC = 16: half the tile latency)
+void set_update_waves(int nw);
+void set_update_w8_max_tiles(int ntiles);
+void set_update_w8_inpanel(int on);     // ... only for launches of at most this many tiles (0 = every launch)
 void launch_flag_gate(unsigned *word, unsigned need, unsigned *abort_word, unsigned code, hipStream_t s);
 // like launch_update but the (i,k) and (j,k) operands come from a separate packed
 // panel buffer P (ldp rows, row index = global row), used by the sharded path.
