@@ -43,8 +43,8 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (= fp64 vector peak): 256 CU x 4 SIMD
 #                                  x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 issues every 64 cycles
-MFMA_UTIL_PROFILE = "r02_update_kernel_mfma_util.json"      # matrix pipe busy fraction of the update kernel (rocprofv3 --pmc)
-TRAFFIC_PROFILE = "r02_update_kernel_hbm_traffic.json"
+MFMA_UTIL_PROFILE = "r03_update_kernel_mfma_util.json"      # matrix pipe busy fraction of the update kernel (rocprofv3 --pmc)
+TRAFFIC_PROFILE = "r03_update_kernel_hbm_traffic.json"
 
 
 def chol_flops(n):
@@ -349,16 +349,19 @@ def main():
         if launches > 0 and st["update_sum_ms"] > 0:
             achieved = flops / (st["update_sum_ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma",
-                        "kernel": "cocons::update_kernel<64, 8, 0> (trailing SYRK/GEMM, v_mfma_f64_16x16x4_f64)",
+                        "kernel": "cocons::update_kernel<64, 8, 0, false, 4> / <64, 16, 0, false, 8> (trailing SYRK/GEMM, "
+                                  "v_mfma_f64_16x16x4_f64; the 8-wave form for launches of <= 3500 tiles)",
                         "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
                         "measured_in": "this run (HIP events around each launch on the launch stream)",
                         "flops_per_launch": flops / max(launches, 1),
                         "launch_ms": round(st["update_avg_ms"], 4), "launches_per_eval": launches,
                         "pipe_busy_frac_pmc": None,
-                        "pipe_busy_source": "NOT measured in this run: profiles/r02_update_kernel_mfma_util.json "
-                                            "(SQ_VALU_MFMA_BUSY_CYCLES over SIMD cycles, all 39 launches, plain schedule); "
-                                            "bare-instruction probes in profiles/r02_mfma_f64_probe.json",
+                        "pipe_busy_source": "NOT measured in this run: profiles/r03_update_kernel_mfma_util.json "
+                                            "(SQ_VALU_MFMA_BUSY_CYCLES over SIMD cycles, all 39 launches; rocprofv3 --pmc "
+                                            "serialises kernels, so that pass runs the plain schedule -- the kernels and their "
+                                            "per-launch traffic are the same); bare-instruction probes in "
+                                            "profiles/r02_mfma_f64_probe.json",
                         "traffic": None}
             mu = os.path.join(ROOT, "profiles", MFMA_UTIL_PROFILE)
             if n == 10000 and os.path.exists(mu):

@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r3_tests.log 2>&1
+echo "tests rc=$?"; tail -3 gpurun_out/r3_tests.log
+timeout -k 10 300 python bench.py > gpurun_out/r3_bench.log 2>&1
+echo "bench rc=$?"; tail -1 gpurun_out/r3_bench.log | cut -c1-900

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 passes of tools/r2_pmc.sh (gpurun_out/r2_pmc_*/p_counter_collection.csv,
-gpurun_out/r2_prof_trace) into the committed profiles/r02_*.json / .csv files."""
+"""Summarise the rocprofv3 passes of tools/r3_pmc.sh (gpurun_out/r3_pmc_*/p_counter_collection.csv,
+gpurun_out/r3_prof_trace) into the committed profiles/r03_*.json / .csv files.
+    python tools/summarize_pmc.py [run-prefix r3] [profile-prefix r03]"""
 import csv
 import json
 import os
@@ -9,6 +10,8 @@ import subprocess
 import sys
 from collections import defaultdict
 
+RUN = sys.argv[1] if len(sys.argv) > 1 else "r3"
+OUT = sys.argv[2] if len(sys.argv) > 2 else "r03"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(R, "gpurun_out")
 P = os.path.join(R, "profiles")
@@ -16,7 +19,7 @@ commit = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], captur
 
 
 def load(i):
-    rows = list(csv.DictReader(open(os.path.join(G, "r2_pmc_%d" % i, "p_counter_collection.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(G, "%s_pmc_%d" % (RUN, i), "p_counter_collection.csv"))))
     per = defaultdict(dict)      # dispatch -> {counter: value, name, dur}
     for r in rows:
         d = per[int(r["Dispatch_Id"])]
@@ -31,10 +34,15 @@ def last_eval(disp, key):
     """dispatches of the last complete evaluation (from its pair_sym kernel to the next)"""
     idx = [i for i, d in enumerate(disp) if "pair_sym" in d["name"]]
     s, e = idx[-2], idx[-1]
-    return [d for d in disp[s:e] if key in d["name"]]
+    return [d for d in disp[s:e] if (key(d["name"]) if callable(key) else key in d["name"])]
 
 
-shutil.copy(os.path.join(G, "r2_prof_trace", "t_kernel_stats.csv"), os.path.join(P, "r02_bench_n10000_kernel_stats.csv"))
+def trailing(name):
+    """the trailing-update launches: role 0 of update_kernel, 4- or 8-wave instantiation"""
+    return "update_kernel<64," in name and (", 0, false" in name or name.rstrip().endswith("<64, 8, 0>") or "<64, 8, 0>" in name)
+
+
+shutil.copy(os.path.join(G, "%s_prof_trace" % RUN, "t_kernel_stats.csv"), os.path.join(P, "%s_bench_n10000_kernel_stats.csv" % OUT))
 
 # ---- assembly kernel (pair_sym): VALU counters ---------------------------------------------------
 a1 = last_eval(load(1), "pair_sym")[0]
@@ -43,7 +51,7 @@ pairs = 10000 * 10001 / 2.0
 clock = a1["GRBM_GUI_ACTIVE"] / 8.0 / (a1["dur_us"] * 1e-6) / 1e9
 out = {
     "kernel": "cocons::pair_sym_kernel<0, false> (general-nu Bessel-K assembly), n = 10000, range 0.05",
-    "commit": commit, "command": "tools/r2_pmc.sh (rocprofv3 --pmc, COCONS_ENGINE=0, bench.py --steps 3)",
+    "commit": commit, "command": "tools/%s_pmc.sh (rocprofv3 --pmc, COCONS_ENGINE=0, bench.py --steps 3)" % RUN,
     "duration_us": a1["dur_us"], "pairs": pairs, "pairs_per_s": pairs / (a1["dur_us"] * 1e-6),
     "counters": {k: v for k, v in {**a1, **a2}.items() if k not in ("name", "dur_us", "grid")},
     "valu_wave_instructions_per_pair": a1["SQ_INSTS_VALU"] * 64.0 / pairs / 64.0 * 1.0,
@@ -56,18 +64,18 @@ out = {
     "clock_GHz_from_GRBM_GUI_ACTIVE": clock,
     "hbm_write_GBps": 8.0 * pairs / (a1["dur_us"] * 1e-6) / 1e9,
 }
-json.dump(out, open(os.path.join(P, "r02_pair_sym_valu.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(P, "%s_pair_sym_valu.json" % OUT), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
 
 # ---- update kernel: MFMA busy, LDS, HBM traffic ---------------------------------------------------
-u3 = last_eval(load(3), "update_kernel<64, 8, 0>")
-fe = last_eval(load(4), "update_kernel<64, 8, 0>")
-wr = last_eval(load(5), "update_kernel<64, 8, 0>")
-tc = last_eval(load(6), "update_kernel<64, 8, 0>")
+u3 = last_eval(load(3), trailing)
+fe = last_eval(load(4), trailing)
+wr = last_eval(load(5), trailing)
+tc = last_eval(load(6), trailing)
 tot = lambda L, k: sum(d[k] for d in L)
 mf = {
-    "kernel": "cocons::update_kernel<64, 8, 0> (trailing update), 39 launches of one evaluation at n = 10000",
-    "commit": commit, "command": "tools/r2_pmc.sh pass 3",
+    "kernel": "cocons::update_kernel<64, {8,16}, 0, false, {4,8}> (trailing update), 39 launches of one evaluation at n = 10000",
+    "commit": commit, "command": "tools/%s_pmc.sh pass 3" % RUN,
     "mfma_busy_over_simd_cycles_all_launches": tot(u3, "SQ_VALU_MFMA_BUSY_CYCLES") / (tot(u3, "GRBM_GUI_ACTIVE") / 8.0 * 1024.0),
     "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)",
     "mfma_instructions_per_eval": tot(u3, "SQ_INSTS_MFMA"),
@@ -76,13 +84,13 @@ mf = {
     "first_launches": [{"dur_us": d["dur_us"], "mfma_busy_frac": d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
                         "clock_GHz": d["GRBM_GUI_ACTIVE"] / 8.0 / (d["dur_us"] * 1e-6) / 1e9} for d in u3[:4]],
 }
-json.dump(mf, open(os.path.join(P, "r02_update_kernel_mfma_util.json"), "w"), indent=1)
+json.dump(mf, open(os.path.join(P, "%s_update_kernel_mfma_util.json" % OUT), "w"), indent=1)
 print(json.dumps(mf, indent=1)[:1200])
 fetch_kb, write_kb = tot(fe, "FETCH_SIZE"), tot(wr, "WRITE_SIZE")
 n_l = len(fe)
 alg_c = 5.3e9
 tr = {
-    "kernel": "cocons::update_kernel<64, 8, 0> (trailing launches, K = 256), n = 10000", "commit": commit,
+    "kernel": "cocons::update_kernel<64, {8,16}, 0, false, {4,8}> (trailing launches, K = 256), n = 10000", "commit": commit,
     "launches_per_eval": n_l,
     "FETCH_SIZE_KB_per_eval_raw": fetch_kb, "WRITE_SIZE_KB_per_eval": write_kb,
     "l2_hit_rate": tot(tc, "TCC_HIT_sum") / max(tot(tc, "TCC_HIT_sum") + tot(tc, "TCC_MISS_sum"), 1.0),
@@ -95,5 +103,5 @@ tr = {
             "and its operand reads are 16 B/lane, so the true read volume lies between raw (low) and 2 x raw (high); "
             "`hbm_bytes_per_launch` is the uncorrected sum.  WRITE_SIZE equals the algorithmic C write.",
 }
-json.dump(tr, open(os.path.join(P, "r02_update_kernel_hbm_traffic.json"), "w"), indent=1)
+json.dump(tr, open(os.path.join(P, "%s_update_kernel_hbm_traffic.json" % OUT), "w"), indent=1)
 print(json.dumps(tr, indent=1))
