@@ -350,7 +350,7 @@ matern_points_kernel(int n, const double *nu, const double *x, double *out)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double u = x[i], v = nu[i];
-    out[i] = (u < 706.0) ? matern_bessel(v, u) : matern_asymptotic(v, u);
+    out[i] = matern_bessel(v, u);
 }
 
 void launch_matern_points(int n, const double *nu, const double *x, double *out, hipStream_t s)

@@ -61,6 +61,39 @@ __device__ __forceinline__ double fast_rcp(double x)
     return r;
 }
 
+// 2^a e^-u for |a| < 1000, 0 <= u < 1100, in ONE exponential: u = n_u ln 2 + r (Cody-Waite, r exact to ~1e-17), a = n_a + f_a
+// (exact), so 2^a e^-u = 2^(n_a - n_u + k) 2^g with g = f_a - r log2(e) - k in [-1/2, 1/2]; 2^g = e^(g ln 2) by its Taylor series
+// to degree 14 (|g ln 2| <= 0.347: truncation 1e-19).  Relative error ~4e-16; replaces exp2(a) * exp(-u) (two library
+// calls, ~60 instructions) by ~30.
+__device__ __forceinline__ double pow2a_expmu(double a, double u)
+{
+    const double L2E = 1.4426950408889634074, LN2 = 0.6931471805599453094;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double nu_ = rint(u * L2E);
+    double r = fma(-nu_, LN2_HI, u);
+    r = fma(-nu_, LN2_LO, r);
+    const double na = rint(a);
+    const double f = fma(-r, L2E, a - na);
+    const double k = rint(f);
+    const double t = (f - k) * LN2;
+    double p = 1.0 / 87178291200.0;                   // 1/14!
+    p = fma(p, t, 1.0 / 6227020800.0);
+    p = fma(p, t, 1.0 / 479001600.0);
+    p = fma(p, t, 1.0 / 39916800.0);
+    p = fma(p, t, 1.0 / 3628800.0);
+    p = fma(p, t, 1.0 / 362880.0);
+    p = fma(p, t, 1.0 / 40320.0);
+    p = fma(p, t, 1.0 / 5040.0);
+    p = fma(p, t, 1.0 / 720.0);
+    p = fma(p, t, 1.0 / 120.0);
+    p = fma(p, t, 1.0 / 24.0);
+    p = fma(p, t, 1.0 / 6.0);
+    p = fma(p, t, 0.5);
+    p = fma(p, t, 1.0);
+    p = fma(p, t, 1.0);
+    return ldexp(p, (int)(na - nu_ + k));
+}
+
 __constant__ double c_inv_k[64] = {
     0.0, 1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10, 1.0 / 11, 1.0 / 12,
     1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16, 1.0 / 17, 1.0 / 18, 1.0 / 19, 1.0 / 20, 1.0 / 21, 1.0 / 22, 1.0 / 23,
@@ -72,7 +105,7 @@ __constant__ double c_inv_k[64] = {
 constexpr double HANKEL_U0 = 20.0;
 constexpr int HANKEL_TERMS = 20;
 
-// 2^(1-nu)/Gamma(nu) * u^nu * K_nu(u), 0 < u < 706
+// 2^(1-nu)/Gamma(nu) * u^nu * K_nu(u) for 0 < u < 706; for u >= 706 the reference's asymptotic stand-in (see below)
 __device__ __noinline__ double matern_bessel(double nu, double u)
 {
     const double tol = 2.220446049250313e-16;
@@ -90,7 +123,10 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
     double gammi = gam2 + mu * gam1;   // 1/Gamma(1-mu)
     // (nu <= 3.5: what the 20 terms are validated for -- at u = 20 the truncation error grows to 1e-14 at nu = 8 and
     // 1e-12 at nu = 15; smooth_limits come from the user, so larger orders keep the continued fraction)
-    if (u >= HANKEL_U0 && nu <= 3.5) {
+    // u >= 706: the reference switches to the LEADING term of this very series, sqrt(pi / 2u) e^-u, for every nu
+    // (src/cocons_full.cpp:301-305; values below 1e-300 that underflow to zero near u = 745) -- the same code with S = 1
+    // instead of a pow / tgamma / exp chain of library calls (range 0.02 at n = 10^4: 2.0 -> 1.3 ms assembly)
+    if (u >= HANKEL_U0 && (nu <= 3.5 || u >= 706.0)) {
         // Large arguments: Hankel's asymptotic series  K_nu(u) ~ sqrt(pi / 2u) e^-u sum_k a_k(nu) / u^k,
         // a_k = prod_{j<=k} (4 nu^2 - (2j-1)^2) / (8 j), directly at order nu (no recurrence from mu).  For
         // u >= 20 and nu <= 3.5 twenty terms leave a truncation error below 1.5e-16 (checked against mpmath over
@@ -105,12 +141,13 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
             t *= fma(p4, Ak, -Bk * w);
             S += t;
         }
+        if (u >= 706.0) S = 1.0;
         double rg = (n == 0) ? mu * gampl : gampl;
         double prod = 1.0;
         for (int k = 1; k < n; ++k) prod *= (mu + k);
-        rg = rg / prod;
-        // 2^(1-nu) u^nu sqrt(pi / 2u) = sqrt(pi/2) 2^((nu - 1/2) log2 u + 1 - nu)
-        return 1.2533141373155002512 * exp2(fma(nu - 0.5, log2(u), 1.0 - nu)) * exp(-u) * rg * S;
+        rg = rg * fast_rcp(prod);
+        // 2^(1-nu) u^nu sqrt(pi / 2u) e^-u = sqrt(pi/2) 2^((nu - 1/2) log2 u + 1 - nu) e^-u: one exponential
+        return 1.2533141373155002512 * pow2a_expmu(fma(nu - 0.5, log2(u), 1.0 - nu), u) * rg * S;
     }
     double kmu, kmu1;                  // K_mu, K_{mu+1}, both WITHOUT the factor exp(-u) when u > 2
     double escale;                     // the factor still to be applied: exp(-u) (CF2) or 1 (Temme)
@@ -167,7 +204,7 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         }
         kmu = sqrt(pi / (2.0 * u)) / S;
         kmu1 = kmu * (0.5 + mu + u + (mu2 - 0.25) * f) / u;
-        escale = exp(-u);
+        escale = 0.0;                  // marks: exp(-u) still to be applied (folded into the final power of two)
     }
     // forward recurrence to order nu, and 1/Gamma(nu) = gampl / prod_{k=1}^{n-1} (mu+k)
     double rg = (n == 0) ? mu * gampl : gampl;
@@ -180,16 +217,10 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         ck = next;
         if (k < n) prod *= (mu + k);
     }
-    rg = rg / prod;
-    // 2^(1-nu) u^nu = 2^(nu log2 u + 1 - nu): the exponent stays O(25), so its rounding is harmless
-    return exp2(fma(nu, log2(u), 1.0 - nu)) * escale * rg * pk;
-}
-
-// asymptotic branch of the reference for u >= 706 (src/cocons_full.cpp:301-305)
-__device__ __noinline__ double matern_asymptotic(double smtns, double u)
-{
-    return pow(2.0, -(smtns - 1)) / tgamma(smtns) * pow(u, smtns) *
-           sqrt(3.14159265358979323846 / (2.0 * u)) * exp(-u);
+    rg = rg * fast_rcp(prod);
+    // 2^(1-nu) u^nu = 2^(nu log2 u + 1 - nu): the exponent stays O(25), so its rounding is harmless; times e^-u on the CF2 side
+    const double ex = fma(nu, log2(u), 1.0 - nu);
+    return (escale == 0.0 ? pow2a_expmu(ex, u) : exp2(ex)) * rg * pk;
 }
 
 // Value of one covariance entry from the per-location SoA; ia = first ("ii") location,
@@ -205,6 +236,7 @@ __device__ __forceinline__ double pair_value_idx(const double *base_a, size_t sa
                                                  double gr, double nu_fixed, bool coincident_check)
 {
     const double epsilon = 2.220446049250313e-16;
+    const double rgr = 1.0 / gr;                        // (wave-uniform: once per kernel)
     const double *pa = base_a + ia, *pb = base_b + ib;
     double ax = pa[0], ay = pa[sa], bx = pb[0], by = pb[sb];
     if (coincident_check && ax == bx && ay == by) return pa[11 * sa];    // cocons_full.cpp:410-414
@@ -219,20 +251,25 @@ __device__ __forceinline__ double pair_value_idx(const double *base_a, size_t sa
     if (MODE == MODE_GEOM) smtns = pa[10 * sa] * pb[10 * sb];
     else if (MODE == MODE_MEAN) smtns = (pa[10 * sa] + pb[10 * sb]) / 2;
     else smtns = nu_fixed;
-    double u = sqrt(8 * smtns / (gr * det)) *
-               sqrt(fma(kahan(s22, dx * dx, -s11, dy * dy), 1.0, -2 * s12 * dx * dy));
+    // u = sqrt(8 nu / (gr det)) sqrt(q) as ONE square root over ONE reciprocal of det (the reference takes two roots and a
+    // division, :140-141; the same reciprocal serves the normalisation below): u moves by a few ulp, M(u) by u times that --
+    // below 3e-13 at u = 700, inside the entrywise tolerance of 2e-12
+    const double rdet = fast_rcp(det);
+    double u = sqrt((8 * smtns) * (rgr * rdet) *
+                    fma(kahan(s22, dx * dx, -s11, dy * dy), 1.0, -2 * s12 * dx * dy));
     if (u <= epsilon) return pa[11 * sa];
     double m;
     if (MODE == MODE_HALF) m = exp(-u);
     else if (MODE == MODE_THREEHALF) m = (1 + u) * exp(-u);
     else if (MODE == MODE_FIVEHALF) m = (1 + u + u * u / 3) * exp(-u);
-    else m = (u < 706.0) ? matern_bessel(smtns, u) : matern_asymptotic(smtns, u);
+    else m = matern_bessel(smtns, u);
     // stage 2: amplitude (fields reloaded, see above)
     asm volatile("" : "+v"(ia), "+v"(ib));
     pa = base_a + ia;
     pb = base_b + ib;
-    double amp = sqrt(pa[8 * sa] * pb[7 * sb] * pb[6 * sb]);
-    return m * pa[9 * sa] * pb[9 * sb] * amp / sqrt(det);
+    // (1 / det is formed again rather than kept across the Bessel call: one more live value there spills)
+    double amp = sqrt(pa[8 * sa] * pb[7 * sb] * pb[6 * sb] * fast_rcp(det));      // sqrt(dets_i sin t_i dets_j sin t_j / det)
+    return m * pa[9 * sa] * pb[9 * sb] * amp;
 }
 
 // One entry of the sparse/taper covariance (src/cocons_taper.cpp:229-262 and its copies, :86-129):
@@ -261,7 +298,7 @@ __device__ __forceinline__ double taper_value_idx(const double *base_a, size_t s
     if (MODE == MODE_HALF) m = exp(-u);
     else if (MODE == MODE_THREEHALF) m = (1 + u) * exp(-u);
     else if (MODE == MODE_FIVEHALF) m = (1 + u + u * u / 3) * exp(-u);
-    else m = (u < 706.0) ? matern_bessel(smtns, u) : matern_asymptotic(smtns, u);
+    else m = matern_bessel(smtns, u);
     return prefactor * m * si * pb[9 * sb];
 }
 

@@ -821,6 +821,29 @@ def test_device_matern_large_argument_branch_vs_mpmath():
     assert rel.max() < 1e-13, (rel.max(), nu[ok][rel.argmax()], u[ok][rel.argmax()])
 
 
+def test_device_matern_asymptotic_stand_in_vs_mpmath():
+    """u >= 706: the reference replaces K_nu by its leading asymptotic term, 2^(1-nu)/Gamma(nu) u^nu sqrt(pi/2u) e^-u
+    (src/cocons_full.cpp:301-305).  The device routine forms it with its own exponential and reciprocal-gamma table, not
+    with pow / tgamma: against 40-digit mpmath where the value is still a normal double."""
+    import mpmath as mp
+    from cocons_amd import _lib
+    mp.mp.dps = 40
+    rng = np.random.default_rng(79)
+    nu = np.concatenate([rng.uniform(0.25, 3.5, 200), rng.uniform(3.5, 12.0, 50)])
+    u = np.concatenate([rng.uniform(706.0, 712.0, 240), [706.0, 706.0000001, 720.5, 730.0, 744.0, 760.0, 800.0, 1500.0, 900.0, 708.0]])
+    want = np.array([float(mp.power(2, 1 - mp.mpf(a)) / mp.gamma(mp.mpf(a)) * mp.power(mp.mpf(b), mp.mpf(a)) *
+                           mp.sqrt(mp.pi / (2 * mp.mpf(b))) * mp.exp(-mp.mpf(b))) for a, b in zip(nu, u)])
+    out = np.empty_like(u)
+    L = _lib.load()
+    _lib.check(L.cocons_debug_matern(u.size, nu.ctypes.data_as(_lib.c_dp), u.ctypes.data_as(_lib.c_dp),
+                                     out.ctypes.data_as(_lib.c_dp)), "cocons_debug_matern")
+    ok = want > 1e-305                                          # comfortably normal doubles
+    assert ok.sum() > 100
+    rel = np.abs(out[ok] - want[ok]) / want[ok]
+    assert rel.max() < 1e-12, (rel.max(), nu[ok][rel.argmax()], u[ok][rel.argmax()])
+    assert np.all(np.isfinite(out)) and np.all(out[~ok] <= 1e-304)          # underflow: tiny or zero, never NaN
+
+
 def test_device_matern_large_orders_vs_mpmath():
     """Orders beyond what the Hankel branch is validated for (nu > 3.5; smooth_limits are the user's) stay on the
     continued fraction for every u: against 40-digit mpmath at nu up to 15, u from 2 to 300."""
