@@ -237,19 +237,23 @@ __device__ __forceinline__ double pair_value_idx(const double *base_a, size_t sa
 {
     const double epsilon = 2.220446049250313e-16;
     const double rgr = 1.0 / gr;                        // (wave-uniform: once per kernel)
-    const double *pa = base_a + ia, *pb = base_b + ib;
-    double ax = pa[0], ay = pa[sa], bx = pb[0], by = pb[sb];
-    if (coincident_check && ax == bx && ay == by) return pa[11 * sa];    // cocons_full.cpp:410-414
-    double ard = pa[2 * sa], aan2 = pa[3 * sa], ara = pa[4 * sa], act = pa[5 * sa];
-    double brd = pb[2 * sb], ban2 = pb[3 * sb], bra = pb[4 * sb], bct = pb[5 * sb];
+    // field f of location i: a wave-uniform base (base + f * stride: scalar registers) plus ONE 32-bit byte offset per
+    // side -- per-lane 64-bit pointer arithmetic for every field was a twentieth of the kernel's instructions
+#define FA(f) (*(const double *)((const char *)(base_a + (size_t)(f) * sa) + oa))
+#define FB(f) (*(const double *)((const char *)(base_b + (size_t)(f) * sb) + ob))
+    unsigned oa = 8u * (unsigned)ia, ob = 8u * (unsigned)ib;
+    double ax = FA(0), ay = FA(1), bx = FB(0), by = FB(1);
+    if (coincident_check && ax == bx && ay == by) return FA(11);    // cocons_full.cpp:410-414
+    double ard = FA(2), aan2 = FA(3), ara = FA(4), act = FA(5);
+    double brd = FB(2), ban2 = FB(3), bra = FB(4), bct = FB(5);
     double s11 = (ard + brd) * 0.5;
     double s22 = kahan(ard, aan2, -brd, ban2) * 0.5;
     double s12 = kahan(ara, act, -bra, bct) * 0.5;
     double det = kahan(s11, s22, s12, s12);
     double dx = ax - bx, dy = ay - by;
     double smtns;
-    if (MODE == MODE_GEOM) smtns = pa[10 * sa] * pb[10 * sb];
-    else if (MODE == MODE_MEAN) smtns = (pa[10 * sa] + pb[10 * sb]) / 2;
+    if (MODE == MODE_GEOM) smtns = FA(10) * FB(10);
+    else if (MODE == MODE_MEAN) smtns = (FA(10) + FB(10)) / 2;
     else smtns = nu_fixed;
     // u = sqrt(8 nu / (gr det)) sqrt(q) as ONE square root over ONE reciprocal of det (the reference takes two roots and a
     // division, :140-141; the same reciprocal serves the normalisation below): u moves by a few ulp, M(u) by u times that --
@@ -257,19 +261,19 @@ __device__ __forceinline__ double pair_value_idx(const double *base_a, size_t sa
     const double rdet = fast_rcp(det);
     double u = sqrt((8 * smtns) * (rgr * rdet) *
                     fma(kahan(s22, dx * dx, -s11, dy * dy), 1.0, -2 * s12 * dx * dy));
-    if (u <= epsilon) return pa[11 * sa];
+    if (u <= epsilon) return FA(11);
     double m;
     if (MODE == MODE_HALF) m = exp(-u);
     else if (MODE == MODE_THREEHALF) m = (1 + u) * exp(-u);
     else if (MODE == MODE_FIVEHALF) m = (1 + u + u * u / 3) * exp(-u);
     else m = matern_bessel(smtns, u);
     // stage 2: amplitude (fields reloaded, see above)
-    asm volatile("" : "+v"(ia), "+v"(ib));
-    pa = base_a + ia;
-    pb = base_b + ib;
+    asm volatile("" : "+v"(oa), "+v"(ob));
     // (1 / det is formed again rather than kept across the Bessel call: one more live value there spills)
-    double amp = sqrt(pa[8 * sa] * pb[7 * sb] * pb[6 * sb] * fast_rcp(det));      // sqrt(dets_i sin t_i dets_j sin t_j / det)
-    return m * pa[9 * sa] * pb[9 * sb] * amp;
+    double amp = sqrt(FA(8) * FB(8) * fast_rcp(det));      // sqrt(dets_i sin t_i dets_j sin t_j / det), field 8 = dets sin t
+    return m * FA(9) * FB(9) * amp;
+#undef FA
+#undef FB
 }
 
 // One entry of the sparse/taper covariance (src/cocons_taper.cpp:229-262 and its copies, :86-129):
