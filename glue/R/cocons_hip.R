@@ -103,6 +103,17 @@ GetNeg2loglikelihoodREML <- function(theta, par.pos, locs, x_covariates, x_betas
 cocons_hip_multi <- function(locs, x_covariates, z, smooth.limits, devices)
   .Call(`_cocons_hip_multi_create`, locs, x_covariates, as.matrix(z), as.double(smooth.limits), as.integer(devices))
 
+# replica mode inside ONE R process: a list of parameter points (the 2p+1 points of a finite-difference gradient,
+# R/optim.R:256-259, or getHessian's grid, R/getFunctions.R:979-1016) dealt over the GPUs of a multi handle
+cocons_hip_multi_neg2loglik_batch <- function(m, theta_lists) {
+  res <- .Call(`_cocons_hip_multi_neg2loglik_batch`, m, lapply(theta_lists, function(th) th[-1]),
+               lapply(theta_lists, function(th) th$mean))
+  ifelse(res[[1]] > 0L, 1e+06, res[[2]])
+}
+
+# c(active, time-outs, last abort code) of the resident diagonal-block engine of a fit handle (diagnostic)
+cocons_hip_engine_state <- function(fit) .Call(`_cocons_hip_engine_state`, fit)
+
 # cocoPredict's dense core with the prediction locations split over the GPUs of a multi handle (config C5)
 cocons_hip_multi_predict <- function(m, theta_list, newlocs, X_pred, z_col = 1L) {
   res <- .Call(`_cocons_hip_multi_predict`, m, theta_list[-1], theta_list$mean, as.integer(z_col), newlocs, X_pred)

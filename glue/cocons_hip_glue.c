@@ -407,6 +407,37 @@ SEXP _cocons_hip_multi_neg2loglik(SEXP mp, SEXP theta, SEXP mean)
     return status_value(rc, Rf_ScalarReal(val));
 }
 
+/* replica mode for ONE R process: the points of a finite-difference gradient (R/optim.R:256-259) or of
+ * getHessian (R/getFunctions.R:979-1016) dealt over the handle's GPUs; arguments and result as _cocons_hip_neg2loglik_batch */
+SEXP _cocons_hip_multi_neg2loglik_batch(SEXP mp, SEXP thetas, SEXP means)
+{
+    cocons_multi *m = (cocons_multi *)R_ExternalPtrAddr(mp);
+    if (!m) Rf_error("cocons multi-GPU handle is NULL");
+    const int p = fit_p(mp), nb = (int)XLENGTH(thetas);
+    double *T = (double *)R_alloc((size_t)(nb > 0 ? nb : 1) * 6 * p, sizeof(double));
+    double *M = (double *)R_alloc((size_t)(nb > 0 ? nb : 1) * p, sizeof(double));
+    for (int i = 0; i < nb; ++i) {
+        theta_table(VECTOR_ELT(thetas, i), p, T + (size_t)i * 6 * p);
+        memcpy(M + (size_t)i * p, Rf_isMatrix(means) ? REAL(means) + (size_t)i * p : REAL(VECTOR_ELT(means, i)),
+               (size_t)p * sizeof(double));
+    }
+    SEXP st = PROTECT(Rf_allocVector(INTSXP, nb)), val = PROTECT(Rf_allocVector(REALSXP, nb));
+    hip_check(cocons_multi_neg2loglik_batch(m, nb, T, M, REAL(val), INTEGER(st)), "GetNeg2loglikelihood (multi-GPU batch)");
+    SEXP out = status_value(0, val);
+    SET_VECTOR_ELT(out, 0, st);
+    UNPROTECT(2);
+    return out;
+}
+
+/* c(engine active, hand-off time-outs so far, abort code of the last one) of a fit handle: cocons_fit_engine_state */
+SEXP _cocons_hip_engine_state(SEXP fitp)
+{
+    SEXP out = PROTECT(Rf_allocVector(INTSXP, 3));
+    hip_check(cocons_fit_engine_state(fit_of(fitp), INTEGER(out)), "engine state");
+    UNPROTECT(1);
+    return out;
+}
+
 /* dense kriging core with the prediction locations split over the handle's GPUs: list(status, cbind(stochastic, quadform)) */
 SEXP _cocons_hip_multi_predict(SEXP mp, SEXP theta, SEXP mean, SEXP z_col, SEXP locs_pred, SEXP X_pred)
 {
@@ -472,6 +503,8 @@ static const R_CallMethodDef CallEntries[] = {
     {"_cocons_hip_multi_create", (DL_FUNC)&_cocons_hip_multi_create, 5},
     {"_cocons_hip_multi_neg2loglik", (DL_FUNC)&_cocons_hip_multi_neg2loglik, 3},
     {"_cocons_hip_multi_predict", (DL_FUNC)&_cocons_hip_multi_predict, 6},
+    {"_cocons_hip_multi_neg2loglik_batch", (DL_FUNC)&_cocons_hip_multi_neg2loglik_batch, 3},
+    {"_cocons_hip_engine_state", (DL_FUNC)&_cocons_hip_engine_state, 1},
     {NULL, NULL, 0}
 };
 
