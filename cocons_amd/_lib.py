@@ -84,6 +84,7 @@ SIGNATURES = {
     "cocons_shard_panel_apply_range": (c_int, [c_vp, c_int, c_int, c_int]),
     "cocons_shard_finish": (c_int, [c_vp, c_dp, ctypes.POINTER(c_int)]),
     "cocons_shard_num_panels": (c_int, [c_vp]),
+    "cocons_shard_panel_owner": (c_int, [c_int, c_int]),
     "cocons_shard_exchange_bytes": (ctypes.c_longlong, [c_vp]),
     "cocons_shard_set_exchange": (c_int, [c_vp, c_vp, c_vp, ctypes.c_longlong]),
     "cocons_fit_stream": (c_vp, [c_vp]),

@@ -233,6 +233,9 @@ struct cocons_fit {
     double *dA;
     double *dinv;            // 2 x 8 x 256
     double *dwinv;           // 2 x 128 x 128: the engine's W = L^-1 of the two current diagonal tiles (launch_panel's operand)
+    double *dwfull = nullptr, *dwT = nullptr;   // panel mode 3: inverse of the current 256 x 256 block factor; scratch (launch_potrf_engine)
+    double *dpin = nullptr;  // panel mode 3: scratch panel, lda x 256 (launch_panel_gemm's input), allocated on first use
+    size_t pin_cap = 0;
     int *dinfo;
     double *dout;            // reductions
     double *hout;            // pinned mirror
@@ -260,6 +263,7 @@ struct cocons_fit {
     bool engine_ok;               // false: this handle never uses the resident engine (batch slots, band-limited taper fits)
     bool engine_live;             // the engine of the NEXT factorize call is already launched (engine_start)
     bool engine_used;             // the factorisation enqueued last runs on the engine schedule
+    bool engine_w3 = false;       // ... and its engine publishes whole-block inverses (panel mode 3)
     bool engine_active_last;      // the last COMPLETED operation ran on the engine schedule (cocons_fit_engine_state)
     int engine_skip;              // operations still to run on the plain schedule after a hand-off timed out (back-off)
     int engine_fails;             // consecutive time-outs (the back-off doubles with each, up to 64 operations)
@@ -331,6 +335,9 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->stream3) hipStreamSynchronize(f->stream3);
         hipFree(f->dX); hipFree(f->dlocs); hipFree(f->dz); hipFree(f->dxb); hipFree(f->dloc);
         hipFree(f->dA); hipFree(f->dinv); hipFree(f->dwinv); hipFree(f->dinfo); hipFree(f->dout);
+        if (f->dwfull) hipFree(f->dwfull);
+        if (f->dwT) hipFree(f->dwT);
+        if (f->dpin) hipFree(f->dpin);
         hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad); hipFree(f->dred);
         if (f->xbuf_own) { hipFree(f->xbuf[0]); hipFree(f->xbuf[1]); }
         hipHostFree(f->hout); hipHostFree(f->hinfo);
@@ -859,7 +866,7 @@ static Tunables &tun()
         rd("COCONS_PANEL_OVERLAP", t.overlap);
         rd("COCONS_UPD_DYNAMIC", t.upd_dynamic);
         rd("COCONS_ENGINE_FUSED", t.engine_fused);
-        if (t.panel_mode < 0 || t.panel_mode > 2) t.panel_mode = 0;
+        if (t.panel_mode < 0 || t.panel_mode > 3) t.panel_mode = 0;
         t.init = true;
     }
     return t;
@@ -892,7 +899,8 @@ static bool engine_enabled() { return tun().engine != 0; }
 // bracketed by timing events (profile runs): appended as (start, stop)
 static bool timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int t0, int t1, hipStream_t s,
                          std::vector<hipEvent_t> *ev_upd, unsigned *sig, int sig_tile, unsigned *queue = nullptr,
-                         unsigned *near = nullptr, int near_tiles = 0, const UpdStrips *strips = nullptr)
+                         unsigned *near = nullptr, int near_tiles = 0, const UpdStrips *strips = nullptr,
+                         const UpdRedirect *redir = nullptr)
 {
     const int mt = v.mt;
     if (t1 <= t0) return false;
@@ -906,7 +914,7 @@ static bool timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int 
         hipEventRecord(a, s);
     }
     const bool took = launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, abort_word,
-                                    queue, hb, v.nt, near, near_tiles, strips);
+                                    queue, hb, v.nt, near, near_tiles, strips, 0, redir);
     if (ev_upd) {
         hipEventRecord(b, s);
         ev_upd->push_back(a); ev_upd->push_back(b);
@@ -961,16 +969,21 @@ static unsigned *tile_queue(cocons_fit *f, int k)
 //   0 (default) = three launches behind the trailing update: solve | in-panel update | solve;
 //   1 = one launch of GEMMs with the engine's tile inverses (launch_panel) behind the trailing update;
 //   2 = the same GEMMs as TASKS of the trailing update that precedes them (launch_update's strips);
-//   modes 1 and 2 only for the blocks whose update is long enough to hide the engine's longer chain (COCONS_STRIP_MIN far
+//   3 = ONE tile-parallel product with the inverse of the whole 256 x 256 block factor (launch_panel_gemm), its input taken
+//       from a scratch panel that the preceding trailing update fills (UpdRedirect);
+//   modes 1, 2 and 3 only for the blocks whose update is long enough to hide the engine's longer chain (COCONS_STRIP_MIN far
 //   tiles), mode 0 for the later, short blocks.  Measured in alternation in one process at n = 10^4 (tools/ab_modes.py):
 //   mode 1 = mode 0 within 0.1 %, mode 2 +0.4 ... +1.4 % -- but mode 2 puts the panel's time into the update launches
-//   (their sum grows from 7.0 to 7.6 ms), so the default stays the schedule whose launches are what their name says.
+//   (their sum grows from 7.0 to 7.6 ms); mode 3 +1.0 ... +1.4 % in turns of 10 evaluations (the panel takes 26-36 us
+//   instead of ~50, one launch boundary less), but in turns of 300 evaluations +0.5 / -0.9 %: the updates and the NEXT
+//   evaluation's assembly behind the shorter pauses run 1-5 % longer -- the chip is power-limited and in the steady state
+//   an evaluation costs its energy, not its critical path.  So the default stays the plain trio.
 static int panel_mode()
 {
     int v = tun().panel_mode;
     static int m4 = -1;                                        // the alternative update kernel knows no strips
     if (m4 < 0) { const char *e = getenv("COCONS_UPD_MFMA4"); m4 = e ? atoi(e) : 0; }
-    if (m4 != 0 && v == 2) v = 0;
+    if (m4 != 0 && v >= 2) v = 0;
     return v;
 }
 
@@ -995,6 +1008,25 @@ static int panel_w_until(const FactorView &v)
     return t;
 }
 
+// panel mode 3: the block-inverse buffers (zero above the diagonal, for good) and the scratch panel for leading dimension lda
+static int panel_gemm_buffers(cocons_fit *f, size_t lda)
+{
+    if (!f->dwfull) {
+        HIPCHK(hipMalloc(&f->dwfull, 4 * (size_t)TILE * TILE * sizeof(double)));
+        HIPCHK(hipMalloc(&f->dwT, (size_t)TILE * TILE * sizeof(double)));
+        HIPCHK(hipMemsetAsync(f->dwfull, 0, 4 * (size_t)TILE * TILE * sizeof(double), f->stream));
+        HIPCHK(hipMemsetAsync(f->dwT, 0, (size_t)TILE * TILE * sizeof(double), f->stream));
+    }
+    const size_t need = lda * 2 * TILE;
+    if (f->pin_cap < need) {
+        HIPCHK(hipStreamSynchronize(f->stream));
+        if (f->dpin) { HIPCHK(hipFree(f->dpin)); f->dpin = nullptr; f->pin_cap = 0; }
+        HIPCHK(hipMalloc(&f->dpin, need * sizeof(double)));
+        f->pin_cap = need;
+    }
+    return 0;
+}
+
 static int engine_start(cocons_fit *f, const FactorView &v)
 {
     if (f->engine_live) return 0;
@@ -1004,9 +1036,12 @@ static int engine_start(cocons_fit *f, const FactorView &v)
     unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
     HIPCHK(hipEventRecord(f->ev_eng, M));
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
+    const bool m3 = panel_mode() == 3 && panel_w_until(v) > 2;
+    if (m3) if (int rc = panel_gemm_buffers(f, v.lda)) return rc;
     launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
                         f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dwinv, panel_w_until(v),
-                        tun().engine_fused);
+                        tun().engine_fused, m3 ? f->dwfull : nullptr, m3 ? f->dwT : nullptr);
+    f->engine_w3 = m3;
     f->engine_live = true;
     return 0;
 }
@@ -1079,7 +1114,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     // U(k)'s tile order) P's gate opens and the panel kernels are placed as soon as U(k)'s retiring workgroups leave room --
     // in the tail of U(k), where the chip drains anyway.  U(k+2) waits for the panel's event.  COCONS_PANEL_OVERLAP=0:
     // everything in order on the main stream (the round-2 schedule).
-    const int overlap = tun().overlap;
+    const int overlap = f->engine_w3 ? 0 : tun().overlap;
     if (overlap && !f->stream3) {
         HIPCHK(hipStreamCreateWithFlags(&f->stream3, hipStreamNonBlocking));
         for (auto &e : f->ev_panel) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1096,7 +1131,15 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         const int hb = band_hi(v, t);                // rows of block t's panel: [r0, hb) and the rows under the matrix
         const int br = hb >= 0 ? hb * TILE : -1, er = nt * TILE;
         const bool with_w = t < w_until;             // the engine publishes the inverses of this block's tiles
-        if (with_w && panel_mode() == 2) {
+        if (with_w && f->engine_w3 && two && mt - t >= 3) {
+            // U(k) leaves the panel's columns below the diagonal block in the scratch panel; one product forms the panel
+            UpdRedirect rd;
+            rd.pin = f->dpin; rd.row_tile0 = r0;
+            timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), nullptr, near_tiles, nullptr, &rd);
+            launch_panel_gemm(v.A, v.lda, t, r0 * TILE, mt * TILE, f->dpin, f->dwfull, xr + t, abort_word, M);
+            continue;
+        }
+        if (with_w && panel_mode() == 2 && !f->engine_w3) {
             // the panel's strips are tasks of U(k) itself: nothing to launch behind it
             UpdStrips us;
             us.nstrips = (mt - r0) * 2; us.row0 = r0 * TILE; us.lead = strip_lead();
@@ -1108,7 +1151,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), (overlap || tun().near_force) ? near + t : nullptr,
                      near_tiles);
         if (overlap) launch_flag_gate(near + t, update_near_count(t, mt, near_tiles), abort_word, 0x700u + t, P);
-        if (with_w) {
+        if (with_w && !f->engine_w3) {
             launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, mt * TILE, f->dwinv, out, xr, abort_word, P);
         } else {
             launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, mt * TILE, f->dinv + (size_t)(t & 1) * 2048, P,
@@ -2132,8 +2175,24 @@ extern "C" int cocons_chol_solve(int n, const double *Ain, int nrhs, const doubl
 }
 
 // ---------------------------------------------------------------------------
-// column-panel sharded evaluation.  Panel = 2 tiles (256 columns); owner(k) = k % world.
+// column-panel sharded evaluation.  Panel = 2 tiles (256 columns); panels are dealt over the ranks in GROUPS of G
+// consecutive panels, owner(k) = (k / G) % world (COCONS_SHARD_GROUP, default 4).  Inside a group the owner goes on to
+// its next panel while the broadcast of the previous one is still travelling, so per panel the chain is
+// max(factor, broadcast) instead of factor + broadcast; G = 1 is the round-1/2 cyclic deal.
 static const int PT = 2;     // tiles per panel
+
+static int shard_group()
+{
+    static const int g = [] {
+        const char *e = getenv("COCONS_SHARD_GROUP");
+        int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : v;
+    }();
+    return g;
+}
+static inline int shard_owner(int k, int world) { return (k / shard_group()) % world; }
+
+extern "C" int cocons_shard_panel_owner(int k, int world) { return (k < 0 || world < 1) ? -1 : shard_owner(k, world); }
 
 extern "C" int cocons_shard_num_panels(cocons_fit *f) { return f ? (f->nt + PT - 1) / PT : -1; }
 
@@ -2180,7 +2239,8 @@ extern "C" int cocons_shard_begin(cocons_fit *f, const double *theta, const doub
     const int np = cocons_shard_num_panels(f);
     // per-location vectors are replicated; each rank assembles only its own column panels
     bool first = true;
-    for (int k = rank; k < np; k += world) {
+    for (int k = 0; k < np; ++k) {
+        if (shard_owner(k, world) != rank) continue;
         int c0 = k * PT * TILE, c1 = c0 + PT * TILE;
         if (c1 > f->npad) c1 = f->npad;
         if (first) { assemble_sigma(f, theta, 0, c0, c1); first = false; }
@@ -2260,7 +2320,7 @@ static int shard_apply_range(cocons_fit *f, int k, int j0, int j1)
     // operand pointer such that P[row + kk*rows] addresses GLOBAL row `row`
     const double *P = f->xbuf[k & 1] - (size_t)t0 * TILE;
     launch_update_from(f->dA, f->lda, P, rows, w * TILE, c0, mt, c0, c1, true, f->stream,
-                       PT, f->world, f->rank);
+                       PT * shard_group(), f->world, f->rank);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2281,10 +2341,12 @@ extern "C" int cocons_shard_finish(cocons_fit *f, double *partial, int *info)
     const int np = cocons_shard_num_panels(f);
     const int nr = f->nrhs_cur, len = 1 + nr * nr;
     int cnt = 0;
-    for (int k = f->rank; k < np; k += f->world, ++cnt) {
+    for (int k = 0; k < np; ++k) {
+        if (shard_owner(k, f->world) != f->rank) continue;
         int c0 = k * PT * TILE, c1 = c0 + PT * TILE;
         if ((size_t)(cnt + 1) * len > f->out_cap) return fail(-1, "cocons_shard_finish: reduction buffer too small");
         launch_finalize_cols(f->dA, f->lda, c0, c1, f->n, f->npad, nr, f->dout + (size_t)cnt * len, f->stream);
+        ++cnt;
     }
     if (cnt > 0)
         HIPCHK(hipMemcpyAsync(f->hout, f->dout, (size_t)cnt * len * sizeof(double), hipMemcpyDeviceToHost, f->stream));
@@ -2374,7 +2436,7 @@ static inline long long shard_panel_bytes(cocons_fit *f, int k)
 // hand panel k (already packed on the owner) to the communication stream
 static int coll_bcast_panel(cocons_fit *f, int k, bool in_group)
 {
-    const int b = k & 1, owner = k % f->coll_world;
+    const int b = k & 1, owner = shard_owner(k, f->coll_world);
     const long long bytes = shard_panel_bytes(f, k);
     HIPCHK(hipEventRecord(f->ev_main[b], f->stream));
     HIPCHK(hipStreamWaitEvent(f->cstream, f->ev_main[b], 0));
@@ -2390,12 +2452,18 @@ static int coll_bcast_panel(cocons_fit *f, int k, bool in_group)
     return 0;
 }
 
-// one rank's part of schedule step k: everything between "panel k has arrived" and "panel k is applied"
+// one rank's part of schedule step k: everything between "panel k has arrived" and "panel k is applied".
+// The owner of panel k has the packed panel in its exchange buffer already: it does not wait for its own broadcast
+// to complete before it goes on -- only for the broadcast of panel k-1, whose buffer the next pack overwrites (the
+// local readers of that buffer are earlier work of the main stream).  So inside a group of consecutive panels of one
+// owner the broadcast of k travels while k+1 is being factored.
 static int shard_step_pre(cocons_fit *f, int k, int np)
 {
-    HIPCHK(hipStreamWaitEvent(f->stream, f->ev_comm[k & 1], 0));
+    const int W = f->coll_world;
+    if (f->coll_rank != shard_owner(k, W)) HIPCHK(hipStreamWaitEvent(f->stream, f->ev_comm[k & 1], 0));
+    else if (k >= 1) HIPCHK(hipStreamWaitEvent(f->stream, f->ev_comm[(k - 1) & 1], 0));
     const int nxt = k + 1;
-    if (nxt < np && f->coll_rank == nxt % f->coll_world) {
+    if (nxt < np && f->coll_rank == shard_owner(nxt, W)) {
         if (int rc = shard_apply_range(f, k, nxt, nxt + 1)) return rc;      // only the columns of panel k+1 ...
         if (int rc = cocons_shard_panel_factor(f, nxt)) return rc;          // ... factor and pack it
     }
@@ -2405,7 +2473,7 @@ static int shard_step_pre(cocons_fit *f, int k, int np)
 static int shard_step_post(cocons_fit *f, int k, int np)
 {
     const int nxt = k + 1;
-    if (nxt < np && f->coll_rank == nxt % f->coll_world) return shard_apply_range(f, k, nxt + 1, -1);
+    if (nxt < np && f->coll_rank == shard_owner(nxt, f->coll_world)) return shard_apply_range(f, k, nxt + 1, -1);
     return shard_apply_range(f, k, k + 1, -1);
 }
 

@@ -694,6 +694,9 @@ struct EngineArgs {
                              // W = L^-1 of each diagonal tile, published before out[t] (see panel_kernel)
     int w_until;             // ... for the blocks that start at a tile t < w_until (the others: no inverse, no cost)
     int fused;               // blocks without W take the fused pass (potrf_block_fused)
+    double *wfull;           // WINV == 2: 256 x 256 (leading dimension 256, zero above the diagonal): the inverse of the whole
+                             // diagonal BLOCK's factor, [[W00, 0], [-W11 L10 W00, W11]] (see panel_gemm_kernel)
+    double *wT;              // WINV == 2: 128 x 128 scratch, W00^T
 };
 
 // W = L^-1 of the 128 x 128 tile whose factor (block-packed) and Q operands (all eight diagonal blocks) are in LDS:
@@ -701,10 +704,11 @@ struct EngineArgs {
 // triangular strip -- stored transposed, write-through, column-major with leading dimension 128.  168 MFMAs on the
 // longest strip (wave 0), ~5 us; the explicit inverse of a TRIANGULAR tile costs the solve that uses it a forward error
 // of eps cond(L) = eps sqrt(cond(Sigma block)), far inside the eps cond(Sigma) any Cholesky of Sigma carries.
-__device__ __noinline__ void engine_tile_inverse(double *W, int wave, int lane)
+__device__ __noinline__ void engine_tile_inverse(double *W, int ldw, double *WT, int wave, int lane)
 {
     // (out of line: inlined twice into the engine it pushed the kernel past its registers.  The LDS image is reached
     // through the kernel's dynamic-LDS symbol, so the reads stay ds_read -- a pointer argument would make them flat.)
+    // ldw: leading dimension of W; WT (may be null): W^T as well, leading dimension 128 (engine_block_inverse_offdiag)
     extern __shared__ double smem[];
     const double *S = smem, *QALL = smem + 37 * 256;
     d4 B[8];
@@ -736,14 +740,74 @@ __device__ __noinline__ void engine_tile_inverse(double *W, int wave, int lane)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int wr = 16 * j + 4 * r + kq, wc = 16 * wave + a;      // W(wr, wc) = W^T(wc, wr)
-            store_wt(W + wr + wc * TILE, wr >= wc ? B[j][r] : 0.0);
+            const double v = wr >= wc ? B[j][r] : 0.0;
+            store_wt(W + wr + (size_t)wc * ldw, v);
+            if (WT) store_wt(WT + wc + wr * TILE, v);
         }
+    }
+}
+
+// The off-diagonal tile of the inverse of a 256 x 256 block factor [[L00, 0], [L10, L11]]:  W10 = -W11 L10 W00, from
+// W00^T (WT, engine_tile_inverse of tile t), W11 (already in Wf) and L10 = A(t+1, t) (the engine's strip solve) -- two
+// 128^3 products on the engine's idle matrix pipes, ~20 us, only for the blocks whose trailing update is long enough to
+// hide them.  With the full inverse the panel below the block is ONE product X = B Wf^T without any dependent chain
+// (panel_gemm_kernel).  Called by all 8 waves behind a barrier; LDS (free at this point) holds L10, then N^T = (L10 W00)^T,
+// as 64 blocks, block (ib, jb) at (ib * 8 + jb) * 256.
+__device__ __noinline__ void engine_block_inverse_offdiag(const double *A, size_t lda, int c0, double *Wf, const double *WT,
+                                                          int wave, int lane)
+{
+    extern __shared__ double smem[];
+    double *XS = smem;
+    const int c1 = c0 + TILE;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        d4 b = glb_blk_wt(A, lda, c1 + 16 * wave, c0 + 16 * j, lane);
+        lds_blk_store(XS + (wave * 8 + j) * 256, lane, b);
+    }
+    __syncthreads();
+    d4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    // N^T(i, j) = sum_k W00^T(i, k) L10(j, k); rows 16 wave .. of W00^T are zero left of block column `wave`
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        if (kb < wave) continue;
+        d4 P = glb_blk_wt(WT, TILE, 16 * wave, 16 * kb, lane);
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            d4 Q = lds_blk(XS + (jb * 8 + kb) * 256, lane);
+            blk_mma(acc[jb], P, Q);
+        }
+    }
+    __syncthreads();                                   // every wave is done with L10
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) lds_blk_store(XS + (wave * 8 + jb) * 256, lane, acc[jb]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    // W10(i, j) = -sum_k W11(i, k) N^T(j, k); rows 16 wave .. of W11 end with block column `wave`
+    const double *W11 = Wf + TILE + (size_t)TILE * (2 * TILE);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        if (kb > wave) continue;
+        d4 P = glb_blk_wt(W11, 2 * TILE, 16 * wave, 16 * kb, lane);
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            d4 Q = lds_blk(XS + (jb * 8 + kb) * 256, lane);
+            blk_mma(acc[jb], P, Q);
+        }
+    }
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        d4 v = -acc[jb];
+        glb_blk_store_wt(Wf + TILE, 2 * TILE, 16 * wave, 16 * jb, lane, v);
     }
 }
 
 // FUSED / WINV: which paths the instantiation contains at all (each alternative costs the others registers: with
 // everything in one kernel the spills reached the pivot chains of the plain path)
-template <bool FUSED, bool WINV>
+// WINV: 0 = no inverses, 1 = the two tile inverses (panel_kernel), 2 = the inverse of the whole block (panel_gemm_kernel)
+template <bool FUSED, int WINV>
 __global__ void __launch_bounds__(512)
 potrf_engine_kernel(EngineArgs e)
 {
@@ -780,7 +844,8 @@ potrf_engine_kernel(EngineArgs e)
         if (*okp == 0) return;
         potrf_tile_body<true>(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem, QALL);
         __syncthreads();
-        if (WINV && t < e.w_until) engine_tile_inverse(e.winv + (size_t)(t & 1) * TILE * TILE, wave, lane);
+        if (WINV == 1 && t < e.w_until) engine_tile_inverse(e.winv + (size_t)(t & 1) * TILE * TILE, TILE, nullptr, wave, lane);
+        if (WINV == 2 && t < e.w_until && t + 1 < e.nt) engine_tile_inverse(e.wfull, 2 * TILE, e.wT, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t);
@@ -836,10 +901,19 @@ potrf_engine_kernel(EngineArgs e)
         __syncthreads();                           // X in LDS is dead; the tile is re-read from memory
         potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, (WINV && t < e.w_until) ? QALL : nullptr);
         __syncthreads();
-        if (WINV && t < e.w_until) engine_tile_inverse(e.winv + (size_t)((t + 1) & 1) * TILE * TILE, wave, lane);
+        if (WINV == 1 && t < e.w_until) engine_tile_inverse(e.winv + (size_t)((t + 1) & 1) * TILE * TILE, TILE, nullptr, wave, lane);
+        if (WINV == 2 && t < e.w_until)
+            engine_tile_inverse(e.wfull + TILE + (size_t)TILE * (2 * TILE), 2 * TILE, nullptr, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t + 1);
+        if (WINV == 2 && t < e.w_until) {
+            // the block's inverse is complete with its off-diagonal tile: second count on xr[t] (panel_gemm_kernel waits for 2)
+            engine_block_inverse_offdiag(A, lda, c0, e.wfull, e.wT, wave, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) signal_add(e.xr + t);
+        }
     }
 }
 
@@ -1082,6 +1156,123 @@ panel_kernel(PanelArgs a)
                               nullptr, 0u);
 }
 
+// The panel below an engine-factored 256 x 256 diagonal block as ONE tile-parallel product (COCONS_PANEL_MODE=3):
+//     X(rows, 0..255) = B(rows, 0..255) Wf^T,      Wf = inverse of the block's factor (EngineArgs::wfull),
+// one workgroup per 64 x 64 tile of X, K = 64 (jt + 1) for the tile's 64-column group jt (Wf is lower triangular) -- no
+// dependent chain and four times the workgroups of the strip forms above, so the launch lasts one short tile instead of
+// three latency-bound stages (15 us against 45-50).  B is NOT read in place (a tile of X would overwrite what the tiles to
+// its right still read): the trailing update that precedes the panel stores the panel's columns below the diagonal block
+// into the scratch panel `pin` instead of into the matrix (UpdArgs::redir_*), and this kernel writes X into the matrix.
+struct PanelGemmArgs {
+    double *A; size_t lda;
+    int c0, row0;            // first column of the block; first row below it (workgroup b: rows row0 + 64 (b >> 2) ..)
+    const double *pin;       // B: element (global row, panel column c) at pin[row + c * lda]
+    const double *wf;        // 256 x 256, leading dimension 256
+    unsigned *wflag; unsigned need;   // the engine's word for Wf (xr[t] >= 2)
+    unsigned *abort_word;
+    int nstrips;
+};
+
+// 4 waves (2 x 2, each 32 x 32 of the tile), K chunks of 16 through two 20 KB LDS buffers, 40 KB and ~110 registers: four
+// workgroups per CU, so the whole launch (at most ~630 tiles) is resident at once.  On a chip that is otherwise idle a
+// tile's time is memory round trips, not arithmetic: a chunk-by-chunk double buffer measured 2.5 us per chunk (40 us per
+// launch, as long as the three kernels this replaces), so every thread keeps the loads of FOUR chunks in flight.
+__global__ void __launch_bounds__(256)
+panel_gemm_kernel(PanelGemmArgs a)
+{
+    constexpr int TM = 64, KC = 16, LDT = TM + 16, D = 4;
+    constexpr int TPC = 256 / KC, RPT = TM / TPC;              // 16 threads per panel column, 4 rows each
+    static_assert(RPT == 4, "two 16-byte loads per thread, side and chunk");
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    __shared__ double sI[2][KC * LDT];
+    __shared__ double sJ[2][KC * LDT];
+    unsigned *share = (unsigned *)&sI[0][TM];      // padding of the first staged column (see update_kernel)
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wi = wave & 1, wj = wave >> 1;
+    // workgroups are dealt over the 8 XCDs by block index: the four column groups of a strip go to ONE XCD, back to back, so
+    // that the strip's rows of B are fetched into that XCD's L2 once (not up to four times)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int strip = (q >> 2) * 8 + xcd, jt = 3 - (q & 3);               // the longest products first
+    if (strip >= a.nstrips) return;
+    if (tid == 0) *share = wait_ge(a.wflag, a.need, a.abort_word, 0x800u) ? 1u : 0u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned ok = *share;
+    __syncthreads();
+    if (!ok) return;
+    const int row0 = a.row0 + TM * strip;
+    const int nch = (TM / KC) * (jt + 1);          // K = 64 (jt + 1): Wf is lower triangular; a multiple of D
+    const int kc = tid / TPC, rg = (tid % TPC) * RPT;
+    const double *gI = a.pin + (size_t)(row0 + rg) + (size_t)kc * a.lda;
+    const double *gJ = a.wf + (size_t)(TM * jt + rg) + (size_t)kc * (2 * TILE);
+    const size_t cI = (size_t)KC * a.lda, cJ = (size_t)KC * (2 * TILE);
+    d2 stI[D][2], stJ[D][2];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        stI[d][0] = *(const d2 *)(gI + d * cI);
+        stI[d][1] = *(const d2 *)(gI + d * cI + 2);
+        stJ[d][0] = *(const d2 *)(gJ + d * cJ);
+        stJ[d][1] = *(const d2 *)(gJ + d * cJ + 2);
+    }
+    d4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int ro = (lane >> 4) * LDT + (lane & 15);
+    for (int c0 = 0; c0 < nch; c0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int ch = c0 + d, cur = d & 1;
+            *(d2 *)(&sI[cur][kc * LDT + rg]) = stI[d][0];
+            *(d2 *)(&sI[cur][kc * LDT + rg + 2]) = stI[d][1];
+            *(d2 *)(&sJ[cur][kc * LDT + rg]) = stJ[d][0];
+            *(d2 *)(&sJ[cur][kc * LDT + rg + 2]) = stJ[d][1];
+            if (ch + D < nch) {
+                stI[d][0] = *(const d2 *)(gI + (size_t)(ch + D) * cI);
+                stI[d][1] = *(const d2 *)(gI + (size_t)(ch + D) * cI + 2);
+                stJ[d][0] = *(const d2 *)(gJ + (size_t)(ch + D) * cJ);
+                stJ[d][1] = *(const d2 *)(gJ + (size_t)(ch + D) * cJ + 2);
+            }
+            __syncthreads();            // (the buffer was last read two chunks ago, before the previous barrier)
+            const double *bI = &sI[cur][ro + 32 * wi];
+            const double *bJ = &sJ[cur][ro + 32 * wj];
+#pragma unroll
+            for (int s4 = 0; s4 < KC / 4; ++s4) {
+                const double p0 = bI[s4 * 4 * LDT], p1 = bI[s4 * 4 * LDT + 16];
+                const double q0 = bJ[s4 * 4 * LDT], q1 = bJ[s4 * 4 * LDT + 16];
+                acc[0][0] = MFMA64(q0, p0, acc[0][0]);
+                acc[0][1] = MFMA64(q1, p0, acc[0][1]);
+                acc[1][0] = MFMA64(q0, p1, acc[1][0]);
+                acc[1][1] = MFMA64(q1, p1, acc[1][1]);
+            }
+        }
+    }
+    double *Cb = a.A + (size_t)(row0 + 32 * wi) + (size_t)(a.c0 + TM * jt + 32 * wj) * a.lda;
+    const unsigned ldab = 8u * (unsigned)a.lda;
+    const unsigned cvo = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldab;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *(double *)((char *)(Cb + 16 * x) + (cvo + (unsigned)(16 * y + 4 * r) * ldab)) = acc[x][y][r];
+}
+
+void launch_panel_gemm(double *A, size_t lda, int t, int r0, int r1, const double *pin, const double *wfull,
+                       unsigned *wflag, unsigned *abort_word, hipStream_t s)
+{
+    const int nb = (r1 - r0) / 64;
+    if (nb <= 0) return;
+    PanelGemmArgs a;
+    a.A = A; a.lda = lda; a.c0 = t * TILE; a.row0 = r0; a.pin = pin; a.wf = wfull;
+    a.wflag = wflag; a.need = 2u; a.abort_word = abort_word; a.nstrips = nb;
+    hipLaunchKernelGGL(panel_gemm_kernel, dim3(32 * ((nb + 7) / 8)), dim3(256), 0, s, a);
+}
+
 // ---------------------------------------------------------------------------
 // Trailing update: C(ti,tj) -= P(ti,:) P(tj,:)^T over K panel columns.  TM x TM tiles, 4 waves x
 // (TM/2 x TM/2); instantiated with TM = 64 (each wave 2 x 2 MFMA blocks, up to 8 workgroups per CU).
@@ -1111,6 +1302,9 @@ struct UpdArgs {
     PanelArgs pan;
     int skew, kblk;                // packed band buffer (kernels.h band_index): C and P are its unshifted base, the operand
                                    // panel is tile column kblk; rows then count from each tile column's own diagonal tile
+    long long redir_off; int redir_ti0;   // redir_ti0 > 0 (lower_only launches): the tiles of the first four 64-wide columns --
+                                   // the NEXT panel's -- in tile rows >= redir_ti0 (below its diagonal block) are stored
+                                   // redir_off elements away from their place in C: into the scratch panel panel_gemm_kernel reads
 };
 
 // ROLE only names the instantiation (0 = trailing update, 1 = in-panel / sharded update) so that
@@ -1199,14 +1393,17 @@ update_kernel(UpdArgs a)
             // 1-D order over the tiles (ti >= tj) of the trapezoid, column by column: column j (0-based
             // from tj0) holds H - j tiles and starts at j H - j (j-1)/2.  Bisection in integers: L is
             // uniform, so this stays on the scalar unit.
+            // (Taking the next panel's tiles below its diagonal block LAST in this order -- so that the panel product finds
+            // them in the caches -- was measured with the scratch-panel redirect: the product no faster, these launches 3 %
+            // slower.)
             int lo = 0, hi = a.W - 1;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (mid * a.H - mid * (mid - 1) / 2 <= (int)Lt) lo = mid; else hi = mid - 1;
             }
             const int j = lo;
-            tj = a.tj0 + j;
             const int til = j + ((int)Lt - (j * a.H - j * (j - 1) / 2));
+            tj = a.tj0 + j;
             ti = til < a.Hb ? a.tj0 + til : a.ext0 + (til - a.Hb);
         } else {
             const int til = blockIdx.x;
@@ -1305,6 +1502,8 @@ update_kernel(UpdArgs a)
         // round trips; all sixteen at once would cost the 8th wave per SIMD in registers)
         unsigned cve = cvo;
         asm volatile("" : "+v"(cve));
+        // (scalar: the tile indices are uniform) where the results go -- in place, or into the scratch panel
+        double *Cs = (a.redir_ti0 > 0 && tj < a.tj0 + 4 && ti >= a.redir_ti0) ? Cb + a.redir_off : Cb;
 #pragma unroll
         for (int x = 0; x < NB; ++x)
 #pragma unroll
@@ -1317,11 +1516,11 @@ update_kernel(UpdArgs a)
                 if (wt_wg) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        store_wt((double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)), cv[r]);
+                        store_wt((double *)((char *)(Cs + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)), cv[r]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        *(double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)) = cv[r];
+                        *(double *)((char *)(Cs + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)) = cv[r];
                 }
             }
         if (wt_wg) {
@@ -1673,25 +1872,30 @@ void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s)
 
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
-                         double *winv, int w_until, int fused)
+                         double *winv, int w_until, int fused, double *wfull, double *wT)
 {
     if (t0 >= nt) return;
     EngineArgs e;
     e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
-    e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive; e.winv = winv; e.w_until = winv ? w_until : 0; e.fused = fused;
+    e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive; e.winv = winv;
+    e.wfull = wfull; e.wT = wT;
+    e.w_until = (winv || wfull) ? w_until : 0; e.fused = fused;
     // 136 KB: the 128 KB LDS copy of X plus the flag word; leaves room for ONE update workgroup beside the
     // engine.  (Asking for all 160 KB measured 7 % slower trailing updates chip-wide while the engine was
     // resident; 76 .. 152 KB did not.)
     size_t shm = 136 * 1024;
     { const char *x = getenv("COCONS_ENGINE_LDS"); if (x && (size_t)atol(x) >= shm) shm = (size_t)atol(x); }
-    const bool w = e.w_until > 0, fu = fused != 0;
-    const void *k = w ? (fu ? (const void *)potrf_engine_kernel<true, true> : (const void *)potrf_engine_kernel<false, true>)
-                      : (fu ? (const void *)potrf_engine_kernel<true, false> : (const void *)potrf_engine_kernel<false, false>);
+    const int w = e.w_until > 0 ? (wfull ? 2 : 1) : 0;
+    const bool fu = fused != 0;
+    const void *k = w == 2 ? (const void *)potrf_engine_kernel<false, 2>
+                  : w == 1 ? (fu ? (const void *)potrf_engine_kernel<true, 1> : (const void *)potrf_engine_kernel<false, 1>)
+                           : (fu ? (const void *)potrf_engine_kernel<true, 0> : (const void *)potrf_engine_kernel<false, 0>);
     (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    if (w && fu) hipLaunchKernelGGL((potrf_engine_kernel<true, true>), dim3(1), dim3(512), shm, s, e);
-    else if (w) hipLaunchKernelGGL((potrf_engine_kernel<false, true>), dim3(1), dim3(512), shm, s, e);
-    else if (fu) hipLaunchKernelGGL((potrf_engine_kernel<true, false>), dim3(1), dim3(512), shm, s, e);
-    else hipLaunchKernelGGL((potrf_engine_kernel<false, false>), dim3(1), dim3(512), shm, s, e);
+    if (w == 2) hipLaunchKernelGGL((potrf_engine_kernel<false, 2>), dim3(1), dim3(512), shm, s, e);
+    else if (w == 1 && fu) hipLaunchKernelGGL((potrf_engine_kernel<true, 1>), dim3(1), dim3(512), shm, s, e);
+    else if (w == 1) hipLaunchKernelGGL((potrf_engine_kernel<false, 1>), dim3(1), dim3(512), shm, s, e);
+    else if (fu) hipLaunchKernelGGL((potrf_engine_kernel<true, 0>), dim3(1), dim3(512), shm, s, e);
+    else hipLaunchKernelGGL((potrf_engine_kernel<false, 0>), dim3(1), dim3(512), shm, s, e);
 }
 
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
@@ -1725,7 +1929,7 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig, int sig_tile,
                         unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
-                        unsigned *near, int near_tiles, const UpdStrips *strips, int skew, int kblk)
+                        unsigned *near, int near_tiles, const UpdStrips *strips, int skew, int kblk, const UpdRedirect *redir)
 {
     // tile rows [ti0, ti1), or -- band-limited -- [ti0, band_hi) and [ext0, ti1)
     const bool band = band_hi >= 0;
@@ -1740,6 +1944,13 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     a.nstrips = 0; a.strip_pos = 0; a.near_need = 0;
     memset(&a.pan, 0, sizeof a.pan);
     a.skew = skew; a.kblk = kblk;
+    a.redir_off = 0; a.redir_ti0 = 0;
+    if (redir && redir->pin && lower_only && ti0 == tj0 && !band && !skew && world == 1 && tj1 - tj0 >= 2 &&
+        rows_band >= 3 && !(strips && strips->nstrips > 0)) {
+        // element (row, tj0 * 128 + c) of the matrix <-> pin[row + c * lda]
+        a.redir_off = (long long)(redir->pin - A) - (long long)tj0 * TILE * (long long)lda;
+        a.redir_ti0 = 2 * redir->row_tile0;
+    }
     a.Hb = 2 * rows_band; a.ext0 = 2 * ext0;
     a.C = A; a.ldc = lda; a.P = P; a.ldp = ldp; a.K = K;
     a.lower_only = lower_only ? 1 : 0;
@@ -1819,10 +2030,10 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
 bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig, int sig_tile,
                    unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
-                   unsigned *near, int near_tiles, const UpdStrips *strips, int skew)
+                   unsigned *near, int near_tiles, const UpdStrips *strips, int skew, const UpdRedirect *redir)
 {
     return launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile,
-                              wait_word, abort_word, queue, band_hi, ext0, near, near_tiles, strips, skew, k0 / TILE);
+                              wait_word, abort_word, queue, band_hi, ext0, near, near_tiles, strips, skew, k0 / TILE, redir);
 }
 
 // tiles of 64 x 64 in the first `near_tiles` (128-wide) tile columns of the trapezoid launch_update(..., lower_only, ti0 ==

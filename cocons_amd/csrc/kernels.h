@@ -122,7 +122,15 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
                          double *winv = nullptr, int w_until = 0,      // W only for blocks starting at a tile < w_until
-                         int fused = 1);   // the other blocks: strip solve and tile update folded into the first tile's factorisation
+                         int fused = 1,    // the other blocks: strip solve and tile update folded into the first tile's factorisation
+                         double *wfull = nullptr, double *wT = nullptr);   // wfull != NULL: the inverse of the whole 256 x 256 block
+                                           // factor (256 x 256, ld 256, zeroed once by the caller) instead of the tile inverses,
+                                           // complete when xr[t] reaches 2; wT: 128 x 128 scratch
+// Panel of the 256-column block at tile t as ONE tile-parallel product X = B Wf^T (rows [r0, r1), multiples of 64):
+// B from the scratch panel `pin` (element (row, c) at pin[row + c lda]; filled by the preceding trailing update through
+// UpdRedirect), Wf = wfull of launch_potrf_engine, X into the matrix.  Waits for wflag >= 2.
+void launch_panel_gemm(double *A, size_t lda, int t, int r0, int r1, const double *pin, const double *wfull,
+                       unsigned *wflag, unsigned *abort_word, hipStream_t s);
 // Panel of the 256-column block at tile t under the engine schedule, ONE launch: rows [r0, r1) (multiples of 64) of
 // tile columns t and (two != 0) t + 1:   X0 = B0 W(t)^T ;  B1 -= X0 X(t+1,t)^T ;  X1 = B1 W(t+1)^T  -- the panel solve as
 // three small GEMMs per 64-row strip on the update kernel's inner loop and footprint (no dependent chain).  Each
@@ -149,13 +157,20 @@ struct UpdStrips {
     const double *winv;
     unsigned *out, *xr;
 };
+// Trailing update whose results for the NEXT panel's columns (the first two tile columns of the trapezoid), tile rows
+// >= row_tile0, go into the scratch panel `pin` instead of into the matrix (launch_panel_gemm reads them there)
+struct UpdRedirect {
+    double *pin;
+    int row_tile0;
+};
 // (returns true when `strips` were taken into the launch; false: the caller forms the panel itself, e.g. launch_panel)
 bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig = nullptr, int sig_tile = -1,
                    unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
                    int band_hi = -1, int ext0 = 0,       // band_hi >= 0: tile rows [ti0, band_hi) and [ext0, ti1)
                    unsigned *near = nullptr, int near_tiles = 0, const UpdStrips *strips = nullptr,
-                   int skew = 0);          // packed band buffer (band_index; with band_hi / ext0): A is its unshifted base
+                   int skew = 0,           // packed band buffer (band_index; with band_hi / ext0): A is its unshifted base
+                   const UpdRedirect *redir = nullptr);
 // near / near_tiles (lower_only launches): the tiles in the first near_tiles tile columns -- the next panel -- are stored
 // write-through and each adds 1 to *near when done; update_near_count() says how many there are.  A stream that has
 // passed launch_flag_gate(near, count, ...) may read them although the update launch is still running.
@@ -174,7 +189,7 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
                         int ptiles, int world, int rank, unsigned *sig = nullptr, int sig_tile = -1,
                         unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
                         int band_hi = -1, int ext0 = 0, unsigned *near = nullptr, int near_tiles = 0,
-                        const UpdStrips *strips = nullptr, int skew = 0, int kblk = 0);
+                        const UpdStrips *strips = nullptr, int skew = 0, int kblk = 0, const UpdRedirect *redir = nullptr);
 
 
 // reductions: out[0] = sum_{i<n} log(A(i,i)); out[1 + a*nr + b] = sum_{c<n} A(row0+a,c) A(row0+b,c)

@@ -6,7 +6,8 @@ the device, so "Sigma row-block partitioned" = panels (256 columns) dealt block-
 over the ranks:
 
     for each panel k:
-        owner(k) = k mod world : factor the panel in place (potrf + panel solve), pack it
+        owner(k) = (k div G) mod world : factor the panel in place (potrf + panel solve), pack it   (groups of G
+                                          consecutive panels, COCONS_SHARD_GROUP, default 4)
         broadcast the packed panel (<= 20.7 MB at n = 10^4) from its owner     <- the only collective
         every rank: update its OWN panels right of k with the received panel    (MFMA fp64)
     all-reduce of {sum log diag, Gram of the rhs rows} partial sums             (1 + r^2 doubles)
@@ -214,13 +215,14 @@ def sharded_neg2loglik_core(engine, theta_list, dist, rank, world, group=None, l
     never touches the buffer panel k is being read from)."""
     engine.begin(theta_list, rank, world)
     npan = engine.num_panels()
+    owner_of = getattr(engine, "owner", None) or (lambda k: k % world)
     if world == 1:
         for k in range(npan):
             engine.panel_factor(k)
             engine.panel_apply(k)
     elif not lookahead:
         for k in range(npan):
-            owner = k % world
+            owner = owner_of(k)
             if rank == owner:
                 engine.panel_factor(k)
             dist.broadcast(engine.panel_tensor(k), src=owner, group=group)
@@ -233,12 +235,12 @@ def sharded_neg2loglik_core(engine, theta_list, dist, rank, world, group=None, l
             work.wait()                                   # panel k is in its exchange buffer
             nxt = k + 1
             if nxt < npan:
-                if rank == nxt % world:
+                if rank == owner_of(nxt):
                     engine.panel_apply(k, nxt, nxt + 1)   # only the columns of panel k+1 ...
                     engine.panel_factor(nxt)              # ... factor it ...
                 # ... and put it on the wire while everybody applies panel k to the rest
-                work = dist.broadcast(engine.panel_tensor(nxt), src=nxt % world, group=group, async_op=True)
-                if rank == nxt % world:
+                work = dist.broadcast(engine.panel_tensor(nxt), src=owner_of(nxt), group=group, async_op=True)
+                if rank == owner_of(nxt):
                     engine.panel_apply(k, nxt + 1, None)
                 else:
                     engine.panel_apply(k)

@@ -290,6 +290,8 @@ int cocons_shard_panel_apply(cocons_fit *fit, int k);
 int cocons_shard_panel_apply_range(cocons_fit *fit, int k, int j0, int j1);
 int cocons_shard_finish(cocons_fit *fit, double *partial /* 1 + (r)(r) */, int *info);
 int cocons_shard_num_panels(cocons_fit *fit);
+/* rank that owns panel k among `world` ranks: (k / G) % world, G = COCONS_SHARD_GROUP (default 4) consecutive panels */
+int cocons_shard_panel_owner(int k, int world);
 /* bytes one exchange buffer must hold; optionally hand in two caller-owned device
  * buffers (e.g. torch tensors, so torch.distributed can broadcast them in place) */
 long long cocons_shard_exchange_bytes(cocons_fit *fit);

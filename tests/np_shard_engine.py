@@ -1,6 +1,6 @@
 """TEST DOUBLE (not product code): a numpy implementation of the engine interface that
 cocons_amd.shard.sharded_neg2loglik_core drives, with the same storage conventions as the
-HIP engine (column-major lower factor, 128-tiles, 256-column panels dealt block-cyclically,
+HIP engine (column-major lower factor, 128-tiles, 256-column panels dealt over the ranks in groups of `group`,
 rhs rows under the matrix, packed exchange buffers).  Lets the N>1 schedule and its
 collectives run over gloo on CPU.  Panels a rank does not own are filled with NaN, so any
 use of data that was never broadcast shows up in the result."""
@@ -11,8 +11,9 @@ TILE, PT = 128, 2
 
 
 class NumpyShardEngine:
-    def __init__(self, oracle, locs, X, z, smooth_limits):
+    def __init__(self, oracle, locs, X, z, smooth_limits, group=1):
         self.O = oracle
+        self.group = max(1, int(group))
         self.locs, self.X = np.asarray(locs, float), np.asarray(X, float)
         self.z = np.asarray(z, float).reshape(self.X.shape[0], -1)
         self.n, self.r = self.z.shape
@@ -26,6 +27,10 @@ class NumpyShardEngine:
     def num_panels(self):
         return (self.nt + PT - 1) // PT
 
+    def owner(self, k):
+        """(k div G) mod world: csrc/api.hip shard_owner."""
+        return (k // self.group) % self.world
+
     def _cols(self, k):
         c0 = k * PT * TILE
         return c0, min(c0 + PT * TILE, self.npad)
@@ -35,7 +40,9 @@ class NumpyShardEngine:
         S = self.O.cov_rns(theta_list, self.locs, self.X, self.sl)
         A = np.full((self.lda, self.npad), np.nan)
         resid = self.z - (self.X @ np.asarray(theta_list["mean"], float))[:, None]
-        for k in range(rank, self.num_panels(), world):
+        for k in range(self.num_panels()):
+            if self.owner(k) != rank:
+                continue
             c0, c1 = self._cols(k)
             A[:, c0:c1] = 0.0
             hi = min(c1, self.n)
@@ -74,7 +81,7 @@ class NumpyShardEngine:
         j0 = k + 1 if j0 is None else max(j0, k + 1)
         j1 = self.num_panels() if (j1 is None or j1 < 0) else min(j1, self.num_panels())
         for j in range(j0, j1):
-            if j % self.world != self.rank:
+            if self.owner(j) != self.rank:
                 continue
             d0, d1 = self._cols(j)
             # rows >= d0 of own panel j:  C -= P(rows) P(cols d0:d1)^T
@@ -82,7 +89,9 @@ class NumpyShardEngine:
 
     def finish(self):
         part = np.zeros(1 + self.r * self.r)
-        for k in range(self.rank, self.num_panels(), self.world):
+        for k in range(self.num_panels()):
+            if self.owner(k) != self.rank:
+                continue
             c0, c1 = self._cols(k)
             hi = min(c1, self.n)
             if hi <= c0:

@@ -216,8 +216,10 @@ def _free_port():
     return p
 
 
-def _shard_worker(rank, world, port, g, out_dir, predict_first=False):
+def _shard_worker(rank, world, port, g, out_dir, predict_first=False, group=None):
     sys.path.insert(0, ROOT)
+    if group is not None:
+        os.environ["COCONS_SHARD_GROUP"] = str(group)      # read once, when the library is first used
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch                      # noqa: F401
@@ -244,19 +246,21 @@ def _shard_worker(rank, world, port, g, out_dir, predict_first=False):
 
 
 @pytest.mark.shared_gpu
-@pytest.mark.parametrize("world,g,predict_first", [(2, 40, False), (3, 50, False), (4, 15, False), (2, 40, True),
-                                                   (2, 100, False)])
-def test_native_sharded_evaluation_shared_gpu(tmp_path, world, g, predict_first):
+@pytest.mark.parametrize("world,g,predict_first,group", [(2, 40, False, None), (3, 50, False, None), (4, 15, False, None),
+                                                         (2, 40, True, None), (2, 100, False, None),
+                                                         (2, 40, False, 1), (3, 50, False, 2), (4, 50, False, 3)])
+def test_native_sharded_evaluation_shared_gpu(tmp_path, world, g, predict_first, group):
     """The production sharded path -- the schedule inside the HIP library (sharded_eval: panel ownership,
     look-ahead, communication stream, double-buffered exchange, final all-reduce) -- with `world` ranks
     sharing this box's single GPU.  RCCL refuses several ranks on one device, so the library's
     broadcast / all-reduce hooks are served by gloo through host memory; everything else is the code the
     RCCL build runs.  Must reproduce the single-GPU value.  (2, 100) is BASELINE config C3 at its full
-    size n = 10 000 in sharded form."""
+    size n = 10 000 in sharded form.  `group` = panels per ownership group (None: the library's default, 4;
+    1: the cyclic deal of rounds 1-2)."""
     import torch.multiprocessing as mp
     import cocons_amd as ca
     from cocons_amd import workloads as wl
-    mp.spawn(_shard_worker, args=(world, _free_port(), g, str(tmp_path), predict_first), nprocs=world, join=True)
+    mp.spawn(_shard_worker, args=(world, _free_port(), g, str(tmp_path), predict_first, group), nprocs=world, join=True)
     res = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r)) for r in range(world)]
     for r in res[1:]:
         assert np.array_equal(r, res[0])

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, seed, out_dir, lookahead=True):
+def _worker(rank, world, port, n, seed, out_dir, lookahead=True, group=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -37,20 +37,24 @@ def _worker(rank, world, port, n, seed, out_dir, lookahead=True):
     th = wl.theta_full(scale0=np.log(0.2))
     th["mean"] = np.array([0.1, -0.2, 0.05])
     z = rng.standard_normal((n, 2))
-    eng = NumpyShardEngine(O, locs, X, z, wl.SMOOTH_LIMITS)
+    eng = NumpyShardEngine(O, locs, X, z, wl.SMOOTH_LIMITS, group=group)
     val, parts = sharded_neg2loglik_core(eng, th, dist, rank, world, lookahead=lookahead)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([[val], parts]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,lookahead", [(2, 700, True), (3, 900, True), (2, 200, True), (2, 700, False),
-                                                  (4, 1300, True), (4, 200, True), (3, 100, False)])
-def test_sharded_schedule_over_gloo(oracle, tmp_path, world, n, lookahead):
+@pytest.mark.parametrize("world,n,lookahead,group", [(2, 700, True, 1), (3, 900, True, 1), (2, 200, True, 1),
+                                                        (2, 700, False, 1), (4, 1300, True, 1), (4, 200, True, 1),
+                                                        (3, 100, False, 1),
+                                                        # panels dealt in groups of consecutive panels (the library's
+                                                        # default deal): 6 panels over 4 ranks in pairs leaves a rank idle
+                                                        (2, 1300, True, 2), (4, 1300, True, 2), (3, 900, False, 3)])
+def test_sharded_schedule_over_gloo(oracle, tmp_path, world, n, lookahead, group):
     import torch.multiprocessing as mp
     from cocons_amd import workloads as wl
     seed = 100 + n
-    mp.spawn(_worker, args=(world, _free_port(), n, seed, str(tmp_path), lookahead), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, seed, str(tmp_path), lookahead, group), nprocs=world, join=True)
     res = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r)) for r in range(world)]
     for r in res[1:]:
         assert np.array_equal(r, res[0])              # identical on every rank
