@@ -34,9 +34,25 @@ for i, (x, y) in enumerate(locs):
     rp.append(len(ci) + 1)
 print("pattern: n = %d, nnz = %d (%.1f per row, %.2f %% dense), built in %.1f s" %
       (n, len(ci), len(ci) / n, 100.0 * len(ci) / n / n, time.perf_counter() - t0))
+
+
+def device_free_bytes():
+    """free device memory (hipMemGetInfo through ctypes): the handle's footprint is the drop across its creation"""
+    import ctypes
+    from cocons_amd.shard import _hip_runtime
+    hip = _hip_runtime()
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+    return free.value
+
+
+ca.CoconsFit(locs[:300], X[:300], z[:300], wl.SMOOTH_LIMITS).neg2loglik_core(th)   # library + context are up
+free0 = device_free_bytes()
 fit = ca.CoconsTaperFit(locs, X, z, wl.SMOOTH_LIMITS, np.array(ci, dtype=np.int32), np.array(rp, dtype=np.int32), np.array(ent))
 for _ in range(3):
     v, parts = fit.neg2loglik_core(th)
+print("device memory of the handle (pattern, data, factorisation buffer): %.3f GB; a dense n x n buffer alone: %.2f GB" %
+      ((free0 - device_free_bytes()) / 1e9, 8.0 * n * n / 1e9))
 K = 20
 t0 = time.perf_counter()
 for _ in range(K):
