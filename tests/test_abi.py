@@ -4,6 +4,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -98,3 +100,20 @@ def test_glue_covers_the_reference_call_surface():
     rfile = open(os.path.join(root, "glue", "R", "cocons_hip.R")).read()
     for sym in re.findall(r"`(_cocons_hip_[a-z_0-9]+)`", rfile):
         assert sym in table, sym
+
+
+def test_glue_compiles_against_declared_apis():
+    """R is not installed here, so the glue is never linked -- but the compiler's front end can still check it: every call
+    of a cocons_* entry point against include/cocons_hip.h (argument count and types) and every use of R's C API against
+    the documented prototypes (tests/r_api_decls: declarations only, test infrastructure).  -Werror: an implicit
+    declaration, a wrong arity or a pointer-type mismatch in a shim fails this test."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    r = subprocess.run([gcc, "-std=gnu11", "-fsyntax-only", "-Wall", "-Wextra", "-Wno-unused-parameter",
+                        "-Wno-cast-function-type", "-Werror", "-I", os.path.join(ROOT, "tests", "r_api_decls"),
+                        "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "glue", "cocons_hip_glue.c")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
