@@ -239,7 +239,7 @@ struct cocons_fit {
     int *dinfo;
     double *dout;            // reductions
     double *hout;            // pinned mirror
-    int *hinfo;
+    int *hinfo, *hinfo_init = nullptr;
     double smooth_limits[2];
     size_t out_cap;
     // predict scratch
@@ -334,13 +334,13 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->stream2) hipStreamSynchronize(f->stream2);
         if (f->stream3) hipStreamSynchronize(f->stream3);
         hipFree(f->dX); hipFree(f->dlocs); hipFree(f->dz); hipFree(f->dxb); hipFree(f->dloc);
-        hipFree(f->dA); hipFree(f->dinv); hipFree(f->dwinv); hipFree(f->dinfo); hipFree(f->dout);
+        hipFree(f->dA); hipFree(f->dinv); hipFree(f->dwinv); hipFree(f->dinfo);      // (dout is part of dinfo's allocation)
         if (f->dwfull) hipFree(f->dwfull);
         if (f->dwT) hipFree(f->dwT);
         if (f->dpin) hipFree(f->dpin);
         hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad); hipFree(f->dred);
         if (f->xbuf_own) { hipFree(f->xbuf[0]); hipFree(f->xbuf[1]); }
-        hipHostFree(f->hout); hipHostFree(f->hinfo);
+        hipHostFree(f->hinfo);                                  // (hout, hinfo_init: the same allocation)
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
         if (f->ev_eng) hipEventDestroy(f->ev_eng);
         hipFree(f->dflags);
@@ -483,12 +483,19 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     CK(hipMalloc(&f->dinv, 2 * 8 * 256 * sizeof(double)));
     CK(hipMalloc(&f->dwinv, 2 * (size_t)TILE * TILE * sizeof(double)));
     CK(hipMemsetAsync(f->dwinv, 0, 2 * (size_t)TILE * TILE * sizeof(double), f->stream));   // zero above the diagonal, for good
-    CK(hipMalloc(&f->dinfo, 2 * sizeof(int)));      // [0] failing minor (atomicMin), [1] abort word of the engine hand-offs
+    // the two info words -- [0] failing minor (atomicMin), [1] abort word of the engine hand-offs -- sit in the 8 bytes in
+    // front of the reduction outputs, on the device and in the pinned host mirror: an evaluation brings both home in ONE copy
     int nr_max = r + (q > p ? q : p);
     f->out_cap = (size_t)(1 + nr_max * nr_max) * (size_t)(f->nt + 2);
-    CK(hipMalloc(&f->dout, f->out_cap * sizeof(double)));
-    CK(hipHostMalloc(&f->hout, f->out_cap * sizeof(double)));
-    CK(hipHostMalloc(&f->hinfo, 2 * sizeof(int)));
+    {
+        double *dbase = nullptr, *hbase = nullptr;
+        CK(hipMalloc(&dbase, (f->out_cap + 1) * sizeof(double)));
+        CK(hipHostMalloc(&hbase, (f->out_cap + 2) * sizeof(double)));
+        f->dinfo = (int *)dbase; f->dout = dbase + 1;
+        f->hinfo = (int *)hbase; f->hout = hbase + 1;
+        f->hinfo_init = (int *)(hbase + 1 + f->out_cap);      // constant {0x7f7f7f7f, 0}: reset_info's source
+        f->hinfo_init[0] = 0x7f7f7f7f; f->hinfo_init[1] = 0;
+    }
     for (auto &e : f->ev) CK(hipEventCreate(&e));
     CK(hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&f->ev_eng, hipEventDisableTiming));
@@ -1174,8 +1181,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
 
 static int reset_info(cocons_fit *f)
 {
-    HIPCHK(hipMemsetAsync(f->dinfo, 0x7f, sizeof(int), f->stream));
-    HIPCHK(hipMemsetAsync(f->dinfo + 1, 0, sizeof(int), f->stream));
+    HIPCHK(hipMemcpyAsync(f->dinfo, f->hinfo_init, 2 * sizeof(int), hipMemcpyHostToDevice, f->stream));
     return 0;
 }
 
@@ -1200,9 +1206,8 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
     if (int rc = factorize(f, main_view(f), ev_upd)) return rc;
     if (stage_events) hipEventRecord(f->ev[2], f->stream);
     launch_finalize(f->dA, f->lda, f->n, f->npad, nrhs, f->dout, f->stream, f->skew, f->npad);
-    HIPCHK(hipMemcpyAsync(f->hout, f->dout, (size_t)(1 + nrhs * nrhs) * sizeof(double),
+    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, (size_t)(2 + nrhs * nrhs) * sizeof(double),       // info words + outputs
                           hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, f->stream));
     if (stage_events) hipEventRecord(f->ev[3], f->stream);
     HIPCHK(hipGetLastError());
     return 0;
