@@ -151,14 +151,41 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
     }
     double kmu, kmu1;                  // K_mu, K_{mu+1}, both WITHOUT the factor exp(-u) when u > 2
     double escale;                     // the factor still to be applied: exp(-u) (CF2) or 1 (Temme)
+    double l2u;                        // log2(u) for the final power of two
     if (u <= 2.0) {
+        // Temme's series.  Its set-up used to be five library calls (sin, log, sinh, cosh, exp: ~250 instructions, more
+        // than the series itself); now ONE log and ONE exp: sin(pi mu) on |pi mu| <= pi/2 by its Taylor polynomial
+        // (degree 21: 1e-18), cosh(e) and sinh(e)/e from E = exp(e) and 1/E (sinh(e)/e by its series where |e| < 1/4: the
+        // difference E - 1/E cancels there), and log2(u) = 1 - d log2(e) from the logarithm already taken.
         double x2 = 0.5 * u, pimu = pi * mu;
-        double fact = fabs(pimu) < tol ? 1.0 : pimu / sin(pimu);
+        const double y = pimu * pimu;
+        double sp = -1.0 / 51090942171709440000.0;          // -1/21!
+        sp = fma(sp, y, 1.0 / 121645100408832000.0);         //  1/19!
+        sp = fma(sp, y, -1.0 / 355687428096000.0);           // -1/17!
+        sp = fma(sp, y, 1.0 / 1307674368000.0);              //  1/15!
+        sp = fma(sp, y, -1.0 / 6227020800.0);                // -1/13!
+        sp = fma(sp, y, 1.0 / 39916800.0);                   //  1/11!
+        sp = fma(sp, y, -1.0 / 362880.0);                    // -1/9!
+        sp = fma(sp, y, 1.0 / 5040.0);                       //  1/7!
+        sp = fma(sp, y, -1.0 / 120.0);                       // -1/5!
+        sp = fma(sp, y, 1.0 / 6.0);                          //  1/3!
+        sp = fma(-sp, y, 1.0);                               // sin(x)/x = 1 - x^2 (1/3! - x^2 (1/5! - ...))
+        double fact = fast_rcp(sp);                          // pi mu / sin(pi mu)
         double d = -log(x2), e = mu * d;
-        double fact2 = fabs(e) < tol ? 1.0 : sinh(e) / e;
-        double ff = fact * (gam1 * cosh(e) + gam2 * fact2 * d);
+        l2u = fma(-d, 1.4426950408889634074, 1.0);
+        const double E = exp(e), Ei = fast_rcp(E);
+        const double e2 = e * e;
+        double sh = 1.0 / 6227020800.0;                       // sinh(e)/e = sum e^(2k) / (2k+1)!, |e| < 1/4: 1e-19 after e^12
+        sh = fma(sh, e2, 1.0 / 39916800.0);
+        sh = fma(sh, e2, 1.0 / 362880.0);
+        sh = fma(sh, e2, 1.0 / 5040.0);
+        sh = fma(sh, e2, 1.0 / 120.0);
+        sh = fma(sh, e2, 1.0 / 6.0);
+        sh = fma(sh, e2, 1.0);
+        double fact2 = fabs(e) < 0.25 ? sh : 0.5 * (E - Ei) * fast_rcp(e);
+        double ff = fact * (gam1 * (0.5 * (E + Ei)) + gam2 * fact2 * d);
         double sum = ff;
-        e = exp(e);
+        e = E;
         double pp = 0.5 * e / gampl, q = 0.5 / (e * gammi), c = 1.0;
         d = x2 * x2;
         double sum1 = pp;
@@ -182,6 +209,7 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         //   q_k = (q_{k-2} - (b_k - 2) q_{k-1}) / a_k ,  C_k = -C_{k-1} a_k / k
         // become  A_k = -(B_{k-1} - (b_k - 2) A_{k-1}) / k ,  B_k = -(a_k / k) A_{k-1}
         // (a_k cancels), leaving one reciprocal per step.
+        l2u = log2(u);
         double a = mu2 - 0.25;
         double b = 2.0 * (u + 1.0), D = fast_rcp(b), f = D, delta = D;
         double Ak = -a;          // C_1 q_1 = -a * 1
@@ -219,7 +247,7 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
     }
     rg = rg * fast_rcp(prod);
     // 2^(1-nu) u^nu = 2^(nu log2 u + 1 - nu): the exponent stays O(25), so its rounding is harmless; times e^-u on the CF2 side
-    const double ex = fma(nu, log2(u), 1.0 - nu);
+    const double ex = fma(nu, l2u, 1.0 - nu);
     return (escale == 0.0 ? pow2a_expmu(ex, u) : exp2(ex)) * rg * pk;
 }
 
