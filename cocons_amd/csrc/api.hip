@@ -253,9 +253,6 @@ struct cocons_fit {
     hipEvent_t ev[8];
     hipStream_t stream2;          // stream the resident diagonal-tile engine is launched on
     hipEvent_t ev_eng;            // orders the engine launch behind the reset of its flag words
-    hipStream_t stream3;          // panel stream of the engine schedule: the solves below a diagonal block run here, beside
-                                  // the tail of the trailing update that produced their input (see factorize)
-    hipEvent_t ev_panel[2];       // panel of block t done (by block parity): the next trailing update waits for it
     unsigned *dflags;             // flags_cap words each: in[t], out[t], xr[t] (see launch_potrf_engine); 64: the alive word;
                                   // flags_cap: tile counters of the trailing updates; flags_cap: near[t], finished tiles of
                                   // the next panel's columns (launch_update's near)
@@ -332,7 +329,6 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         hipSetDevice(f->device);
         if (f->stream) hipStreamSynchronize(f->stream);
         if (f->stream2) hipStreamSynchronize(f->stream2);
-        if (f->stream3) hipStreamSynchronize(f->stream3);
         hipFree(f->dX); hipFree(f->dlocs); hipFree(f->dz); hipFree(f->dxb); hipFree(f->dloc);
         hipFree(f->dA); hipFree(f->dinv); hipFree(f->dwinv); hipFree(f->dinfo);      // (dout is part of dinfo's allocation)
         if (f->dwfull) hipFree(f->dwfull);
@@ -353,8 +349,6 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->slots) { for (auto c : *f->slots) cocons_fit_destroy(c); delete f->slots; f->slots = nullptr; }
         if (f->unsorted) { cocons_fit_destroy(f->unsorted); f->unsorted = nullptr; }
         if (f->stream2) hipStreamDestroy(f->stream2);
-        if (f->stream3) hipStreamDestroy(f->stream3);
-        for (auto &e : f->ev_panel) if (e) hipEventDestroy(e);
         if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     }
     delete f->h_locs; delete f->h_X; delete f->h_z;
@@ -499,8 +493,8 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     for (auto &e : f->ev) CK(hipEventCreate(&e));
     CK(hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&f->ev_eng, hipEventDisableTiming));
-    // (stream3 / ev_panel -- the panel stream of the overlap experiment -- are created on first use: every stream a process
-    // holds competes for the few hardware queues, and a third stream per handle halved the throughput of the batch slots)
+    // (two streams per handle and no more: every stream a process holds competes for the few hardware queues -- a third one
+    // per handle, for a panel-overlap experiment since removed, halved the throughput of the batch slots)
     // (a taper handle allocates its buffer once the envelope of its pattern is known: packed, it is a fraction of n^2)
     if (!defer_matrix && fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
 #undef CK
@@ -693,7 +687,6 @@ extern "C" int cocons_fit_set_stream(cocons_fit *f, void *stream)
     // stream that is about to be destroyed
     HIPCHK(hipStreamSynchronize(f->stream));
     HIPCHK(hipStreamSynchronize(f->stream2));
-    if (f->stream3) HIPCHK(hipStreamSynchronize(f->stream3));
     if (f->own_stream) { HIPCHK(hipStreamDestroy(f->stream)); f->own_stream = false; }
     f->stream = (hipStream_t)stream;
     return 0;
@@ -855,9 +848,7 @@ struct Tunables {
     int panel_mode = 0;      // COCONS_PANEL_MODE, see panel_mode()
     int strip_lead = 3600;   // COCONS_STRIP_LEAD
     int strip_min = 3600;    // COCONS_STRIP_MIN
-    int overlap = 0;         // COCONS_PANEL_OVERLAP
     int upd_dynamic = 1;     // COCONS_UPD_DYNAMIC
-    int near_force = 0;      // (experiment) count the near tiles write-through although nobody waits for them
     int engine_fused = 0;    // COCONS_ENGINE_FUSED: the engine's fused pass over a diagonal block (potrf_block_fused)
     bool init = false;
 };
@@ -870,7 +861,6 @@ static Tunables &tun()
         rd("COCONS_PANEL_MODE", t.panel_mode);
         rd("COCONS_STRIP_LEAD", t.strip_lead);
         rd("COCONS_STRIP_MIN", t.strip_min);
-        rd("COCONS_PANEL_OVERLAP", t.overlap);
         rd("COCONS_UPD_DYNAMIC", t.upd_dynamic);
         rd("COCONS_ENGINE_FUSED", t.engine_fused);
         if (t.panel_mode < 0 || t.panel_mode > 3) t.panel_mode = 0;
@@ -888,9 +878,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "panel_mode") t.panel_mode = value;
     else if (k == "strip_lead") t.strip_lead = value;
     else if (k == "strip_min") t.strip_min = value;
-    else if (k == "overlap") t.overlap = value;
     else if (k == "upd_dynamic") t.upd_dynamic = value;
-    else if (k == "near_force") t.near_force = value;
     else if (k == "engine_fused") t.engine_fused = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
@@ -956,7 +944,6 @@ static int flags_reset(cocons_fit *f, int nt)
 {
     if (f->flags_cap < nt) {
         HIPCHK(hipStreamSynchronize(f->stream2));
-        if (f->stream3) HIPCHK(hipStreamSynchronize(f->stream3));
         if (f->dflags) { HIPCHK(hipFree(f->dflags)); f->dflags = nullptr; }
         f->flags_cap = round_up(nt + 8, 64);
         HIPCHK(hipMalloc(&f->dflags, (5 * (size_t)f->flags_cap + 64) * sizeof(unsigned)));
@@ -1115,19 +1102,10 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     unsigned *abort_word = (unsigned *)(f->dinfo + 1);
     launch_engine_gate(f->dflags + 3 * (size_t)f->flags_cap, abort_word, M);
     panel_ops(f, v, 0, M);
-    // The panel of block t (solve, in-panel update, solve: three short launches that use a fraction of the chip) runs on
-    // a stream of its own, P, held back by flags instead of by the end of the update U(k) that feeds it: U(k) stores the
-    // tiles of the panel's columns write-through and counts them in near[t]; once they are all there (they come first in
-    // U(k)'s tile order) P's gate opens and the panel kernels are placed as soon as U(k)'s retiring workgroups leave room --
-    // in the tail of U(k), where the chip drains anyway.  U(k+2) waits for the panel's event.  COCONS_PANEL_OVERLAP=0:
-    // everything in order on the main stream (the round-2 schedule).
-    const int overlap = f->engine_w3 ? 0 : tun().overlap;
-    if (overlap && !f->stream3) {
-        HIPCHK(hipStreamCreateWithFlags(&f->stream3, hipStreamNonBlocking));
-        for (auto &e : f->ev_panel) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    hipStream_t P = overlap ? f->stream3 : M;
-    if (overlap) HIPCHK(hipStreamWaitEvent(P, f->ev_eng, 0));     // behind the reset of the flag words
+    // (Running the panel kernels on a stream of their own behind near-tile flags, so that they start in the tail of the
+    // update that feeds them, was built and measured in round 3: slower -- a 90 KB-LDS solve is not placed beside eight
+    // update workgroups per CU, the event back to the main stream costs 12 us -- and removed)
+    hipStream_t P = M;
     const int w_until = panel_w_until(v);
     for (int k = 0; k + 2 < nt; k += 2) {
         const int t = k + 2;
@@ -1155,9 +1133,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
                 launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, mt * TILE, f->dwinv, out, xr, abort_word, M);
             continue;
         }
-        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), (overlap || tun().near_force) ? near + t : nullptr,
-                     near_tiles);
-        if (overlap) launch_flag_gate(near + t, update_near_count(t, mt, near_tiles), abort_word, 0x700u + t, P);
+        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), nullptr, near_tiles);
         if (with_w && !f->engine_w3) {
             launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, mt * TILE, f->dwinv, out, xr, abort_word, P);
         } else {
@@ -1169,11 +1145,6 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
                 launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, r0 * TILE, mt * TILE,
                                  f->dinv + (size_t)((t + 1) & 1) * 2048, P, out + t + 1, abort_word, br, er);
             }
-        }
-        if (overlap) {
-            hipEvent_t ev = f->ev_panel[(t >> 1) & 1];
-            HIPCHK(hipEventRecord(ev, P));
-            HIPCHK(hipStreamWaitEvent(M, ev, 0));
         }
     }
     return 0;
@@ -1248,7 +1219,6 @@ static bool engine_retry(cocons_fit *f, int st)
     f->engine_live = false;
     f->engine_used = false;
     hipStreamSynchronize(f->stream2);
-    if (f->stream3) hipStreamSynchronize(f->stream3);
     return true;
 }
 

@@ -2063,19 +2063,6 @@ unsigned update_near_count(int ti0, int ti1, int near_tiles)
     return (unsigned)(W * H - W * (W - 1) / 2);
 }
 
-// one lane that waits until *word >= need (bounded: sets the abort word on a time-out): holds a stream back until
-// the producers of another, still running launch have delivered
-__global__ void __launch_bounds__(64)
-flag_gate_kernel(unsigned *word, unsigned need, unsigned *abort_word, unsigned code)
-{
-    if (threadIdx.x == 0) (void)wait_ge<false>(word, need, abort_word, code);
-}
-
-void launch_flag_gate(unsigned *word, unsigned need, unsigned *abort_word, unsigned code, hipStream_t s)
-{
-    hipLaunchKernelGGL(flag_gate_kernel, dim3(1), dim3(64), 0, s, word, need, abort_word, code);
-}
-
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
                           double *out, hipStream_t s)
 {

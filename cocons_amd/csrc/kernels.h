@@ -172,14 +172,13 @@ bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int t
                    int skew = 0,           // packed band buffer (band_index; with band_hi / ext0): A is its unshifted base
                    const UpdRedirect *redir = nullptr);
 // near / near_tiles (lower_only launches): the tiles in the first near_tiles tile columns -- the next panel -- are stored
-// write-through and each adds 1 to *near when done; update_near_count() says how many there are.  A stream that has
-// passed launch_flag_gate(near, count, ...) may read them although the update launch is still running.
+// write-through and each adds 1 to *near when done; update_near_count() says how many there are (the strips of panel mode 2
+// wait for that count inside the launch).
 unsigned update_near_count(int ti0, int ti1, int near_tiles);
 // waves per workgroup of the trailing-update kernel: 4 (default) or 8 (512 threads, KC = 16: half the tile latency)
 void set_update_waves(int nw);
 void set_update_w8_max_tiles(int ntiles);
 void set_update_w8_inpanel(int on);     // ... only for launches of at most this many tiles (0 = every launch)
-void launch_flag_gate(unsigned *word, unsigned need, unsigned *abort_word, unsigned code, hipStream_t s);
 // like launch_update but the (i,k) and (j,k) operands come from a separate packed
 // panel buffer P (ldp rows, row index = global row), used by the sharded path.
 // (ptiles, world, rank): when world > 1 only tile columns tj with (tj / ptiles) % world == rank

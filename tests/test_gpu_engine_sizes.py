@@ -2,10 +2,14 @@
 engine, the dynamic tile order, the GEMM panel) -- every entry point against the CPU oracle, which still finishes in
 seconds at n = 1024 ... 4096.  Closes the thin spots of the small-n tests (tests/test_gpu_parity.py run n = 260 ... 700,
 where the plain schedule is used).  The autouse fixture in conftest.py asserts that no hand-off timed out."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+ENGINE_OFF = os.environ.get("COCONS_ENGINE", "1") == "0"      # (tools/gpu_switch_matrix.sh runs the suite that way too)
 
 N2LL_RTOL = 1e-8
 
@@ -31,7 +35,7 @@ def test_c5_shifted_grid_n2048_vs_oracle(oracle):
     Xp = wl.design_from_locs(lp, sc["mean.vector"], sc["sd.vector"])["std.covs"]
     fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
     got = ca.cocoPredict_dense(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS, z, fit=fit)
-    assert fit.engine_state()["active"]
+    assert fit.engine_state()["active"] or ENGINE_OFF
     want = oracle.cocoPredict_dense(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS, z)
     assert np.allclose(got["systematic"], want["systematic"], rtol=1e-13, atol=0)
     assert np.max(np.abs(got["stochastic"] - want["stochastic"])) < 1e-9 * np.max(np.abs(want["stochastic"]))
@@ -56,7 +60,7 @@ def test_profile_and_reml_n4096_q3_vs_oracle(oracle):
     lam = (0.1, 0.0, 0.3)
     fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, x_betas=X)
     got = ca.GetNeg2loglikelihoodProfile(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam, fit=fit)
-    assert fit.engine_state()["active"]
+    assert fit.engine_state()["active"] or ENGINE_OFF
     want = oracle.GetNeg2loglikelihoodProfile(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam)
     assert abs(got - want) <= N2LL_RTOL * abs(want)
     got = ca.GetNeg2loglikelihoodREML(tv, pp, locs, X, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
@@ -117,7 +121,7 @@ def test_fuzz_random_parameters_n1024_r3(oracle):
             continue
         worst = max(worst, abs(got - want) / abs(want))
     assert worst <= N2LL_RTOL, worst
-    assert nfail < 5 and used_engine == 12
+    assert nfail < 5 and (used_engine == 12 or ENGINE_OFF)
 
 
 def test_taper_objective_n10000_vs_host_sparse_lu(oracle):
