@@ -117,3 +117,16 @@ def test_glue_compiles_against_declared_apis():
                         "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "glue", "cocons_hip_glue.c")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-4000:]
+
+
+def test_panel_ownership_deal_matches_the_python_twin():
+    """cocons_shard_panel_owner (no GPU call): panels are dealt in groups of COCONS_SHARD_GROUP consecutive panels
+    (default 4), owner(k) = (k div G) mod world -- the same deal the gloo twin's numpy engine uses (tests/np_shard_engine.py)."""
+    from cocons_amd import _lib
+    lib = _lib.load()
+    g = int(os.environ.get("COCONS_SHARD_GROUP", "4"))
+    for world in (1, 2, 3, 8):
+        owners = [lib.cocons_shard_panel_owner(k, world) for k in range(40)]
+        assert owners == [(k // g) % world for k in range(40)]
+        assert all(0 <= o < world for o in owners)
+    assert lib.cocons_shard_panel_owner(-1, 2) == -1 and lib.cocons_shard_panel_owner(0, 0) == -1
