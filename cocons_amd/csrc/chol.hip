@@ -136,17 +136,20 @@ __device__ __forceinline__ double rdlane(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
-// l = sqrt(a), r = 1/sqrt(a) for a normal positive a (pivots of an SPD matrix); both to
-// about 1 ulp: v_rsq_f64 seed, two Newton steps on r, one correction of l.
+// l = sqrt(a), r = 1/sqrt(a) for a normal positive a (pivots of an SPD matrix); both to about 1 ulp.  v_rsq_f64 delivers
+// 24 bits (measured: tools/diag/seed_precision.hip, max relative error 2^-24.2), so ONE third-order step
+//     y = y0 (1 + t/2 + 3 t^2/8),   t = 1 - a y0^2        (truncation 5/16 t^3 < 2^-70)
+// gives r after four dependent operations -- r is what the pivot chain of potrf16_step waits for -- and l = a y with one
+// Heron correction follows off the chain.  (Rounds 1-2 ran two Newton steps and two corrections: r came out last, after
+// eleven dependent operations, sixteen times per 16 x 16 block on the one wave every diagonal tile waits for.)
 __device__ __forceinline__ void rsqrt_pivot(double a, double &l, double &r)
 {
-    double y = __builtin_amdgcn_rsq(a);
-    double h = 0.5 * a;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
+    const double y0 = __builtin_amdgcn_rsq(a);
+    const double s0 = a * y0;
+    const double t = fma(-s0, y0, 1.0);
+    const double y = fma(y0 * t, fma(t, 0.375, 0.5), y0);
     double s = a * y;
     s = fma(fma(-s, s, a), 0.5 * y, s);      // s + (a - s^2) / (2 s)
-    y = fma(fma(-s, y, 1.0), y, y);          // y + y (1 - s y)
     l = (a > 0.0) ? s : __builtin_nan("");   // non-positive pivot: propagate NaN like sqrt would
     r = (a > 0.0) ? y : __builtin_nan("");
 }

@@ -51,14 +51,14 @@ __device__ __forceinline__ double kahan(double a, double b, double c, double d)
     return res - err;
 }
 
-// 1/x for moderate x: v_rcp_f64 seed + two Newton steps (|rel err| ~ 1e-16; no scaling,
-// the operands below are O(1)..O(1e3))
+// 1/x for moderate x: v_rcp_f64 seed (24 bits, measured: tools/diag/seed_precision.hip) + ONE third-order step
+// r (1 + e + e^2), e = 1 - x r (truncation e^3 < 2^-72; |rel err| ~ 1e-16; no scaling, the operands below are
+// O(1)..O(1e3)) -- three dependent operations where two Newton steps took four
 __device__ __forceinline__ double fast_rcp(double x)
 {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(fma(e, e, e), r, r);
 }
 
 // 2^a e^-u for |a| < 1000, 0 <= u < 1100, in ONE exponential: u = n_u ln 2 + r (Cody-Waite, r exact to ~1e-17), a = n_a + f_a
