@@ -850,6 +850,8 @@ struct Tunables {
     int strip_min = 3600;    // COCONS_STRIP_MIN
     int upd_dynamic = 1;     // COCONS_UPD_DYNAMIC
     int engine_fused = 0;    // COCONS_ENGINE_FUSED: the engine's fused pass over a diagonal block (potrf_block_fused)
+    int gate_sabotage = 0;   // (tests) the next N engine-schedule factorisations wait at the gate for a word nobody raises:
+                             // a genuine 5 ms time-out, abort code 0x600, to exercise the fall-back and its book-keeping
     bool init = false;
 };
 static Tunables &tun()
@@ -880,6 +882,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "strip_min") t.strip_min = value;
     else if (k == "upd_dynamic") t.upd_dynamic = value;
     else if (k == "engine_fused") t.engine_fused = value;
+    else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
     else return fail(-1, "cocons_debug_tune: unknown switch %s", name);
@@ -1100,7 +1103,9 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
     unsigned *near = f->dflags + 4 * (size_t)f->flags_cap + 64;
     unsigned *abort_word = (unsigned *)(f->dinfo + 1);
-    launch_engine_gate(f->dflags + 3 * (size_t)f->flags_cap, abort_word, M);
+    unsigned *alive = f->dflags + 3 * (size_t)f->flags_cap;
+    if (tun().gate_sabotage > 0) { --tun().gate_sabotage; alive += 1; }      // (tests: a word that stays zero)
+    launch_engine_gate(alive, abort_word, M);
     panel_ops(f, v, 0, M);
     // (Running the panel kernels on a stream of their own behind near-tile flags, so that they start in the tail of the
     // update that feeds them, was built and measured in round 3: slower -- a 90 KB-LDS solve is not placed beside eight

@@ -163,3 +163,41 @@ def test_taper_objective_n10000_vs_host_sparse_lu(oracle):
     want = n * np.log(2 * np.pi) + logdet + quad
     assert abs(got - want) <= N2LL_RTOL * abs(want)
     assert abs(2 * parts[0] - logdet) <= 1e-9 * abs(logdet) and abs(parts[1] - quad) <= 1e-8 * abs(quad)
+
+
+@pytest.mark.shared_gpu          # (exempt from the autouse "no time-out" check: this test provokes one on purpose)
+def test_engine_timeout_is_survived_counted_and_backed_off():
+    """A genuine hand-off time-out (the gate kernel is made to wait for a word nobody raises: 5 ms, abort code 0x600) must
+    cost ONE evaluation its engine schedule and nothing else: the value is the plain schedule's, the time-out is counted and
+    its code kept (cocons_fit_engine_state), two operations -- the repeat of this one and the next -- take the plain schedule
+    (back-off, doubling with consecutive time-outs), then the engine is used again.  Round 2's fall-back was silent and
+    permanent."""
+    import cocons_amd as ca
+    from cocons_amd import _lib, workloads as wl
+    if ENGINE_OFF:
+        pytest.skip("COCONS_ENGINE=0")
+    L = _lib.load()
+    locs, sc = _grid(48)                         # n = 2304: 18 tiles, engine schedule
+    X = sc["std.covs"]
+    z = wl.synthetic_z(locs.shape[0])
+    th = wl.theta_full()
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    try:
+        v0 = fit.neg2loglik_core(th)[0]
+        st = fit.engine_state()
+        assert st == {"active": True, "retries": 0, "last_abort": 0}
+        _lib.check(L.cocons_debug_tune(b"gate_sabotage", 1), "tune")
+        v1 = fit.neg2loglik_core(th)[0]
+        st = fit.engine_state()
+        assert st["retries"] == 1 and st["last_abort"] == 0x600 and not st["active"], st
+        assert abs(v1 - v0) <= 1e-12 * abs(v0)
+        # back-off after the first time-out: 2 operations on the plain schedule, the repeat inside the call above being one
+        assert abs(fit.neg2loglik_core(th)[0] - v0) <= 1e-12 * abs(v0)
+        assert not fit.engine_state()["active"]
+        v4 = fit.neg2loglik_core(th)[0]
+        st = fit.engine_state()
+        assert st["active"] and st["retries"] == 1, st
+        assert abs(v4 - v0) <= 1e-12 * abs(v0)
+    finally:
+        L.cocons_debug_tune(b"gate_sabotage", 0)
+        fit.close()
