@@ -139,6 +139,17 @@ def main():
     dist = None
     ctl = None          # gloo group: rendezvous of the RCCL unique id, barriers, timing -- never a panel
     if world > 1:
+        # A rank stuck in a collective (a peer died, a link is down) must end the run, loudly, not sit there until
+        # somebody else's time-out: every rank arms a watchdog that kills it -- non-zero exit, no JSON -- when the whole
+        # multi-GPU bench (normally well under a minute) has not finished in COCONS_BENCH_WATCHDOG_S seconds (default 300).
+        import threading
+
+        def _watchdog(limit=float(os.environ.get("COCONS_BENCH_WATCHDOG_S", "300"))):
+            time.sleep(limit)
+            sys.stderr.write("bench.py: rank %d still running after %.0f s -- a collective is stuck; giving up\n" % (rank, limit))
+            sys.stderr.flush()
+            os._exit(4)
+        threading.Thread(target=_watchdog, daemon=True).start()
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
