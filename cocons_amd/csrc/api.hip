@@ -806,6 +806,8 @@ struct FactorView {
     const int *hi = nullptr;   // band-limited factorisation (taper handles): hi[c] = one past the last tile row of tile
                                // column c that can be non-zero in the factor (envelope of the pattern); nullptr = dense
     int skew = 0;              // > 0: A is a packed band buffer (kernels.h band_index) of `skew` tile rows per tile column
+    int trim = 0;              // 1: the last 64 of the mt * 128 rows hold nothing (the tile of right-hand sides has at most 64
+                               // rows in use): no kernel of the factorisation touches them
 };
 
 static FactorView main_view(cocons_fit *f)
@@ -838,11 +840,13 @@ static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
     const int hb = band_hi(v, k);                       // rows [.., hb) of the band, then the rows under the matrix [nt, mt)
     const int br = hb >= 0 ? hb * TILE : -1, er = nt * TILE;
     launch_potrf_tile(A, lda, k * TILE, q0, f->dinfo, s);
-    launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, mt * TILE, q0, s, nullptr, nullptr, br, er);
+    const int r1 = mt * TILE - 64 * v.trim;
+    launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, r1, q0, s, nullptr, nullptr, br, er);
     if (k + 1 < nt) {
-        launch_update(A, lda, k * TILE, TILE, k + 1, mt, k + 1, k + 2, true, s, nullptr, -1, nullptr, nullptr, nullptr, hb, nt);
+        launch_update(A, lda, k * TILE, TILE, k + 1, mt, k + 1, k + 2, true, s, nullptr, -1, nullptr, nullptr, nullptr, hb, nt,
+                      nullptr, 0, nullptr, 0, nullptr, v.trim);
         launch_potrf_tile(A, lda, (k + 1) * TILE, q1, f->dinfo, s);
-        launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, mt * TILE, q1, s, nullptr, nullptr, br, er);
+        launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, r1, q1, s, nullptr, nullptr, br, er);
     }
 }
 
@@ -917,7 +921,7 @@ static bool timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int 
         hipEventRecord(a, s);
     }
     const bool took = launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, abort_word,
-                                    queue, hb, v.nt, near, near_tiles, strips, 0, redir);
+                                    queue, hb, v.nt, near, near_tiles, strips, 0, redir, v.trim);
     if (ev_upd) {
         hipEventRecord(b, s);
         ev_upd->push_back(a); ev_upd->push_back(b);
@@ -1086,10 +1090,11 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
                 double *Ak = band_base(v.A, k, v.skew);
                 const int e0 = v.skew ? k + v.skew : nt, e1 = e0 + (mt - nt);      // tile rows under the matrix
                 launch_potrf_tile(Ak, v.lda, k * TILE, q, f->dinfo, M);
-                launch_trsm_tile(Ak, v.lda, k * TILE, (k + 1) * TILE, e1 * TILE, q, M, nullptr, nullptr, hb * TILE, e0 * TILE);
+                launch_trsm_tile(Ak, v.lda, k * TILE, (k + 1) * TILE, e1 * TILE - 64 * v.trim, q, M, nullptr, nullptr, hb * TILE,
+                                 e0 * TILE);
                 if (k + 1 < nt)
                     launch_update(v.A, v.lda, k * TILE, TILE, k + 1, mt, k + 1, hb < nt ? hb : nt, true, M, nullptr, -1,
-                                  nullptr, nullptr, nullptr, hb, nt, nullptr, 0, nullptr, v.skew);
+                                  nullptr, nullptr, nullptr, hb, nt, nullptr, 0, nullptr, v.skew, nullptr, v.trim);
             }
             return 0;
         }
@@ -1117,6 +1122,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     // update workgroups per CU, the event back to the main stream costs 12 us -- and removed)
     hipStream_t P = M;
     const int w_until = panel_w_until(v);
+    const int rend = mt * TILE - 64 * v.trim;         // one past the last row any panel kernel touches
     for (int k = 0; k + 2 < nt; k += 2) {
         const int t = k + 2;
         const bool two = t + 1 < nt;                 // the block has a second tile
@@ -1131,28 +1137,28 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
             UpdRedirect rd;
             rd.pin = f->dpin; rd.row_tile0 = r0;
             timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), nullptr, near_tiles, nullptr, &rd);
-            launch_panel_gemm(v.A, v.lda, t, r0 * TILE, mt * TILE, f->dpin, f->dwfull, xr + t, abort_word, M);
+            launch_panel_gemm(v.A, v.lda, t, r0 * TILE, rend, f->dpin, f->dwfull, xr + t, abort_word, M);
             continue;
         }
         if (with_w && panel_mode() == 2 && !f->engine_w3) {
             // the panel's strips are tasks of U(k) itself: nothing to launch behind it
             UpdStrips us;
-            us.nstrips = (mt - r0) * 2; us.row0 = r0 * TILE; us.lead = strip_lead();
+            us.nstrips = (mt - r0) * 2 - v.trim; us.row0 = r0 * TILE; us.lead = strip_lead();
             us.winv = f->dwinv; us.out = out; us.xr = xr;
             if (!timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), near + t, near_tiles, &us))
-                launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, mt * TILE, f->dwinv, out, xr, abort_word, M);
+                launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, rend, f->dwinv, out, xr, abort_word, M);
             continue;
         }
         timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), nullptr, near_tiles);
         if (with_w && !f->engine_w3) {
-            launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, mt * TILE, f->dwinv, out, xr, abort_word, P);
+            launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, rend, f->dwinv, out, xr, abort_word, P);
         } else {
-            launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, mt * TILE, f->dinv + (size_t)(t & 1) * 2048, P,
+            launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048, P,
                              out + t, abort_word, br, er);
             if (two) {
                 launch_update(v.A, v.lda, t * TILE, TILE, r0, mt, t + 1, t + 2, false, P, nullptr, -1, xr + t, abort_word,
-                              nullptr, hb, nt);
-                launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, r0 * TILE, mt * TILE,
+                              nullptr, hb, nt, nullptr, 0, nullptr, 0, nullptr, v.trim);
+                launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, r0 * TILE, rend,
                                  f->dinv + (size_t)((t + 1) & 1) * 2048, P, out + t + 1, abort_word, br, er);
             }
         }
@@ -1191,7 +1197,9 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
         if (int rc = engine_start(f, main_view(f))) return rc;
     assemble_rhs(f, mean, use_trend, xb, nxb, 0, f->npad, zero_rest);
     if (stage_events) hipEventRecord(f->ev[1], f->stream);
-    if (int rc = factorize(f, main_view(f), ev_upd)) return rc;
+    FactorView fv = main_view(f);
+    fv.trim = (f->rhs_act - nrhs >= 64) ? 1 : 0;      // at most 64 of the 128 rows under the matrix are in use
+    if (int rc = factorize(f, fv, ev_upd)) return rc;
     if (stage_events) hipEventRecord(f->ev[2], f->stream);
     launch_finalize(f->dA, f->lda, f->n, f->npad, nrhs, f->dout, f->stream, f->skew, f->npad);
     HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, (size_t)(2 + nrhs * nrhs) * sizeof(double),       // info words + outputs

@@ -1951,12 +1951,16 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig, int sig_tile,
                         unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
-                        unsigned *near, int near_tiles, const UpdStrips *strips, int skew, int kblk, const UpdRedirect *redir)
+                        unsigned *near, int near_tiles, const UpdStrips *strips, int skew, int kblk, const UpdRedirect *redir,
+                        int trim64)
 {
     // tile rows [ti0, ti1), or -- band-limited -- [ti0, band_hi) and [ext0, ti1)
     const bool band = band_hi >= 0;
     const int rows_band = (band ? band_hi : ti1) - ti0, rows_ext = band ? ti1 - ext0 : 0;
     if (rows_band + rows_ext <= 0 || rows_band < 0 || rows_ext < 0 || tj1 <= tj0 || K <= 0) return false;
+    trim64 = trim64 ? 1 : 0;
+    const int rows64 = 2 * (rows_band + rows_ext) - trim64;        // 64-row tiles the launch covers
+    if (rows64 <= 0) return false;
     if (upd_waves < 0) { const char *e = getenv("COCONS_UPD_WAVES"); set_update_waves(e ? atoi(e) : 8); }
     if (upd_w8_max_tiles < 0) { const char *e = getenv("COCONS_UPD_W8_MAX_TILES"); set_update_w8_max_tiles(e ? atoi(e) : 3500); }
     bool use_w8 = false;
@@ -1983,12 +1987,12 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     // 64 x 64 tiles throughout (the 128 x 128 shape measured 31 TFLOP/s against 50): tile indices in
     // units of 64 from here on
     a.ti0 = 2 * ti0; a.tj0 = 2 * tj0;
-    dim3 grid(2 * (rows_band + rows_ext), 2 * (tj1 - tj0));
+    dim3 grid(rows64, 2 * (tj1 - tj0));
     if (lower_only) {
         // requires ti0 >= tj0 == first column: the trapezoid rows tj0..ti1, columns tj0..tj1
         if (ti0 != tj0) { a.lower_only = 0; }    // strictly-below rectangle: every tile does work
         else {
-            const long long H = 2LL * (rows_band + rows_ext), W = 2LL * (tj1 - tj0);
+            const long long H = rows64, W = 2LL * (tj1 - tj0);
             a.H = (int)H; a.W = (int)W;
             long long total = W * H - W * (W - 1) / 2;
             static int slots = 0;
@@ -2002,7 +2006,7 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
             if (strips && strips->nstrips > 0 && near && !band && world == 1 && !upd_form4() &&
                 (queue || total + strips->nstrips <= slots - 8)) {
                 // the next panel's strips ride in this launch, `lead` tiles behind the near tiles (time for the engine)
-                const long long nnear = (long long)update_near_count(ti0, ti1, near_tiles);
+                const long long nnear = (long long)update_near_count(ti0, ti1, near_tiles) - 2LL * near_tiles * trim64;
                 long long pos = nnear + strips->lead;
                 if (pos > total) pos = total;
                 a.nstrips = strips->nstrips; a.strip_pos = (unsigned)pos; a.near_need = (unsigned)nnear;
@@ -2052,10 +2056,11 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
 bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig, int sig_tile,
                    unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
-                   unsigned *near, int near_tiles, const UpdStrips *strips, int skew, const UpdRedirect *redir)
+                   unsigned *near, int near_tiles, const UpdStrips *strips, int skew, const UpdRedirect *redir, int trim64)
 {
     return launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile,
-                              wait_word, abort_word, queue, band_hi, ext0, near, near_tiles, strips, skew, k0 / TILE, redir);
+                              wait_word, abort_word, queue, band_hi, ext0, near, near_tiles, strips, skew, k0 / TILE, redir,
+                              trim64);
 }
 
 // tiles of 64 x 64 in the first `near_tiles` (128-wide) tile columns of the trapezoid launch_update(..., lower_only, ti0 ==

@@ -170,7 +170,9 @@ bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int t
                    int band_hi = -1, int ext0 = 0,       // band_hi >= 0: tile rows [ti0, band_hi) and [ext0, ti1)
                    unsigned *near = nullptr, int near_tiles = 0, const UpdStrips *strips = nullptr,
                    int skew = 0,           // packed band buffer (band_index; with band_hi / ext0): A is its unshifted base
-                   const UpdRedirect *redir = nullptr);
+                   const UpdRedirect *redir = nullptr,
+                   int trim64 = 0);        // 1: the last 64 rows of the row range hold nothing (a 128-row tile of right-hand
+                                           // sides of which at most 64 rows are used): they are not updated
 // near / near_tiles (lower_only launches): the tiles in the first near_tiles tile columns -- the next panel -- are stored
 // write-through and each adds 1 to *near when done; update_near_count() says how many there are (the strips of panel mode 2
 // wait for that count inside the launch).
@@ -188,7 +190,8 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
                         int ptiles, int world, int rank, unsigned *sig = nullptr, int sig_tile = -1,
                         unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
                         int band_hi = -1, int ext0 = 0, unsigned *near = nullptr, int near_tiles = 0,
-                        const UpdStrips *strips = nullptr, int skew = 0, int kblk = 0, const UpdRedirect *redir = nullptr);
+                        const UpdStrips *strips = nullptr, int skew = 0, int kblk = 0, const UpdRedirect *redir = nullptr,
+                        int trim64 = 0);
 
 
 // reductions: out[0] = sum_{i<n} log(A(i,i)); out[1 + a*nr + b] = sum_{c<n} A(row0+a,c) A(row0+b,c)
