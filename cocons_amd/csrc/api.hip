@@ -247,6 +247,9 @@ struct cocons_fit {
     int pred_cap;
     // sharded state
     int rank, world, nrhs_cur;
+    int n_user, pad0;             // n = pad0 + n_user: dense handles keep pad0 = npad - n_user placeholder observations IN FRONT
+                                  // of the caller's (their columns are made unit vectors before every factorisation,
+                                  // launch_front_identity), so that n == npad and no padding sits in the trailing matrix
     double *xbuf[2];
     size_t xbuf_bytes;
     bool xbuf_own;
@@ -446,12 +449,6 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
             }
         }
     }
-    auto permute_cols = [&](const double *src, int ncol) {
-        std::vector<double> out((size_t)n * ncol);
-        for (int c = 0; c < ncol; ++c)
-            for (int i = 0; i < n; ++i) out[(size_t)i + (size_t)c * n] = src[(size_t)perm[i] + (size_t)c * n];
-        return out;
-    };
     f->h_locs = new std::vector<double>(locs, locs + (size_t)2 * n);      // host copies: ORIGINAL order
     f->h_X = new std::vector<double>(X, X + (size_t)n * p);
     f->h_z = new std::vector<double>();
@@ -459,12 +456,34 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     f->sorted = false;
     for (int i = 0; i < n; ++i)
         if (perm[i] != i) { f->sorted = true; break; }
-    std::vector<double> plocs = permute_cols(locs, 2), pX = permute_cols(X, p), pz, pxb;
-    if (r > 0) pz = permute_cols(z, r);
-    if (q > 0) pxb = permute_cols(x_betas, q);
+    // Identity padding in FRONT (handles whose internal order is theirs to choose, i.e. allow_sort): pad0 placeholder
+    // observations (copies of the first one; their rows and columns are overwritten by unit vectors before every
+    // factorisation) precede the caller's, so that the internal problem has exactly npad = n observations and no padding
+    // rides through every trailing update.  Order-dependent entry points then go through the unsorted twin, like after a
+    // Morton sort.  COCONS_FRONT_PAD=0: padding behind the observations (rounds 1-2).
+    f->n_user = n;
+    {
+        const char *e = getenv("COCONS_FRONT_PAD");
+        f->pad0 = (allow_sort && (e ? atoi(e) : 1)) ? f->npad - n : 0;
+    }
+    const int pad0 = f->pad0, nint = n + pad0;
+    if (pad0 > 0) f->sorted = true;
+    auto permute_pad = [&](const double *src, int ncol, bool zero_pad) {
+        std::vector<double> out((size_t)nint * ncol);
+        for (int c = 0; c < ncol; ++c) {
+            for (int i = 0; i < pad0; ++i) out[(size_t)i + (size_t)c * nint] = zero_pad ? 0.0 : src[(size_t)perm[0] + (size_t)c * n];
+            for (int i = 0; i < n; ++i) out[(size_t)(pad0 + i) + (size_t)c * nint] = src[(size_t)perm[i] + (size_t)c * n];
+        }
+        return out;
+    };
+    std::vector<double> plocs = permute_pad(locs, 2, false), pX = permute_pad(X, p, false), pz, pxb;
+    if (r > 0) pz = permute_pad(z, r, true);
+    if (q > 0) pxb = permute_pad(x_betas, q, true);
     locs = plocs.data(); X = pX.data();
     if (r > 0) z = pz.data();
     if (q > 0) x_betas = pxb.data();
+    n = nint;                     // from here on: the internal problem
+    f->n = n;
     CK(hipMalloc(&f->dX, (size_t)n * p * sizeof(double)));
     CK(hipMalloc(&f->dlocs, (size_t)n * 2 * sizeof(double)));
     CK(hipMemcpyAsync(f->dX, X, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice, f->stream));
@@ -933,7 +952,8 @@ static bool timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int 
 // trailing block of order m (real columns only) times K, plus the rhs rows:  K m (m+1) + 2 K r m
 static void count_update_flops(cocons_fit *f, int kw, int t0)
 {
-    double m = (double)f->n - (double)t0 * TILE;
+    double m = (double)f->n_user - ((double)t0 * TILE - (double)f->pad0);      // the caller's rows and columns from t0 on
+    if (m > (double)f->n_user) m = (double)f->n_user;
     if (m < 0) m = 0;
     const double K = (double)kw * TILE;
     f->upd_flops += K * m * (m + 1.0) + 2.0 * K * (double)f->nrhs_cur * m;
@@ -1073,6 +1093,10 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
 {
     const int nt = v.nt, mt = v.mt;
     hipStream_t M = f->stream;
+    // the placeholder observations in front (fit_create_impl): whatever the assembly kernels put into their columns --
+    // covariances, right-hand sides, cross-covariance rows -- is replaced by unit vectors, in every view whose first
+    // indices are the handle's observations
+    launch_front_identity(v.A, v.lda, f->pad0, mt * TILE, M);
     if (!engine_wanted(f, v)) {
         f->engine_used = false;
         if (int rc = flags_reset(f, nt)) return rc;
@@ -1223,7 +1247,9 @@ static int info_status(cocons_fit *f)
     else if (f->engine_skip > 0) --f->engine_skip;
     int info = f->hinfo[0];
     if (info != 0x7f7f7f7f) {
-        if (info > f->n) info = f->n;   // failure reported inside the identity padding cannot happen; clamp anyway
+        info -= f->pad0;                // (minors are counted in the handle's internal order, behind its front padding)
+        if (info < 1) info = 1;
+        if (info > f->n_user) info = f->n_user;   // failure reported inside the identity padding cannot happen; clamp anyway
         g_err = "leading minor not positive";
         return info;
     }
@@ -1290,7 +1316,7 @@ static void dense_collect(cocons_fit *f, double *sum_logliks, double *parts)
     double logdet = f->hout[0], total = 0.0;
     for (int k = 0; k < nr; ++k) {                                   // R/neg2loglikelihood.R:212-218
         double quad = f->hout[1 + k * nr + k];
-        total += f->n * LOG_2PI + 2 * logdet + quad;
+        total += f->n_user * LOG_2PI + 2 * logdet + quad;
         if (parts) parts[1 + k] = quad;
     }
     if (parts) parts[0] = logdet;
@@ -1310,9 +1336,9 @@ static void dense_collect(cocons_fit *f, double *sum_logliks, double *parts)
 static cocons_fit *clone_for_slot(cocons_fit *f)
 {
     if (f->taper_nnz <= 0)
-        return cocons_fit_create(f->n, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
+        return cocons_fit_create(f->n_user, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
                                  f->smooth_limits, f->device);
-    cocons_fit *c = fit_create_impl(f->n, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
+    cocons_fit *c = fit_create_impl(f->n_user, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
                                     f->smooth_limits, f->device, false, true);      // h_* of a taper handle are in ITS order
     if (!c) return nullptr;
     c->skew = f->skew;                        // the same (packed) buffer layout as the original
@@ -1494,7 +1520,7 @@ extern "C" int cocons_neg2loglik_profile(cocons_fit *f, const double *theta, dou
         if (st) return st;
         break;
     }
-    return profile_tail(f, f->q, (double)f->n, false, sum_logliks, parts);   // R/neg2loglikelihood.R:155-160
+    return profile_tail(f, f->q, (double)f->n_user, false, sum_logliks, parts);   // R/neg2loglikelihood.R:155-160
 }
 
 extern "C" int cocons_neg2loglik_reml(cocons_fit *f, const double *theta, int rank, double *sum_logliks, double *parts)
@@ -1511,7 +1537,7 @@ extern "C" int cocons_neg2loglik_reml(cocons_fit *f, const double *theta, int ra
         if (st) return st;
         break;
     }
-    return profile_tail(f, f->p, (double)(f->n - rank), true, sum_logliks, parts);   // :283-287
+    return profile_tail(f, f->p, (double)(f->n_user - rank), true, sum_logliks, parts);   // :283-287
 }
 
 // ---------------------------------------------------------------------------
@@ -1737,7 +1763,7 @@ extern "C" int cocons_cov_rows(cocons_fit *f, const double *theta, int classic, 
     if (int rc = fit_check(f)) return rc;
     if (int rc = no_taper(f, "cocons_cov_rows")) return rc;
     if (!theta || nidx <= 0 || !idx || !out) return fail(-1, "cocons_cov_rows: bad argument");
-    const int n = f->n, p = f->p;
+    const int n = f->n_user, p = f->p;          // (works on the host copies: the caller's observations in the caller's order)
     for (int b = 0; b < nidx; ++b)
         if (idx[b] < 0 || idx[b] >= n) return fail(-1, "cocons_cov_rows: row index out of range (0-based)");
     ThetaVecs tv;
@@ -1960,7 +1986,7 @@ extern "C" int cocons_sim_dense(cocons_fit *f, const double *theta, const double
         // L E depends on the ORDER of the observations (the factor of a permuted matrix is not the
         // permuted factor): the field for given draws is only reproduced in the caller's order
         if (!f->unsorted) {
-            f->unsorted = fit_create_impl(f->n, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(),
+            f->unsorted = fit_create_impl(f->n_user, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(),
                                           f->r > 0 ? f->h_z->data() : nullptr, nullptr, f->smooth_limits,
                                           f->device, false);
             if (!f->unsorted) return -1;
@@ -2137,8 +2163,8 @@ extern "C" int cocons_chol_solve(int n, const double *Ain, int nrhs, const doubl
     // reuse the fit machinery with a dummy 1-column design
     std::vector<double> locs((size_t)2 * n, 0.0), X((size_t)n, 1.0);
     double sl[2] = {0.5, 0.5};
-    cocons_fit *f = cocons_fit_create(n, 1, 0, 0, locs.data(), X.data(), nullptr, nullptr, sl, -1);
-    if (!f) return -1;
+    cocons_fit *f = fit_create_impl(n, 1, 0, 0, locs.data(), X.data(), nullptr, nullptr, sl, -1, false);   // caller's order,
+    if (!f) return -1;                                                                                       // padding behind
     f->engine_ok = false;     // one-shot handle whose input is uploaded once: plain schedule
     int rc = 0;
     do {
@@ -2283,6 +2309,7 @@ extern "C" int cocons_shard_panel_factor(cocons_fit *f, int k)
     const int t0 = k * PT;
     hipStream_t s = f->stream;
     double *A = f->dA;
+    if (k == 0) launch_front_identity(A, f->lda, f->pad0, mt * TILE, s);      // (see factorize; pad0 < 128: inside panel 0)
     launch_potrf_tile(A, f->lda, t0 * TILE, f->dinv, f->dinfo, s);
     launch_trsm_tile(A, f->lda, t0 * TILE, (t0 + 1) * TILE, mt * TILE, f->dinv, s);
     int w = 1;
@@ -2536,14 +2563,16 @@ static int sharded_eval_impl(cocons_fit *f, const double *theta, const double *m
     }
     if (minfo != (double)0x7f7f7f7f) {
         int st = (int)minfo;
-        if (st > f->n) st = f->n;
+        st -= f->pad0;
+        if (st < 1) st = 1;
+        if (st > f->n_user) st = f->n_user;
         g_err = "leading minor not positive";
         return st;
     }
     double total = 0.0;
     for (int c = 0; c < nr; ++c) {
         const double quad = part[1 + c * nr + c];
-        total += f->n * LOG_2PI + 2 * part[0] + quad;
+        total += f->n_user * LOG_2PI + 2 * part[0] + quad;
         if (parts) parts[1 + c] = quad;
     }
     if (parts) parts[0] = part[0];
@@ -2653,12 +2682,14 @@ extern "C" int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *thet
     }
     if (info_min != 0x7f7f7f7f) {
         g_err = "leading minor not positive";
-        return info_min > f0->n ? f0->n : info_min;
+        info_min -= f0->pad0;
+        if (info_min < 1) info_min = 1;
+        return info_min > f0->n_user ? f0->n_user : info_min;
     }
     double total = 0.0;
     for (int c = 0; c < nr; ++c) {
         const double quad = tot[1 + c * nr + c];
-        total += f0->n * LOG_2PI + 2 * tot[0] + quad;
+        total += f0->n_user * LOG_2PI + 2 * tot[0] + quad;
         if (parts) parts[1 + c] = quad;
     }
     if (parts) parts[0] = tot[0];

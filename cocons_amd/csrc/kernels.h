@@ -78,6 +78,7 @@ void launch_taper(int mode, bool pred, int nrows, int nnz, const int *ci, const 
 // zero the tiles inside the envelope (d_hi: device copy of FactorView::hi; max_band = max over c of hi[c] - c)
 void launch_band_zero(double *A, size_t lda, const int *d_hi, int nt, int max_band, hipStream_t s, int skew = 0);
 // identity on the padding diagonal of a taper handle's buffer
+void launch_front_identity(double *A, size_t lda, int pad0, int rows, hipStream_t s);   // columns [0, pad0): unit vectors
 void launch_pad_identity(double *A, size_t lda, int n, int npad, hipStream_t s, int skew = 0);
 void launch_cov_rows(int mode, int n, int nidx, const int *idx, const double *loc, size_t stride, double gr,
                      double nu_fixed, int cor, double *out, hipStream_t s);

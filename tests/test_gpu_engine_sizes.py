@@ -201,3 +201,57 @@ def test_engine_timeout_is_survived_counted_and_backed_off():
     finally:
         L.cocons_debug_tune(b"gate_sabotage", 0)
         fit.close()
+
+
+def test_front_padding_n2115_all_entry_points_vs_oracle(oracle):
+    """n = 45 x 47 = 2115 is not a multiple of 128: the handle keeps 61 placeholder observations IN FRONT of the caller's
+    (unit columns, api.hip fit_create_impl) instead of identity padding behind them.  Every entry point that runs on that
+    layout, on the engine schedule, against the CPU restatement: -2 loglik (two realisations), Profile and REML with q = 3,
+    the kriging core, and the status of a failing factorisation (reported in the caller's numbering)."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, sc = _grid(45, 47)
+    n = locs.shape[0]
+    assert n == 2115 and n % 128 != 0
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.2, -0.1, 0.05])
+    rng = np.random.default_rng(2115)
+    z = rng.standard_normal((n, 2)) + (X @ np.array([0.1, 0.4, -0.3]))[:, None]
+    pp = wl.par_pos_full()
+    pp["mean"] = [True] * 3
+    tv = np.concatenate([th["mean"], wl.theta_vector_from_lists(th, wl.par_pos_full())])
+    lam = (0.1, 0.0, 0.3)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, x_betas=X)
+    got = ca.GetNeg2loglikelihood(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    assert fit.engine_state()["active"] or ENGINE_OFF
+    want = oracle.GetNeg2loglikelihood(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam)
+    assert abs(got - want) <= 1e-11 * abs(want)
+    pq = wl.par_pos_full()
+    tq = wl.theta_vector_from_lists(th, pq)
+    got = ca.GetNeg2loglikelihoodProfile(tq, pq, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam, fit=fit)
+    want = oracle.GetNeg2loglikelihoodProfile(tq, pq, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam)
+    assert abs(got - want) <= N2LL_RTOL * abs(want)
+    got = ca.GetNeg2loglikelihoodREML(tq, pq, locs, X, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    want = oracle.GetNeg2loglikelihoodREML(tq, pq, locs, X, X, wl.SMOOTH_LIMITS, z, n, lam)
+    assert abs(got - want) <= N2LL_RTOL * abs(want)
+    lp = locs[:300] + np.array([0.4 / 44, 0.4 / 46])
+    Xp = wl.design_from_locs(lp, sc["mean.vector"], sc["sd.vector"])["std.covs"]
+    fit1 = ca.CoconsFit(locs, X, z[:, 0], wl.SMOOTH_LIMITS)
+    got = ca.cocoPredict_dense(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS, z[:, 0], fit=fit1)
+    want = oracle.cocoPredict_dense(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS, z[:, 0])
+    assert np.max(np.abs(got["stochastic"] - want["stochastic"])) < 1e-9 * np.max(np.abs(want["stochastic"]))
+    vg, vw = got["sd.pred"] ** 2, want["sd.pred"] ** 2
+    assert np.max(np.abs(vg - vw)) < 1e-11 * np.max(vw)
+    # a matrix that is not positive definite: two coincident locations without a nugget -- the failing minor is
+    # reported between 1 and n (the placeholder columns in front are not counted)
+    locs2 = locs.copy()
+    locs2[1500] = locs2[1499]
+    X2 = X.copy()
+    X2[1500] = X2[1499]
+    th2 = {k: np.array(v, dtype=float) for k, v in th.items()}
+    th2["nugget"] = np.array([-np.inf, 0.0, 0.0])
+    fit2 = ca.CoconsFit(locs2, X2, z[:, 0], wl.SMOOTH_LIMITS)
+    with pytest.raises(ca.CholeskyError) as ei:
+        fit2.neg2loglik_core(th2)
+    assert 1 <= ei.value.minor <= n
