@@ -748,6 +748,7 @@ static void assemble_sigma(cocons_fit *f, const double *theta, int which, int co
     pa.out = f->dA; pa.ld = f->lda;
     pa.nrows_out = f->npad; pa.ncols_out = col1;
     pa.bj0 = col0 / 64;
+    if (pa.bj0 < f->pad0 / 64) pa.bj0 = f->pad0 / 64;      // 64-wide tile rows / columns that are placeholders only: not assembled
     pa.gr = ms.gr; pa.nu_fixed = ms.nu_fixed;
     launch_pair_sym(ms.mode, false, pa, f->stream);
 }
@@ -939,8 +940,11 @@ static bool timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int 
         hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a, s);
     }
-    const bool took = launch_update(v.A, v.lda, k * TILE, kw * TILE, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr, abort_word,
-                                    queue, hb, v.nt, near, near_tiles, strips, 0, redir, v.trim);
+    // the first panel's leading columns are the unit vectors of the front padding (zero below the diagonal): they add
+    // nothing to the trailing matrix, so the update starts behind them (whole 16-column chunks; bit-identical)
+    const int kskip = (k == 0 && !v.hi && !update_alt_form()) ? (f->pad0 / 16) * 16 : 0;
+    const bool took = launch_update(v.A, v.lda, k * TILE + kskip, kw * TILE - kskip, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr,
+                                    abort_word, queue, hb, v.nt, near, near_tiles, strips, 0, redir, v.trim);
     if (ev_upd) {
         hipEventRecord(b, s);
         ev_upd->push_back(a); ev_upd->push_back(b);
@@ -955,7 +959,7 @@ static void count_update_flops(cocons_fit *f, int kw, int t0)
     double m = (double)f->n_user - ((double)t0 * TILE - (double)f->pad0);      // the caller's rows and columns from t0 on
     if (m > (double)f->n_user) m = (double)f->n_user;
     if (m < 0) m = 0;
-    const double K = (double)kw * TILE;
+    const double K = (double)kw * TILE - (t0 == kw ? (double)f->pad0 : 0.0);     // the first panel holds pad0 placeholder columns
     f->upd_flops += K * m * (m + 1.0) + 2.0 * K * (double)f->nrhs_cur * m;
 }
 

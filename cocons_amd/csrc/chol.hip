@@ -1946,6 +1946,7 @@ static bool upd_form4()
     if (form4 < 0) { const char *e = getenv("COCONS_UPD_MFMA4"); form4 = e ? atoi(e) : 0; }
     return form4 != 0;
 }
+bool update_alt_form() { return upd_form4(); }
 
 bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,

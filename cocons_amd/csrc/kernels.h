@@ -180,6 +180,7 @@ bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int t
 unsigned update_near_count(int ti0, int ti1, int near_tiles);
 // waves per workgroup of the trailing-update kernel: 4 (default) or 8 (512 threads, KC = 16: half the tile latency)
 void set_update_waves(int nw);
+bool update_alt_form();                 // COCONS_UPD_MFMA4=1: the alternative update kernel (K must be a multiple of 128)
 void set_update_w8_max_tiles(int ntiles);
 void set_update_w8_inpanel(int on);     // ... only for launches of at most this many tiles (0 = every launch)
 // like launch_update but the (i,k) and (j,k) operands come from a separate packed
