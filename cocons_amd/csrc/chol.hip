@@ -2035,7 +2035,7 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
             }
         }
     }
-    const bool trailing = (K >= 2 * TILE) && world == 1;
+    const bool trailing = (K > TILE) && world == 1;     // (the first trailing update has K = 256 - front padding: still role 0)
     // default: the 16x16x4 kernel (8 waves per SIMD, pipe-bound at the instruction's 48.7 TFLOP/s).
     // COCONS_UPD_MFMA4=1 selects the 4x4x4 kernel: its instruction peaks at 76 TFLOP/s, but at a 32x32
     // tile per wave, one barrier per 32 instructions and 5 waves per SIMD the kernel around it lands
