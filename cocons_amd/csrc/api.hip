@@ -247,6 +247,9 @@ struct cocons_fit {
     int pred_cap;
     // sharded state
     int rank, world, nrhs_cur;
+    int nslot;                    // > 0: the last nslot of the npad rows / columns are SLOTS (npad = n + nslot): columns with a huge
+                                  // diagonal and nothing else, rows that hold the right-hand sides of an evaluation (at most nslot
+                                  // of them) INSIDE the last tile of the matrix -- no tile row under the matrix (enqueue_eval)
     int n_user, pad0;             // n = pad0 + n_user: dense handles keep pad0 = npad - n_user placeholder observations IN FRONT
                                   // of the caller's (their columns are made unit vectors before every factorisation,
                                   // launch_front_identity), so that n == npad and no padding sits in the trailing matrix
@@ -465,6 +468,13 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     {
         const char *e = getenv("COCONS_FRONT_PAD");
         f->pad0 = (allow_sort && (e ? atoi(e) : 1)) ? f->npad - n : 0;
+        // ... except for a few SLOTS kept behind the observations: rows that carry the right-hand sides of an evaluation
+        // through the factorisation as part of the matrix's last tile, instead of a tile row of their own under it (one
+        // row in use of 64: 1.9 % of the trailing updates' arithmetic at n = 10 000).  COCONS_RHS_SLOTS=0: off.
+        const char *e2 = getenv("COCONS_RHS_SLOTS");
+        const int need = round_up(r + (q > p ? q : p) > 0 ? r + (q > p ? q : p) : 1, 16);
+        f->nslot = (f->pad0 >= need && r > 0 && (e2 ? atoi(e2) : 1)) ? need : 0;
+        f->pad0 -= f->nslot;
     }
     const int pad0 = f->pad0, nint = n + pad0;
     if (pad0 > 0) f->sorted = true;
@@ -749,6 +759,7 @@ static void assemble_sigma(cocons_fit *f, const double *theta, int which, int co
     pa.nrows_out = f->npad; pa.ncols_out = col1;
     pa.bj0 = col0 / 64;
     if (pa.bj0 < f->pad0 / 64) pa.bj0 = f->pad0 / 64;      // 64-wide tile rows / columns that are placeholders only: not assembled
+    pa.pad_diag = f->nslot > 0 ? 1e300 : 1.0;               // slot columns: a diagonal no right-hand side can turn negative
     pa.gr = ms.gr; pa.nu_fixed = ms.nu_fixed;
     launch_pair_sym(ms.mode, false, pa, f->stream);
 }
@@ -788,8 +799,9 @@ static int no_taper(cocons_fit *f, const char *who)
 
 // right-hand-side rows under the matrix: rows npad.. : z columns (minus trend), then xb columns
 static void assemble_rhs(cocons_fit *f, const double *mean, bool use_trend, const double *xb, int nxb,
-                         int col0, int col1, bool zero_rest = true)
+                         int col0, int col1, bool zero_rest = true, bool slots = false)
 {
+    if (slots) { zero_rest = false; col1 = f->n; }      // (the assembly zeroed the slot rows; their own columns are not touched)
     RhsArgs ra;
     memset(&ra, 0, sizeof ra);
     ra.n = f->n; ra.p = f->p; ra.X = f->dX; ra.ldx = f->n;
@@ -798,14 +810,14 @@ static void assemble_rhs(cocons_fit *f, const double *mean, bool use_trend, cons
     ra.src = f->dz; ra.lds = f->n;
     ra.out = f->dA; ra.ld = f->lda;
     ra.skew = f->skew; ra.npad = f->npad;
-    ra.row0 = f->npad; ra.nrows = f->r;
+    ra.row0 = slots ? f->n : f->npad; ra.nrows = f->r;
     ra.nrows_zero = (nxb > 0 || !zero_rest) ? 0 : f->rhs_act - f->r;
     ra.col0 = col0; ra.ncols_out = col1;
     launch_rhs_rows(ra, f->stream);
     if (nxb > 0) {
         ra.use_trend = 0;
         ra.src = xb; ra.lds = f->n;
-        ra.row0 = f->npad + f->r; ra.nrows = nxb;
+        ra.row0 = (slots ? f->n : f->npad) + f->r; ra.nrows = nxb;
         ra.nrows_zero = zero_rest ? f->rhs_act - f->r - nxb : 0;
         launch_rhs_rows(ra, f->stream);
     }
@@ -1191,6 +1203,9 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
             }
         }
     }
+    // no rows under the matrix (right-hand sides in the slots of the last tile): nothing on the main stream has waited for
+    // the engine's last tile yet -- what follows (the reductions) must
+    if (mt == nt) launch_engine_gate(out + (nt - 1), abort_word, M);
     return 0;
 }
 
@@ -1223,13 +1238,15 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
     // (tools/diag/occupancy_probe.hip), which costs the 12,000-workgroup assembly 6 % -- and not later, see engine_start
     if (engine_wanted(f, main_view(f)))
         if (int rc = engine_start(f, main_view(f))) return rc;
-    assemble_rhs(f, mean, use_trend, xb, nxb, 0, f->npad, zero_rest);
+    const bool slots = f->nslot >= nrhs && f->nslot > 0;      // the right-hand sides ride in the matrix's last tile
+    assemble_rhs(f, mean, use_trend, xb, nxb, 0, f->npad, zero_rest, slots);
     if (stage_events) hipEventRecord(f->ev[1], f->stream);
     FactorView fv = main_view(f);
-    fv.trim = (f->rhs_act - nrhs >= 64) ? 1 : 0;      // at most 64 of the 128 rows under the matrix are in use
+    if (slots) fv.mt = fv.nt;                         // no rows under the matrix
+    else fv.trim = (f->rhs_act - nrhs >= 64) ? 1 : 0; // at most 64 of the 128 rows under the matrix are in use
     if (int rc = factorize(f, fv, ev_upd)) return rc;
     if (stage_events) hipEventRecord(f->ev[2], f->stream);
-    launch_finalize(f->dA, f->lda, f->n, f->npad, nrhs, f->dout, f->stream, f->skew, f->npad);
+    launch_finalize(f->dA, f->lda, f->n, slots ? f->n : f->npad, nrhs, f->dout, f->stream, f->skew, f->npad);
     HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, (size_t)(2 + nrhs * nrhs) * sizeof(double),       // info words + outputs
                           hipMemcpyDeviceToHost, f->stream));
     if (stage_events) hipEventRecord(f->ev[3], f->stream);

@@ -123,7 +123,7 @@ pair_sym_kernel(PairArgs a)
         double v = 0.0;
         if (c < a.ncols_out) {
             if (r >= n || c >= n) {
-                v = (r == c) ? 1.0 : 0.0;
+                v = (r == c) ? (a.pad_diag != 0.0 ? a.pad_diag : 1.0) : 0.0;
             } else if (r == c) {
                 v = a.rows[r + 11 * a.stride];
             } else {

@@ -50,6 +50,7 @@ struct PairArgs {
     int blocked;           // sym: 8 x 8 pair patches per wave step (set by the launcher, Bessel modes)
     double gr;             // global_range
     double nu_fixed;       // closed-form modes
+    double pad_diag;       // sym: diagonal of the identity padding beyond n (0 = the default, 1.0)
 };
 
 struct RhsArgs {
