@@ -1761,16 +1761,17 @@ __device__ __forceinline__ double block_sum(double v, double *red)
 
 // block b < nr*nr: Gram entry (b / nr, b % nr) over columns [c0,c1) and < n;
 // block nr*nr: sum of log of the diagonal over the same columns.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 finalize_kernel(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr, double *out, int skew, int npad)
 {
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int b = blockIdx.x;
     const int hi = c1 < n ? c1 : n;
     double s = 0.0;
-    // every element sits in a cache line of its own (stride lda): eight loads in flight per thread -- with one at a time the
-    // kernel was 25 us of serial round trips at n = 10^4, on the critical path of every evaluation
-    constexpr int U = 8;
+    // every element sits in a cache line of its own (stride lda): 1024 threads with four loads in flight each -- with 256
+    // threads and one load at a time the kernel was 25 us of serial round trips at n = 10^4, on the critical path of
+    // every evaluation
+    constexpr int U = 4;
     const int step = (int)blockDim.x;
     if (b == nr * nr) {
         for (int c = c0 + (int)threadIdx.x; c < hi; c += U * step) {
@@ -2075,12 +2076,12 @@ unsigned update_near_count(int ti0, int ti1, int near_tiles)
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
                           double *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(256), 0, s, A, lda, c0, c1, n, row0, nr, out, 0, 0);
+    hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(1024), 0, s, A, lda, c0, c1, n, row0, nr, out, 0, 0);
 }
 
 void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s, int skew, int npad)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(256), 0, s, A, lda, 0, n, n, row0, nr, out, skew, npad);
+    hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(1024), 0, s, A, lda, 0, n, n, row0, nr, out, skew, npad);
 }
 
 size_t row_reduce_scratch_doubles(int n, int m)
