@@ -1205,7 +1205,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     }
     // no rows under the matrix (right-hand sides in the slots of the last tile): nothing on the main stream has waited for
     // the engine's last tile yet -- what follows (the reductions) must
-    if (mt == nt) launch_engine_gate(out + (nt - 1), abort_word, M);
+    if (mt == nt) launch_engine_gate(out + (nt - 1), abort_word, M, true);
     return 0;
 }
 
@@ -1257,7 +1257,8 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
 static int info_status(cocons_fit *f)
 {
     // COCONS_DEBUG_ABORT=1: say which wait gave up (0x1tt / 0x2tt engine waiting for tile tt, 0x3tt panel solve
-    // waiting for the engine's tile tt, 0x5.. in-panel update, 0x600 the gate waiting for the engine to be resident)
+    // waiting for the engine's tile tt, 0x5.. in-panel update, 0x600 the gate waiting for the engine to be resident,
+    // 0x800 panel product (mode 3), 0x900 the reductions waiting for the engine's last tile)
     if (f->hinfo[1] != 0 && getenv("COCONS_DEBUG_ABORT"))
         fprintf(stderr, "cocons: hand-off time-out, code 0x%x\n", f->hinfo[1]);
     if (f->hinfo[1] != 0)

@@ -925,9 +925,9 @@ potrf_engine_kernel(EngineArgs e)
 // engine sit on every CU.  So the main stream does not start the factorisation's launches before the
 // engine is resident: this one-lane kernel waits for its alive word (bounded like every other wait).
 __global__ void __launch_bounds__(64)
-engine_gate_kernel(unsigned *alive, unsigned *abort_word)
+engine_gate_kernel(unsigned *alive, unsigned *abort_word, unsigned code, unsigned long long ticks)
 {
-    if (threadIdx.x == 0) (void)wait_ge<false>(alive, 1u, abort_word, 0x600u, GATE_TIMEOUT_TICKS);
+    if (threadIdx.x == 0) (void)wait_ge<false>(alive, 1u, abort_word, code, ticks);
 }
 
 // ---------------------------------------------------------------------------
@@ -1888,9 +1888,12 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
     hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), shm, s, A, lda, c0, dinv, info);
 }
 
-void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s)
+void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile)
 {
-    hipLaunchKernelGGL(engine_gate_kernel, dim3(1), dim3(64), 0, s, alive, abort_word);
+    // last_tile: not the start-up gate (is the engine resident? 5 ms, code 0x600) but the wait of the reductions for the
+    // engine's LAST diagonal tile when no panel kernel has waited for it (code 0x900, the hand-offs' 100 ms bound)
+    hipLaunchKernelGGL(engine_gate_kernel, dim3(1), dim3(64), 0, s, alive, abort_word, last_tile ? 0x900u : 0x600u,
+                       last_tile ? ENGINE_TIMEOUT_TICKS : GATE_TIMEOUT_TICKS);
 }
 
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,

@@ -139,7 +139,7 @@ void launch_panel_gemm(double *A, size_t lda, int t, int r0, int r1, const doubl
 // stage first waits for the engine's word: out[t] (factor and W of tile t), xr[t] (X(t+1,t)), out[t+1].
 void launch_panel(double *A, size_t lda, int t, int two, int r0, int r1, const double *winv,
                   unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s);
-void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s);
+void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false);
 // rows [r0, r1) x cols [c0, c0+128):  X <- X * L(c0)^{-T}, L read from A(c0,c0).
 // wait_word != NULL: the tile comes from the engine -- every workgroup first waits for *wait_word >= 1
 // band_r1 >= 0 (band-limited factorisation): rows [r0, band_r1) and [ext_r0, r1) instead of [r0, r1).
