@@ -1,5 +1,9 @@
 #!/bin/bash
 # this tree against the build in old_r2_tmp/w_prev on ONE box, alternating (the only cross-build comparison that means anything)
+# The reference build is NOT tracked: put a build of the commit to compare with there first, e.g.
+#   git worktree add /tmp/ref <commit> && make -C /tmp/ref/cocons_amd/csrc && mkdir -p old_r2_tmp/w_prev &&
+#   cp -r /tmp/ref/{bench.py,cocons_amd,include,oracle,tools} old_r2_tmp/w_prev/      (built .so files travel with gpurun)
+[ -d old_r2_tmp/w_prev ] || { echo "no reference build under old_r2_tmp/w_prev (see the header of this script)"; exit 2; }
 mkdir -p gpurun_out
 P=old_r2_tmp/w_prev
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r3_tests_full.log 2>&1

@@ -1,5 +1,9 @@
 #!/bin/bash
 # the round-2 build (old_r2_tmp/, not tracked) and this tree on ONE box, alternating: python bench.py as the driver runs it
+# The reference build is NOT tracked: put the round-2 tree (tag of the round-2 VERDICT commit) with its library built there first, e.g.
+#   git worktree add /tmp/ref <commit> && make -C /tmp/ref/cocons_amd/csrc && mkdir -p old_r2_tmp &&
+#   cp -r /tmp/ref/{bench.py,cocons_amd,include,oracle,tools} old_r2_tmp/      (built .so files travel with gpurun)
+[ -d old_r2_tmp ] || { echo "no reference build under old_r2_tmp (see the header of this script)"; exit 2; }
 mkdir -p gpurun_out
 for rep in 1 2 3; do
   for w in r2 r3; do
