@@ -230,6 +230,19 @@ def main():
               "switches": {k: os.environ.get(k) for k in ("COCONS_ENGINE", "COCONS_PANEL_MODE", "COCONS_UPD_DYNAMIC",
                                                          "COCONS_UPD_MFMA4") if os.environ.get(k) is not None}}
 
+    # Stage timings and the dominant kernel's roofline (HIP events on the launch stream around every stage and every
+    # trailing-update launch, cocons_fit_profile) are taken HERE, straight behind the timed steps and on the same warm
+    # device: taken at the end of the run, behind the host-side set-up of the supplementary measurements below (the GPU idle
+    # for half a second), the same launches measured 7 % longer while the clocks ramped up again.  For N > 1 on a plain
+    # single-GPU handle on rank 0 (the kernels are the same ones).
+    st = None
+    if rank == 0:
+        pfit = fit if not shard_mode else ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
+        if pfit is not fit:
+            for _ in range(3):
+                pfit.neg2loglik_core(th)
+        st = pfit.profile_stages(th, reps=3)
+
     # extra (N>1, sharded mode): the replica mode on the same ranks -- every rank evaluates its
     # own theta with its own fit, no collective in the data path ("weak" scaling).
     replica = None
@@ -349,11 +362,7 @@ def main():
 
     out = None
     if rank == 0:
-        # stage timings and the dominant kernel's roofline come from THIS run: HIP events on the launch
-        # stream around every stage and every trailing-update launch (cocons_fit_profile).  For N > 1 they
-        # are taken on a plain single-GPU handle on rank 0 (the kernels are the same ones).
-        pfit = fit if not shard_mode else ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, device=local_rank)
-        st = pfit.profile_stages(th, reps=3)
+        # (stage timings and the dominant kernel's roofline: `st`, taken right behind the timed steps above)
         stages = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()}
         roofline = None
         flops, launches = st["update_flops"], st["update_launches"]
