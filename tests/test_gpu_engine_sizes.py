@@ -256,3 +256,27 @@ def test_front_padding_n2115_all_entry_points_vs_oracle(oracle):
         fit2.neg2loglik_core(th2)          # exactly singular: whether the pivot at the duplicate comes out <= 0 or a rounding
     except ca.CholeskyError as e:          # error above it depends on the schedule (LAPACK's dpotrf is no different); the default
         assert 1 <= e.minor <= n           # schedule reports it, and then in the caller's numbering
+
+
+def test_repeated_evaluations_are_bit_identical():
+    """No floating-point atomics and no schedule-dependent order of summation: the same parameters give the same bits, on
+    the engine schedule (dynamic tile order included), also after another entry point used -- and dirtied -- the rows under
+    the matrix of the same handle."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, sc = _grid(50, 47)                     # n = 2350: front padding and slots in use
+    X = sc["std.covs"]
+    z = wl.synthetic_z(locs.shape[0])
+    th = wl.theta_full()
+    th2 = {k: np.array(v, dtype=float) for k, v in th.items()}
+    th2["scale"][0] += 0.07
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    a0, b0 = fit.neg2loglik_core(th)[0], fit.neg2loglik_core(th2)[0]
+    lp = locs[:100] + 0.3 / 49
+    Xp = wl.design_from_locs(lp, sc["mean.vector"], sc["sd.vector"])["std.covs"]
+    p0 = fit.predict_core(th, lp, Xp)[0].copy()
+    for _ in range(3):
+        assert fit.neg2loglik_core(th)[0] == a0
+        assert fit.neg2loglik_core(th2)[0] == b0
+        assert np.array_equal(fit.predict_core(th, lp, Xp)[0], p0)
+    assert a0 != b0
