@@ -227,8 +227,8 @@ def main():
     # schedule and is counted: cocons_fit_engine_state)
     es = fit.engine_state()
     engine = {"engine_active": es["active"], "engine_retries": es["retries"], "engine_last_abort": es["last_abort"],
-              "switches": {k: os.environ.get(k) for k in ("COCONS_ENGINE", "COCONS_PANEL_MODE", "COCONS_UPD_DYNAMIC",
-                                                         "COCONS_UPD_MFMA4") if os.environ.get(k) is not None}}
+              "switches": {k: os.environ.get(k) for k in ("COCONS_ENGINE", "COCONS_UPD_DYNAMIC", "COCONS_UPD_WAVES",
+                                                         "COCONS_UPD_W8_MAX_TILES") if os.environ.get(k) is not None}}
 
     # Stage timings and the dominant kernel's roofline (HIP events on the launch stream around every stage and every
     # trailing-update launch, cocons_fit_profile) are taken HERE, straight behind the timed steps and on the same warm

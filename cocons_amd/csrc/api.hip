@@ -232,10 +232,6 @@ struct cocons_fit {
     double *dloc;            // LOCP_FIELDS x npad
     double *dA;
     double *dinv;            // 2 x 8 x 256
-    double *dwinv;           // 2 x 128 x 128: the engine's W = L^-1 of the two current diagonal tiles (launch_panel's operand)
-    double *dwfull = nullptr, *dwT = nullptr;   // panel mode 3: inverse of the current 256 x 256 block factor; scratch (launch_potrf_engine)
-    double *dpin = nullptr;  // panel mode 3: scratch panel, lda x 256 (launch_panel_gemm's input), allocated on first use
-    size_t pin_cap = 0;
     int *dinfo;
     double *dout;            // reductions
     double *hout;            // pinned mirror
@@ -260,13 +256,11 @@ struct cocons_fit {
     hipStream_t stream2;          // stream the resident diagonal-tile engine is launched on
     hipEvent_t ev_eng;            // orders the engine launch behind the reset of its flag words
     unsigned *dflags;             // flags_cap words each: in[t], out[t], xr[t] (see launch_potrf_engine); 64: the alive word;
-                                  // flags_cap: tile counters of the trailing updates; flags_cap: near[t], finished tiles of
-                                  // the next panel's columns (launch_update's near)
+                                  // flags_cap: tile counters of the trailing updates
     int flags_cap;
     bool engine_ok;               // false: this handle never uses the resident engine (batch slots, band-limited taper fits)
     bool engine_live;             // the engine of the NEXT factorize call is already launched (engine_start)
     bool engine_used;             // the factorisation enqueued last runs on the engine schedule
-    bool engine_w3 = false;       // ... and its engine publishes whole-block inverses (panel mode 3)
     int border_clean = -1;        // nr >= 0: the rows [nr, rhs_act) under the matrix are known to be exactly zero in every column
                                   // (they were zeroed, and a SUCCESSFUL factorisation keeps zero rows zero): the next
                                   // evaluation with the same nr does not zero them again (-1: unknown)
@@ -276,6 +270,7 @@ struct cocons_fit {
     int engine_fails;             // consecutive time-outs (the back-off doubles with each, up to 64 operations)
     int engine_retries;           // time-outs in the life of the handle, each answered by one repeat on the plain schedule
     int engine_last_abort;        // abort word of the last time-out (who gave up: see info_status)
+    long long engine_ops;         // operations enqueued on the engine schedule so far (the first one's gate is patient)
     // taper fit (cocons_fit_create_taper): the spam pattern (1-based CSR) with the taper's entries; the
     // -2 log-likelihood is then that of the TAPERED covariance, evaluated through the dense factorisation
     int taper_nnz;                // > 0: taper fit
@@ -341,10 +336,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->stream) hipStreamSynchronize(f->stream);
         if (f->stream2) hipStreamSynchronize(f->stream2);
         hipFree(f->dX); hipFree(f->dlocs); hipFree(f->dz); hipFree(f->dxb); hipFree(f->dloc);
-        hipFree(f->dA); hipFree(f->dinv); hipFree(f->dwinv); hipFree(f->dinfo);      // (dout is part of dinfo's allocation)
-        if (f->dwfull) hipFree(f->dwfull);
-        if (f->dwT) hipFree(f->dwT);
-        if (f->dpin) hipFree(f->dpin);
+        hipFree(f->dA); hipFree(f->dinv); hipFree(f->dinfo);      // (dout is part of dinfo's allocation)
         hipFree(f->dlocp); hipFree(f->dXp); hipFree(f->dlocsp); hipFree(f->dstoch); hipFree(f->dquad); hipFree(f->dred);
         if (f->xbuf_own) { hipFree(f->xbuf[0]); hipFree(f->xbuf[1]); }
         hipHostFree(f->hinfo);                                  // (hout, hinfo_init: the same allocation)
@@ -366,6 +358,8 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
     delete f->taper_hi; delete f->taper_inv;
     delete f;
 }
+
+static int engine_warm(cocons_fit *f);
 
 static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *locs,
                                    const double *X, const double *z, const double *x_betas,
@@ -509,8 +503,6 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     CK(hipStreamSynchronize(f->stream));      // the staging vectors above go out of scope
     CK(hipMalloc(&f->dloc, (size_t)LOCP_FIELDS * f->npad * sizeof(double)));
     CK(hipMalloc(&f->dinv, 2 * 8 * 256 * sizeof(double)));
-    CK(hipMalloc(&f->dwinv, 2 * (size_t)TILE * TILE * sizeof(double)));
-    CK(hipMemsetAsync(f->dwinv, 0, 2 * (size_t)TILE * TILE * sizeof(double), f->stream));   // zero above the diagonal, for good
     // the two info words -- [0] failing minor (atomicMin), [1] abort word of the engine hand-offs -- sit in the 8 bytes in
     // front of the reduction outputs, on the device and in the pinned host mirror: an evaluation brings both home in ONE copy
     int nr_max = r + (q > p ? q : p);
@@ -532,6 +524,7 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     // (a taper handle allocates its buffer once the envelope of its pattern is known: packed, it is a fraction of n^2)
     if (!defer_matrix && fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
 #undef CK
+    if (engine_warm(f) != 0) { cocons_fit_destroy(f); return nullptr; }
     return f;
 }
 
@@ -876,7 +869,7 @@ static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
     launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, r1, q0, s, nullptr, nullptr, br, er);
     if (k + 1 < nt) {
         launch_update(A, lda, k * TILE, TILE, k + 1, mt, k + 1, k + 2, true, s, nullptr, -1, nullptr, nullptr, nullptr, hb, nt,
-                      nullptr, 0, nullptr, 0, nullptr, v.trim);
+                      0, v.trim);
         launch_potrf_tile(A, lda, (k + 1) * TILE, q1, f->dinfo, s);
         launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, r1, q1, s, nullptr, nullptr, br, er);
     }
@@ -886,11 +879,7 @@ static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
 // diagnostics header) so that variants can be timed in alternation inside ONE process on ONE device.
 struct Tunables {
     int engine = 1;          // COCONS_ENGINE: 1 = diagonal blocks are factored by the resident engine beside the updates
-    int panel_mode = 0;      // COCONS_PANEL_MODE, see panel_mode()
-    int strip_lead = 3600;   // COCONS_STRIP_LEAD
-    int strip_min = 3600;    // COCONS_STRIP_MIN
     int upd_dynamic = 1;     // COCONS_UPD_DYNAMIC
-    int engine_fused = 0;    // COCONS_ENGINE_FUSED: the engine's fused pass over a diagonal block (potrf_block_fused)
     int gate_sabotage = 0;   // (tests) the next N engine-schedule factorisations wait at the gate for a word nobody raises:
                              // a genuine 5 ms time-out, abort code 0x600, to exercise the fall-back and its book-keeping
     bool init = false;
@@ -901,12 +890,7 @@ static Tunables &tun()
     if (!t.init) {
         auto rd = [](const char *name, int &v) { const char *e = getenv(name); if (e) v = atoi(e); };
         rd("COCONS_ENGINE", t.engine);
-        rd("COCONS_PANEL_MODE", t.panel_mode);
-        rd("COCONS_STRIP_LEAD", t.strip_lead);
-        rd("COCONS_STRIP_MIN", t.strip_min);
         rd("COCONS_UPD_DYNAMIC", t.upd_dynamic);
-        rd("COCONS_ENGINE_FUSED", t.engine_fused);
-        if (t.panel_mode < 0 || t.panel_mode > 3) t.panel_mode = 0;
         t.init = true;
     }
     return t;
@@ -918,11 +902,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     Tunables &t = tun();
     std::string k(name);
     if (k == "engine") t.engine = value;
-    else if (k == "panel_mode") t.panel_mode = value;
-    else if (k == "strip_lead") t.strip_lead = value;
-    else if (k == "strip_min") t.strip_min = value;
     else if (k == "upd_dynamic") t.upd_dynamic = value;
-    else if (k == "engine_fused") t.engine_fused = value;
     else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
@@ -936,16 +916,14 @@ static bool engine_enabled() { return tun().engine != 0; }
 
 // one trailing-update launch (tile columns [t0, t1) of the trapezoid below (t0, t0)), optionally
 // bracketed by timing events (profile runs): appended as (start, stop)
-static bool timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int t0, int t1, hipStream_t s,
-                         std::vector<hipEvent_t> *ev_upd, unsigned *sig, int sig_tile, unsigned *queue = nullptr,
-                         unsigned *near = nullptr, int near_tiles = 0, const UpdStrips *strips = nullptr,
-                         const UpdRedirect *redir = nullptr)
+static void timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int t0, int t1, hipStream_t s,
+                         std::vector<hipEvent_t> *ev_upd, unsigned *sig, int sig_tile, unsigned *queue = nullptr)
 {
     const int mt = v.mt;
-    if (t1 <= t0) return false;
+    if (t1 <= t0) return;
     const int hb = band_hi(v, k);                       // band-limited: tile columns and rows [t0, hb), plus the rows [nt, mt)
     if (hb >= 0 && hb < t1) t1 = hb;
-    if (t1 <= t0) return false;
+    if (t1 <= t0) return;
     unsigned *abort_word = sig ? (unsigned *)(f->dinfo + 1) : nullptr;   // engine schedule: see update_kernel
     hipEvent_t a = nullptr, b = nullptr;
     if (ev_upd) {
@@ -954,14 +932,13 @@ static bool timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int 
     }
     // the first panel's leading columns are the unit vectors of the front padding (zero below the diagonal): they add
     // nothing to the trailing matrix, so the update starts behind them (whole 16-column chunks; bit-identical)
-    const int kskip = (k == 0 && !v.hi && !update_alt_form()) ? (f->pad0 / 16) * 16 : 0;
-    const bool took = launch_update(v.A, v.lda, k * TILE + kskip, kw * TILE - kskip, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr,
-                                    abort_word, queue, hb, v.nt, near, near_tiles, strips, 0, redir, v.trim);
+    const int kskip = (k == 0 && !v.hi) ? (f->pad0 / 16) * 16 : 0;
+    launch_update(v.A, v.lda, k * TILE + kskip, kw * TILE - kskip, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr,
+                  abort_word, queue, hb, v.nt, 0, v.trim);
     if (ev_upd) {
         hipEventRecord(b, s);
         ev_upd->push_back(a); ev_upd->push_back(b);
     }
-    return took;
 }
 
 // algorithmic flops of the trailing update of block k (tile columns [t0, nt)): lower triangle of the
@@ -994,9 +971,9 @@ static int flags_reset(cocons_fit *f, int nt)
         HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->dflags) { HIPCHK(hipFree(f->dflags)); f->dflags = nullptr; }
         f->flags_cap = round_up(nt + 8, 64);
-        HIPCHK(hipMalloc(&f->dflags, (5 * (size_t)f->flags_cap + 64) * sizeof(unsigned)));
+        HIPCHK(hipMalloc(&f->dflags, (4 * (size_t)f->flags_cap + 64) * sizeof(unsigned)));
     }
-    HIPCHK(hipMemsetAsync(f->dflags, 0, (5 * (size_t)f->flags_cap + 64) * sizeof(unsigned), f->stream));
+    HIPCHK(hipMemsetAsync(f->dflags, 0, (4 * (size_t)f->flags_cap + 64) * sizeof(unsigned), f->stream));
     return 0;
 }
 
@@ -1007,65 +984,22 @@ static unsigned *tile_queue(cocons_fit *f, int k)
     return dyn ? f->dflags + 3 * (size_t)f->flags_cap + 64 + k / 2 : nullptr;
 }
 
-// COCONS_PANEL_MODE: how the panel below an engine-factored diagonal block is formed
-//   0 (default) = three launches behind the trailing update: solve | in-panel update | solve;
-//   1 = one launch of GEMMs with the engine's tile inverses (launch_panel) behind the trailing update;
-//   2 = the same GEMMs as TASKS of the trailing update that precedes them (launch_update's strips);
-//   3 = ONE tile-parallel product with the inverse of the whole 256 x 256 block factor (launch_panel_gemm), its input taken
-//       from a scratch panel that the preceding trailing update fills (UpdRedirect);
-//   modes 1, 2 and 3 only for the blocks whose update is long enough to hide the engine's longer chain (COCONS_STRIP_MIN far
-//   tiles), mode 0 for the later, short blocks.  Measured in alternation in one process at n = 10^4 (tools/ab_modes.py):
-//   mode 1 = mode 0 within 0.1 %, mode 2 +0.4 ... +1.4 % -- but mode 2 puts the panel's time into the update launches
-//   (their sum grows from 7.0 to 7.6 ms); mode 3 +1.0 ... +1.4 % in turns of 10 evaluations (the panel takes 26-36 us
-//   instead of ~50, one launch boundary less), but in turns of 300 evaluations +0.5 / -0.9 %: the updates and the NEXT
-//   evaluation's assembly behind the shorter pauses run 1-5 % longer -- the chip is power-limited and in the steady state
-//   an evaluation costs its energy, not its critical path.  So the default stays the plain trio.
-static int panel_mode()
+// Warm-up of the engine's stream at handle creation: ONE launch of the engine kernel that raises its alive word and
+// leaves (t0 >= nt), with the launch configuration of the real thing (512 threads, the dynamic LDS, the function
+// attribute).  The first dispatch of a kernel on a stream that has never run anything makes the runtime set up the
+// hardware queue behind it -- and, for a kernel with a private segment, scratch memory: round 3's engine had 88 B per
+// lane, and the driver's box recorded a 5 ms gate time-out on the FIRST engine-schedule operation of a fresh process
+// (DESIGN.md section 4a).  The kernel is scratch-free now, and what remains of the first-dispatch cost is paid here,
+// outside any bounded wait.
+static int engine_warm(cocons_fit *f)
 {
-    int v = tun().panel_mode;
-    static int m4 = -1;                                        // the alternative update kernel knows no strips
-    if (m4 < 0) { const char *e = getenv("COCONS_UPD_MFMA4"); m4 = e ? atoi(e) : 0; }
-    if (m4 != 0 && v >= 2) v = 0;
-    return v;
-}
-
-// mode 2: tiles of the trailing update in front of the strips (time for the engine: ~2040 tiles run at once and take
-// ~75 us), and the fewest far tiles a block must have to carry its strips at all
-static int strip_lead() { return tun().strip_lead; }
-static int strip_min_far() { return tun().strip_min; }
-
-// first tile of the first block whose panel is NOT formed with the engine's tile inverses (the engine computes them
-// for the blocks before it only): mode 0 -> none, modes 1 and 2 -> while the update has enough far tiles (COCONS_STRIP_MIN;
-// 0 = all blocks): behind a short update the engine is the critical path and its inverse an extra ~10 us per block
-static int panel_w_until(const FactorView &v)
-{
-    if (panel_mode() == 0 || v.hi) return 0;
-    int t = 2;
-    for (; t < v.nt; t += 2) {
-        const int near_tiles = t + 1 < v.nt ? 2 : 1;
-        const long long H = 2LL * (v.mt - t), W = 2LL * (v.nt - t);
-        const long long total = W * H - W * (W - 1) / 2;
-        if (total - (long long)update_near_count(t, v.mt, near_tiles) < strip_min_far()) break;
-    }
-    return t;
-}
-
-// panel mode 3: the block-inverse buffers (zero above the diagonal, for good) and the scratch panel for leading dimension lda
-static int panel_gemm_buffers(cocons_fit *f, size_t lda)
-{
-    if (!f->dwfull) {
-        HIPCHK(hipMalloc(&f->dwfull, 4 * (size_t)TILE * TILE * sizeof(double)));
-        HIPCHK(hipMalloc(&f->dwT, (size_t)TILE * TILE * sizeof(double)));
-        HIPCHK(hipMemsetAsync(f->dwfull, 0, 4 * (size_t)TILE * TILE * sizeof(double), f->stream));
-        HIPCHK(hipMemsetAsync(f->dwT, 0, (size_t)TILE * TILE * sizeof(double), f->stream));
-    }
-    const size_t need = lda * 2 * TILE;
-    if (f->pin_cap < need) {
-        HIPCHK(hipStreamSynchronize(f->stream));
-        if (f->dpin) { HIPCHK(hipFree(f->dpin)); f->dpin = nullptr; f->pin_cap = 0; }
-        HIPCHK(hipMalloc(&f->dpin, need * sizeof(double)));
-        f->pin_cap = need;
-    }
+    if (!engine_enabled() || f->nt <= 4) return 0;
+    if (int rc = flags_reset(f, f->nt)) return rc;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    launch_potrf_engine(nullptr, 0, 0, 0, f->dinv, f->dinfo, f->dflags, f->dflags, f->dflags, (unsigned *)(f->dinfo + 1),
+                        f->dflags + 3 * (size_t)f->flags_cap, f->stream2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(f->stream2));
     return 0;
 }
 
@@ -1078,12 +1012,8 @@ static int engine_start(cocons_fit *f, const FactorView &v)
     unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
     HIPCHK(hipEventRecord(f->ev_eng, M));
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
-    const bool m3 = panel_mode() == 3 && panel_w_until(v) > 2;
-    if (m3) if (int rc = panel_gemm_buffers(f, v.lda)) return rc;
     launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
-                        f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dwinv, panel_w_until(v),
-                        tun().engine_fused, m3 ? f->dwfull : nullptr, m3 ? f->dwT : nullptr);
-    f->engine_w3 = m3;
+                        f->dflags + 3 * (size_t)f->flags_cap, f->stream2);
     f->engine_live = true;
     return 0;
 }
@@ -1134,7 +1064,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
                                  e0 * TILE);
                 if (k + 1 < nt)
                     launch_update(v.A, v.lda, k * TILE, TILE, k + 1, mt, k + 1, hb < nt ? hb : nt, true, M, nullptr, -1,
-                                  nullptr, nullptr, nullptr, hb, nt, nullptr, 0, nullptr, v.skew, nullptr, v.trim);
+                                  nullptr, nullptr, nullptr, hb, nt, v.skew, v.trim);
             }
             return 0;
         }
@@ -1151,56 +1081,32 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     f->engine_live = false;
     f->engine_used = true;
     unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
-    unsigned *near = f->dflags + 4 * (size_t)f->flags_cap + 64;
     unsigned *abort_word = (unsigned *)(f->dinfo + 1);
     unsigned *alive = f->dflags + 3 * (size_t)f->flags_cap;
     if (tun().gate_sabotage > 0) { --tun().gate_sabotage; alive += 1; }      // (tests: a word that stays zero)
-    launch_engine_gate(alive, abort_word, M);
+    launch_engine_gate(alive, abort_word, M, false, f->engine_ops++ == 0);
     panel_ops(f, v, 0, M);
     // (Running the panel kernels on a stream of their own behind near-tile flags, so that they start in the tail of the
     // update that feeds them, was built and measured in round 3: slower -- a 90 KB-LDS solve is not placed beside eight
-    // update workgroups per CU, the event back to the main stream costs 12 us -- and removed)
-    hipStream_t P = M;
-    const int w_until = panel_w_until(v);
+    // update workgroups per CU, the event back to the main stream costs 12 us -- and removed; so were three forms of the
+    // panel as products with explicit inverses published by the engine (round 3's COCONS_PANEL_MODE 1-3: +-1 %, deleted
+    // in round 4))
     const int rend = mt * TILE - 64 * v.trim;         // one past the last row any panel kernel touches
     for (int k = 0; k + 2 < nt; k += 2) {
         const int t = k + 2;
         const bool two = t + 1 < nt;                 // the block has a second tile
         const int r0 = two ? t + 2 : t + 1;          // first tile row below the diagonal block
         if (ev_upd) count_update_flops(f, 2, t);
-        const int near_tiles = two ? 2 : 1;
         const int hb = band_hi(v, t);                // rows of block t's panel: [r0, hb) and the rows under the matrix
         const int br = hb >= 0 ? hb * TILE : -1, er = nt * TILE;
-        const bool with_w = t < w_until;             // the engine publishes the inverses of this block's tiles
-        if (with_w && f->engine_w3 && two && mt - t >= 3) {
-            // U(k) leaves the panel's columns below the diagonal block in the scratch panel; one product forms the panel
-            UpdRedirect rd;
-            rd.pin = f->dpin; rd.row_tile0 = r0;
-            timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), nullptr, near_tiles, nullptr, &rd);
-            launch_panel_gemm(v.A, v.lda, t, r0 * TILE, rend, f->dpin, f->dwfull, xr + t, abort_word, M);
-            continue;
-        }
-        if (with_w && panel_mode() == 2 && !f->engine_w3) {
-            // the panel's strips are tasks of U(k) itself: nothing to launch behind it
-            UpdStrips us;
-            us.nstrips = (mt - r0) * 2 - v.trim; us.row0 = r0 * TILE; us.lead = strip_lead();
-            us.winv = f->dwinv; us.out = out; us.xr = xr;
-            if (!timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), near + t, near_tiles, &us))
-                launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, rend, f->dwinv, out, xr, abort_word, M);
-            continue;
-        }
-        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), nullptr, near_tiles);
-        if (with_w && !f->engine_w3) {
-            launch_panel(v.A, v.lda, t, two ? 1 : 0, r0 * TILE, rend, f->dwinv, out, xr, abort_word, P);
-        } else {
-            launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048, P,
-                             out + t, abort_word, br, er);
-            if (two) {
-                launch_update(v.A, v.lda, t * TILE, TILE, r0, mt, t + 1, t + 2, false, P, nullptr, -1, xr + t, abort_word,
-                              nullptr, hb, nt, nullptr, 0, nullptr, 0, nullptr, v.trim);
-                launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, r0 * TILE, rend,
-                                 f->dinv + (size_t)((t + 1) & 1) * 2048, P, out + t + 1, abort_word, br, er);
-            }
+        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k));
+        launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048, M,
+                         out + t, abort_word, br, er);
+        if (two) {
+            launch_update(v.A, v.lda, t * TILE, TILE, r0, mt, t + 1, t + 2, false, M, nullptr, -1, xr + t, abort_word,
+                          nullptr, hb, nt, 0, v.trim);
+            launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, r0 * TILE, rend,
+                             f->dinv + (size_t)((t + 1) & 1) * 2048, M, out + t + 1, abort_word, br, er);
         }
     }
     // no rows under the matrix (right-hand sides in the slots of the last tile): nothing on the main stream has waited for

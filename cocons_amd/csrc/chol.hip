@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <vector>
 #include "kernels.h"
 
@@ -269,8 +270,7 @@ __constant__ int c_tri_ib[36] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5,
 // Also exports, per diagonal block, the Q operands (4 x 64 lanes) the panel solve needs.
 // qall (LDS, may be null): receives the Q operands of all eight diagonal blocks (8 x 256 doubles)
 // WT: the factor and the Q operands are published with write-through stores (engine)
-// FROM_LDS: the image is already in LDS (the fused engine pass leaves tile t + 1 there): no load
-template <bool WT, bool FROM_LDS = false>
+template <bool WT>
 __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, double *q_out, int *info, double *smem,
                                                 double *qall)
 {
@@ -281,7 +281,7 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
 #define SB(ib, kb) (S + ((ib) * ((ib) + 1) / 2 + (kb)) * 256)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    if (!FROM_LDS) {   // 36 lower blocks, 18 per half-workgroup: every global load is issued before the
+    {   // 36 lower blocks, 18 per half-workgroup: every global load is issued before the
         // first LDS store (one round trip instead of 36; matters when the chip is busy)
         const int i = tid & 15, k = (tid >> 4) & 15;
         const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
@@ -385,236 +385,6 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
 #undef SB
 }
 
-// ---------------------------------------------------------------------------
-// The engine's pass over a 256 x 256 diagonal block, FUSED: while wave 0 runs the pivot chain of tile t (the
-// factorisation of a 128 x 128 tile is one wave's dependent fp64 VALU chain; the matrix pipes of the CU idle beside
-// it), the other waves carry the tile below along, 16 columns behind:
-//     X = A(t+1,t) L(t)^-T      strip by strip (16 rows each, in registers), one 16-column block per step,
-//     A(t+1,t+1) -= X X^T        rank 16 per step, the 36 blocks in registers,
-// so that when tile t is factored, X is complete and tile t+1 is updated and sitting in registers: it goes to LDS and is
-// factored from there (no trip through memory).  Before: factor | solve 13 us | update 8 us | factor; now the solve and
-// the update cost what they add to the steps of the first factorisation.
-// Who does what: wave 0 = pivot wave (as in potrf_tile_body); wave 4 shares wave 0's SIMD and only helps with tile t
-// itself (fp64 MFMAs beside the pivot chain slow it: the DP units are shared); the six waves 1,2,3,5,6,7 hold the eight
-// strips (two of them two) and six blocks of tile t+1 each.
-// LDS (doubles): [0, 36*256) image of tile t | [36*256, 37*256) Q operands of the current diagonal block |
-//                [37*256, 45*256) X(:, jb), the eight 16 x 16 blocks of the current step.
-__device__ __forceinline__ int fused_hidx(int wave) { return wave == 0 || wave == 4 ? -1 : (wave < 4 ? wave - 1 : wave - 2); }
-// blocks of tile t+1 (packed index 0..35) by carrying wave: the two waves with two strips take 3 each (0..5), the four
-// others 8, 8, 7, 7 (6..35); a wave's i-th block (-1: none):
-__device__ __forceinline__ int fused_t2_block(int h, int i)
-{
-    return h < 2 ? (i < 3 ? 3 * h + i : -1) : ((6 + (h - 2) + 4 * i) < 36 ? 6 + (h - 2) + 4 * i : -1);
-}
-
-__device__ __forceinline__ void potrf_block_fused(double *A, size_t lda, int c0, double *q_out, int *info, double *smem)
-{
-    double *S = smem;
-    double *QS = smem + 36 * 256;
-    double *XS = smem + 37 * 256;
-#define SB(ib, kb) (S + ((ib) * ((ib) + 1) / 2 + (kb)) * 256)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c1 = c0 + TILE;
-    const int h = fused_hidx(wave);                   // 0..5 for the six carrying waves, -1 for waves 0 and 4
-    const bool two_strips = h == 0 || h == 1;
-
-    {   // image of tile t (as potrf_tile_body)
-        const int i = tid & 15, k = (tid >> 4) & 15;
-        const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
-        const double *src = A + (size_t)(c0 + i) + (size_t)(c0 + k) * lda;
-        double v[18];
-#pragma unroll
-        for (int t = 0; t < 18; ++t) {
-            const int bb = 2 * t + half;
-            const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
-            v[t] = load_wt(src + (size_t)(16 * ib) + (size_t)(16 * kb) * lda);
-        }
-#pragma unroll
-        for (int t = 0; t < 18; ++t) {
-            const int bb = 2 * t + half;
-            const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
-            SB(ib, kb)[k * 16 + i] = v[t];
-        }
-    }
-    // What this wave carries, in ONE pool of 19 blocks (152 registers; the roles differ by wave but the registers are the
-    // kernel's):  R[0..7] = its strip of A(t+1,t);  R[8..15] = its second strip (waves h = 0, 1) or eight blocks of
-    // A(t+1,t+1) (the others);  R[16..18] = three blocks of A(t+1,t+1) (waves h = 0, 1).
-    d4 R[19];
-    if (h >= 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) R[j] = glb_blk_wt(A, lda, c1 + 16 * h, c0 + 16 * j, lane);
-        if (two_strips) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) R[8 + j] = glb_blk_wt(A, lda, c1 + 16 * (h + 6), c0 + 16 * j, lane);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int bb = fused_t2_block(h, i);
-                const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
-                R[16 + i] = glb_blk_wt(A, lda, c1 + 16 * ib, c1 + 16 * kb, lane);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int bb = fused_t2_block(h, i);
-                if (bb >= 0) {
-                    const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
-                    R[8 + i] = glb_blk_wt(A, lda, c1 + 16 * ib, c1 + 16 * kb, lane);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        d4 D = lds_blk(S, lane);
-        double Q[4];
-        int f = potrf16_regs(D, Q, lane);
-        if (f && lane == 0) atomicMin(info, c0 + f);
-        lds_blk_store(S, lane, D);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            QS[s * 64 + lane] = Q[s];
-            store_wt(q_out + s * 64 + lane, Q[s]);
-        }
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
-        // T: the blocks of tile t below the diagonal block, one per wave -- and column block jb of every strip
-        if (jb < 7 && jb + 1 + wave < 8) {
-            const int ib = jb + 1 + wave;
-            d4 L = lds_blk(SB(jb, jb), lane);
-            double Q[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) Q[s] = QS[s * 64 + lane];
-            double *blk = SB(ib, jb);
-            d4 B = lds_blk(blk, lane);
-            trsm16(B, L, Q);
-            lds_blk_store(blk, lane, B);
-        }
-        if (h >= 0) {
-            d4 L = lds_blk(SB(jb, jb), lane);
-            double Q[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) Q[s] = QS[s * 64 + lane];
-            trsm16(R[jb], L, Q);
-            lds_blk_store(XS + h * 256, lane, R[jb]);
-            if (two_strips) {
-                trsm16(R[8 + jb], L, Q);
-                lds_blk_store(XS + (h + 6) * 256, lane, R[8 + jb]);
-            }
-        }
-        __syncthreads();
-        // S: tile t's own update (wave 0: next diagonal block, then its factorisation) -- and the strips' and tile t+1's
-        if (jb < 7) {
-            if (wave == 0) {
-                const int nb = jb + 1;
-                d4 P = lds_blk(SB(nb, jb), lane);
-                double *blk = SB(nb, nb);
-                d4 acc = lds_blk(blk, lane);
-                d4 NP = -P;
-                blk_mma(acc, NP, P);
-                double Q[4];
-                int f = potrf16_regs(acc, Q, lane);
-                if (f && lane == 0) atomicMin(info, c0 + 16 * nb + f);
-                lds_blk_store(blk, lane, acc);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    QS[s * 64 + lane] = Q[s];
-                    store_wt(q_out + nb * 256 + s * 64 + lane, Q[s]);
-                }
-            } else {
-                int cnt = 0;
-                for (int ib = jb + 1; ib < 8; ++ib) {
-                    for (int kb = jb + 1; kb <= ib; ++kb) {
-                        if (ib == jb + 1) continue;            // (jb+1,jb+1) belongs to wave 0
-                        if ((cnt++ % 7) + 1 != wave) continue;
-                        d4 P = lds_blk(SB(ib, jb), lane);
-                        d4 Qk = lds_blk(SB(kb, jb), lane);
-                        double *blk = SB(ib, kb);
-                        d4 acc = lds_blk(blk, lane);
-                        P = -P;
-                        blk_mma(acc, P, Qk);
-                        lds_blk_store(blk, lane, acc);
-                    }
-                }
-            }
-        }
-        if (h >= 0) {
-            {
-                d4 NX = -R[jb];
-#pragma unroll
-                for (int jj = jb + 1; jj < 8; ++jj) {
-                    d4 Lb = lds_blk(SB(jj, jb), lane);
-                    blk_mma(R[jj], NX, Lb);
-                }
-            }
-            if (two_strips) {
-                d4 NX = -R[8 + jb];
-#pragma unroll
-                for (int jj = jb + 1; jj < 8; ++jj) {
-                    d4 Lb = lds_blk(SB(jj, jb), lane);
-                    blk_mma(R[8 + jj], NX, Lb);
-                }
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int bb = fused_t2_block(h, i);
-                    const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
-                    d4 P = lds_blk(XS + ib * 256, lane);
-                    d4 Qk = lds_blk(XS + kb * 256, lane);
-                    P = -P;
-                    blk_mma(R[16 + i], P, Qk);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int bb = fused_t2_block(h, i);
-                    if (bb >= 0) {
-                        const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
-                        d4 P = lds_blk(XS + ib * 256, lane);
-                        d4 Qk = lds_blk(XS + kb * 256, lane);
-                        P = -P;
-                        blk_mma(R[8 + i], P, Qk);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // tile t and X go out (write-through); tile t+1 takes tile t's place in LDS
-    {
-        const int i = tid & 15, k = (tid >> 4) & 15, half = tid >> 8;
-        double *dst = A + (size_t)(c0 + i) + (size_t)(c0 + k) * lda;
-        int b = 0;
-        for (int ib = 0; ib < 8; ++ib)
-            for (int kb = 0; kb <= ib; ++kb, ++b)
-                if ((b & 1) == half) store_wt(dst + (size_t)(16 * ib) + (size_t)(16 * kb) * lda, SB(ib, kb)[k * 16 + i]);
-    }
-    if (h >= 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) glb_blk_store_wt(A, lda, c1 + 16 * h, c0 + 16 * j, lane, R[j]);
-        if (two_strips) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) glb_blk_store_wt(A, lda, c1 + 16 * (h + 6), c0 + 16 * j, lane, R[8 + j]);
-        }
-    }
-    __syncthreads();                        // every wave has read its part of tile t's image
-    if (h >= 0) {
-        if (two_strips) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) lds_blk_store(S + fused_t2_block(h, i) * 256, lane, R[16 + i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int bb = fused_t2_block(h, i);
-                if (bb >= 0) lds_blk_store(S + bb * 256, lane, R[8 + i]);
-            }
-        }
-    }
-#undef SB
-}
-
 __global__ void __launch_bounds__(512)
 potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
 {
@@ -693,124 +463,8 @@ struct EngineArgs {
     unsigned *in, *out, *xr; // per-tile flag words
     unsigned *abort_word;
     unsigned *alive;         // raised once the workgroup is resident (see engine_gate_kernel)
-    double *winv;            // 2 x 128 x 128 doubles (parity of the tile index; zero outside the lower triangle):
-                             // W = L^-1 of each diagonal tile, published before out[t] (see panel_kernel)
-    int w_until;             // ... for the blocks that start at a tile t < w_until (the others: no inverse, no cost)
-    int fused;               // blocks without W take the fused pass (potrf_block_fused)
-    double *wfull;           // WINV == 2: 256 x 256 (leading dimension 256, zero above the diagonal): the inverse of the whole
-                             // diagonal BLOCK's factor, [[W00, 0], [-W11 L10 W00, W11]] (see panel_gemm_kernel)
-    double *wT;              // WINV == 2: 128 x 128 scratch, W00^T
 };
 
-// W = L^-1 of the 128 x 128 tile whose factor (block-packed) and Q operands (all eight diagonal blocks) are in LDS:
-// the strip solve of the engine applied to the identity -- wave w takes rows 16 w .. of I, X = I L^-T = W^T, an upper
-// triangular strip -- stored transposed, write-through, column-major with leading dimension 128.  168 MFMAs on the
-// longest strip (wave 0), ~5 us; the explicit inverse of a TRIANGULAR tile costs the solve that uses it a forward error
-// of eps cond(L) = eps sqrt(cond(Sigma block)), far inside the eps cond(Sigma) any Cholesky of Sigma carries.
-__device__ __noinline__ void engine_tile_inverse(double *W, int ldw, double *WT, int wave, int lane)
-{
-    // (out of line: inlined twice into the engine it pushed the kernel past its registers.  The LDS image is reached
-    // through the kernel's dynamic-LDS symbol, so the reads stay ds_read -- a pointer argument would make them flat.)
-    // ldw: leading dimension of W; WT (may be null): W^T as well, leading dimension 128 (engine_block_inverse_offdiag)
-    extern __shared__ double smem[];
-    const double *S = smem, *QALL = smem + 37 * 256;
-    d4 B[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) B[j] = (d4){0.0, 0.0, 0.0, 0.0};
-    const int a = lane & 15, kq = lane >> 4;
-    d4 I16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) I16[r] = (a == 4 * r + kq) ? 1.0 : 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (j < wave) continue;                      // wave-uniform: the strip is zero left of its diagonal block
-        if (j == wave) B[j] = I16;
-        d4 L = lds_blk(S + (j * (j + 1) / 2 + j) * 256, lane);
-        double Q[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) Q[s] = QALL[j * 256 + s * 64 + lane];
-        trsm16(B[j], L, Q);
-        d4 NX = -B[j];
-#pragma unroll
-        for (int jj = j + 1; jj < 8; ++jj) {
-            d4 Lb = lds_blk(S + (jj * (jj + 1) / 2 + j) * 256, lane);
-            blk_mma(B[jj], NX, Lb);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (j < wave) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int wr = 16 * j + 4 * r + kq, wc = 16 * wave + a;      // W(wr, wc) = W^T(wc, wr)
-            const double v = wr >= wc ? B[j][r] : 0.0;
-            store_wt(W + wr + (size_t)wc * ldw, v);
-            if (WT) store_wt(WT + wc + wr * TILE, v);
-        }
-    }
-}
-
-// The off-diagonal tile of the inverse of a 256 x 256 block factor [[L00, 0], [L10, L11]]:  W10 = -W11 L10 W00, from
-// W00^T (WT, engine_tile_inverse of tile t), W11 (already in Wf) and L10 = A(t+1, t) (the engine's strip solve) -- two
-// 128^3 products on the engine's idle matrix pipes, ~20 us, only for the blocks whose trailing update is long enough to
-// hide them.  With the full inverse the panel below the block is ONE product X = B Wf^T without any dependent chain
-// (panel_gemm_kernel).  Called by all 8 waves behind a barrier; LDS (free at this point) holds L10, then N^T = (L10 W00)^T,
-// as 64 blocks, block (ib, jb) at (ib * 8 + jb) * 256.
-__device__ __noinline__ void engine_block_inverse_offdiag(const double *A, size_t lda, int c0, double *Wf, const double *WT,
-                                                          int wave, int lane)
-{
-    extern __shared__ double smem[];
-    double *XS = smem;
-    const int c1 = c0 + TILE;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        d4 b = glb_blk_wt(A, lda, c1 + 16 * wave, c0 + 16 * j, lane);
-        lds_blk_store(XS + (wave * 8 + j) * 256, lane, b);
-    }
-    __syncthreads();
-    d4 acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
-    // N^T(i, j) = sum_k W00^T(i, k) L10(j, k); rows 16 wave .. of W00^T are zero left of block column `wave`
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-        if (kb < wave) continue;
-        d4 P = glb_blk_wt(WT, TILE, 16 * wave, 16 * kb, lane);
-#pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
-            d4 Q = lds_blk(XS + (jb * 8 + kb) * 256, lane);
-            blk_mma(acc[jb], P, Q);
-        }
-    }
-    __syncthreads();                                   // every wave is done with L10
-#pragma unroll
-    for (int jb = 0; jb < 8; ++jb) lds_blk_store(XS + (wave * 8 + jb) * 256, lane, acc[jb]);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
-    // W10(i, j) = -sum_k W11(i, k) N^T(j, k); rows 16 wave .. of W11 end with block column `wave`
-    const double *W11 = Wf + TILE + (size_t)TILE * (2 * TILE);
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-        if (kb > wave) continue;
-        d4 P = glb_blk_wt(W11, 2 * TILE, 16 * wave, 16 * kb, lane);
-#pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
-            d4 Q = lds_blk(XS + (jb * 8 + kb) * 256, lane);
-            blk_mma(acc[jb], P, Q);
-        }
-    }
-#pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
-        d4 v = -acc[jb];
-        glb_blk_store_wt(Wf + TILE, 2 * TILE, 16 * wave, 16 * jb, lane, v);
-    }
-}
-
-// FUSED / WINV: which paths the instantiation contains at all (each alternative costs the others registers: with
-// everything in one kernel the spills reached the pivot chains of the plain path)
-// WINV: 0 = no inverses, 1 = the two tile inverses (panel_kernel), 2 = the inverse of the whole block (panel_gemm_kernel)
-template <bool FUSED, int WINV>
 __global__ void __launch_bounds__(512)
 potrf_engine_kernel(EngineArgs e)
 {
@@ -818,37 +472,18 @@ potrf_engine_kernel(EngineArgs e)
     double *QALL = smem + 37 * 256;
     double *XS = smem;
     int *okp = (int *)(smem + 64 * 256);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *A = e.A;
     const size_t lda = e.lda;
     if (tid == 0) __hip_atomic_store(e.alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int t = e.t0; t < e.nt; t += 2) {
-        if (FUSED && t + 1 < e.nt && t >= e.w_until) {
-            // one fused pass over the 256 x 256 block (potrf_block_fused), then tile t + 1 straight from LDS
-            if (tid == 0)
-                *okp = (wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t) &&
-                        wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t)) ? 1 : 0;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (*okp == 0) return;
-            potrf_block_fused(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) { signal_add(e.out + t); signal_add(e.xr + t); }
-            potrf_tile_body<true, true>(A, lda, (t + 1) * TILE, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, nullptr);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) signal_add(e.out + t + 1);
-            continue;
-        }
         if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
         potrf_tile_body<true>(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem, QALL);
         __syncthreads();
-        if (WINV == 1 && t < e.w_until) engine_tile_inverse(e.winv + (size_t)(t & 1) * TILE * TILE, TILE, nullptr, wave, lane);
-        if (WINV == 2 && t < e.w_until && t + 1 < e.nt) engine_tile_inverse(e.wfull, 2 * TILE, e.wT, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t);
@@ -860,10 +495,19 @@ potrf_engine_kernel(EngineArgs e)
         if (*okp == 0) return;
         const int c0 = t * TILE, c1 = (t + 1) * TILE;
         {   // X = A(t+1,t) L(t)^-T : this wave's 16 x 128 strip
-            const int rs = c1 + 16 * wave;
+            // (addresses: a wave-uniform base and ONE 32-bit per-lane offset, re-derived for the stores -- thirty-two
+            // 64-bit pointers held across the solve were what spilled this kernel in round 3: 88 B of scratch per lane,
+            // and a first dispatch that has to wait for the runtime to provide scratch memory)
+            const double *Sb = A + (size_t)(c1 + 16 * wave) + (size_t)c0 * lda;
+            const unsigned ldab = 8u * (unsigned)lda;
+            unsigned lo = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldab;
+            asm volatile("" : "+v"(lo));           // (not loop-invariant: the 32 addresses must not live across the blocks)
             d4 B[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) B[j] = glb_blk_wt(A, lda, rs, c0 + 16 * j, lane);
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    B[j][r] = load_wt((const double *)((const char *)Sb + (lo + (unsigned)(16 * j + 4 * r) * ldab)));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 d4 L = lds_blk(smem + (j * (j + 1) / 2 + j) * 256, lane);
@@ -878,8 +522,12 @@ potrf_engine_kernel(EngineArgs e)
                     blk_mma(B[jj], NX, Lb);
                 }
             }
+            asm volatile("" : "+v"(lo));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) glb_blk_store_wt(A, lda, rs, c0 + 16 * j, lane, B[j]);
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    store_wt((double *)((char *)const_cast<double *>(Sb) + (lo + (unsigned)(16 * j + 4 * r) * ldab)), B[j][r]);
             __syncthreads();                       // every wave is done with the image of L(t)
 #pragma unroll
             for (int j = 0; j < 8; ++j) lds_blk_store(XS + (wave * 8 + j) * 256, lane, B[j]);
@@ -902,21 +550,10 @@ potrf_engine_kernel(EngineArgs e)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // X in LDS is dead; the tile is re-read from memory
-        potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, (WINV && t < e.w_until) ? QALL : nullptr);
-        __syncthreads();
-        if (WINV == 1 && t < e.w_until) engine_tile_inverse(e.winv + (size_t)((t + 1) & 1) * TILE * TILE, TILE, nullptr, wave, lane);
-        if (WINV == 2 && t < e.w_until)
-            engine_tile_inverse(e.wfull + TILE + (size_t)TILE * (2 * TILE), 2 * TILE, nullptr, wave, lane);
+        potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, nullptr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t + 1);
-        if (WINV == 2 && t < e.w_until) {
-            // the block's inverse is complete with its off-diagonal tile: second count on xr[t] (panel_gemm_kernel waits for 2)
-            engine_block_inverse_offdiag(A, lda, c0, e.wfull, e.wT, wave, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) signal_add(e.xr + t);
-        }
     }
 }
 
@@ -982,301 +619,6 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsig
 }
 
 // ---------------------------------------------------------------------------
-// Panel of a 256-column block under the engine schedule, as GEMMs.  The engine publishes, with the factor L of each
-// diagonal tile, its inverse W = L^-1 (engine_tile_inverse); then for the rows below the diagonal block
-//     X0 = B0 W(t)^T          (the solve with tile t)
-//     B1 -= X0 X(t+1,t)^T     (in-panel update; X(t+1,t) is the engine's)
-//     X1 = B1 W(t+1)^T        (the solve with tile t + 1)
-// are products without any dependent chain, and one workgroup per 64-row strip runs all three on the trailing update's
-// inner loop and footprint (4 waves x 32 x 32, K chunks of 8 through 20 KB of LDS, 64 registers): ONE launch instead of
-// three, a fraction of their time, and small enough to sit beside update workgroups.  In place: the 64-column halves of
-// a solve are formed right to left (the left half only reads columns the right half did not write).
-// Before each stage one lane waits for the engine's word (out[t] covers W(t); bounded like every wait), then an
-// acquire: W and X(t+1,t) arrive by write-through stores from another CU.
-struct PanelArgs {
-    double *A; size_t lda;
-    int c0;                  // first column of tile t
-    int two;                 // the block has a second tile
-    int row0;                // first row; workgroup b takes rows row0 + 64 b ..
-    const double *w0, *w1;   // W(t), W(t+1): 128 x 128, column-major, leading dimension 128, zero above the diagonal
-    unsigned *out0, *xr0, *out1, *abort_word;
-};
-
-// acc (+/-)= I(rows, 0..K) J(cols, 0..K)^T streamed through LDS in chunks of KC columns (the trailing update's inner
-// loop); gI / gJ point at the first row of the operand tiles, column 0; ends behind a barrier: LDS free, every wave done.
-template <int TM, int KC, bool NEG>
-__device__ __forceinline__ void panel_stream(d4 (&acc)[TM / 32][TM / 32], const double *gI, size_t ldi, const double *gJ,
-                                             size_t ldj, int K, double *sIb, double *sJb, int wi, int wj)
-{
-    constexpr int LDT = TM + 16, NB = TM / 32, TPC = 256 / KC, RPT = TM / TPC;
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    int lane;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-    const int t2 = 64 * (2 * wj + wi) + lane;
-    const int kc = t2 / TPC, rg = (t2 % TPC) * RPT;
-    const int ro = (lane >> 4) * LDT + (lane & 15);
-    gI += (size_t)rg + (size_t)kc * ldi;
-    gJ += (size_t)rg + (size_t)kc * ldj;
-    const int nch = K / KC;
-    d2 stI[RPT / 2], stJ[RPT / 2];
-#pragma unroll
-    for (int v = 0; v < RPT / 2; ++v) {
-        stI[v] = *(const d2 *)(gI + 2 * v);
-        stJ[v] = *(const d2 *)(gJ + 2 * v);
-    }
-#pragma unroll
-    for (int v = 0; v < RPT / 2; ++v) {
-        *(d2 *)(sIb + kc * LDT + rg + 2 * v) = stI[v];
-        *(d2 *)(sJb + kc * LDT + rg + 2 * v) = stJ[v];
-    }
-    __syncthreads();
-    for (int ch = 0; ch < nch; ++ch) {
-        const int cur = ch & 1;
-        if (ch + 1 < nch) {
-            const double *pI = gI + (size_t)(ch + 1) * KC * ldi;
-            const double *pJ = gJ + (size_t)(ch + 1) * KC * ldj;
-#pragma unroll
-            for (int v = 0; v < RPT / 2; ++v) {
-                stI[v] = *(const d2 *)(pI + 2 * v);
-                stJ[v] = *(const d2 *)(pJ + 2 * v);
-            }
-        }
-        const double *bI = sIb + cur * (KC * LDT) + ro + (TM / 2) * wi;
-        const double *bJ = sJb + cur * (KC * LDT) + ro + (TM / 2) * wj;
-#pragma unroll
-        for (int s = 0; s < KC / 4; ++s) {
-            double pi_[NB], pj_[NB];
-#pragma unroll
-            for (int x = 0; x < NB; ++x) {
-                pi_[x] = bI[s * 4 * LDT + 16 * x];
-                pj_[x] = bJ[s * 4 * LDT + 16 * x];
-            }
-#pragma unroll
-            for (int x = 0; x < NB; ++x)
-#pragma unroll
-                for (int y = 0; y < NB; ++y)
-                    acc[x][y] = NEG ? MFMA64_NEGA(pj_[y], pi_[x], acc[x][y]) : MFMA64(pj_[y], pi_[x], acc[x][y]);
-        }
-        if (ch + 1 < nch) {
-#pragma unroll
-            for (int v = 0; v < RPT / 2; ++v) {
-                *(d2 *)(sIb + (cur ^ 1) * (KC * LDT) + kc * LDT + rg + 2 * v) = stI[v];
-                *(d2 *)(sJb + (cur ^ 1) * (KC * LDT) + kc * LDT + rg + 2 * v) = stJ[v];
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// One strip = 64 rows below the diagonal block: the three stages, each behind its wait.  sIb / sJb: the two operand
-// rings (2 x KC x (TM + 16) doubles each), share: a word of LDS no staging store touches.  near / near_need: the strip's
-// input comes from the trailing update that is still running (the strip is a task INSIDE that launch): wait until its
-// near counter says the panel's columns are complete.  Returns false when the factorisation was given up.
-template <int TM, int KC>
-__device__ __forceinline__ bool panel_strip(const PanelArgs &a, int strip, double *sIb, double *sJb, unsigned *share,
-                                            int wave, unsigned *near, unsigned near_need)
-{
-    constexpr int NB = TM / 32;
-    const int tid = threadIdx.x;
-    const int wi = wave & 1, wj = wave >> 1;
-    const int row0 = a.row0 + TM * strip;
-    const unsigned ldab = 8u * (unsigned)a.lda;
-
-    // stages: 0, 1 = solve with tile t (right half, left half); 2, 3 = in-panel update of the halves of tile t + 1;
-    // 4, 5 = solve with tile t + 1 (right half, left half)
-    const int nstage = a.two ? 6 : 2;
-#pragma unroll 1
-    for (int st = 0; st < nstage; ++st) {
-        if (st == 0 || st == 2 || st == 4) {
-            unsigned *w = st == 0 ? a.out0 : (st == 2 ? a.xr0 : a.out1);
-            if (tid == 0) {
-                bool ok = true;
-                if (st == 0 && near) ok = wait_ge<false>(near, near_need, a.abort_word, 0x700u);
-                *share = (ok && wait_ge(w, 1u, a.abort_word, 0x300u + st)) ? 1u : 0u;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const unsigned ok = *share;
-            __syncthreads();
-            if (!ok) return false;
-        }
-        const bool upd = st == 2 || st == 3;
-        const int h = upd ? st - 2 : 1 - (st & 1);                       // 64-column half of the tile
-        const int ctile = st < 2 ? a.c0 : a.c0 + TILE;                   // tile the stage writes
-        const int col = ctile + TM * h;
-        // the wave's 32 x 32 part of the 64 x 64 tile at (row0, col): a scalar base and one per-lane offset
-        double *Cb = a.A + (size_t)(row0 + (TM / 2) * wi) + (size_t)(col + (TM / 2) * wj) * a.lda;
-        int lane;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-        const unsigned cvo = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldab;
-        d4 acc[NB][NB];
-        if (upd) {
-#pragma unroll
-            for (int x = 0; x < NB; ++x)
-#pragma unroll
-                for (int y = 0; y < NB; ++y)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc[x][y][r] = *(const double *)((const char *)(Cb + 16 * x) + (cvo + (unsigned)(16 * y + 4 * r) * ldab));
-            panel_stream<TM, KC, true>(acc, a.A + (size_t)row0 + (size_t)a.c0 * a.lda, a.lda,
-                                       a.A + (size_t)col + (size_t)a.c0 * a.lda, a.lda, TILE, sIb, sJb, wi, wj);
-        } else {
-#pragma unroll
-            for (int x = 0; x < NB; ++x)
-#pragma unroll
-                for (int y = 0; y < NB; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-            const double *W = st < 2 ? a.w0 : a.w1;
-            panel_stream<TM, KC, false>(acc, a.A + (size_t)row0 + (size_t)ctile * a.lda, a.lda, W + TM * h, TILE,
-                                        TM * (h + 1), sIb, sJb, wi, wj);
-        }
-        unsigned cve = cvo;
-        asm volatile("" : "+v"(cve));
-#pragma unroll
-        for (int x = 0; x < NB; ++x)
-#pragma unroll
-            for (int y = 0; y < NB; ++y)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    *(double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldab)) = acc[x][y][r];
-        // a later stage of THIS workgroup reads these bytes back (as operand or as C): drain, then a barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    return true;
-}
-
-// The panel as a launch of its own (one workgroup per strip means one wave per SIMD and nobody to hide a memory round
-// trip behind: the chunks are KC = 32 columns deep -- 32 MFMAs per wave, 2048 pipe cycles, cover the load of the next
-// chunk -- which takes 80 KB of LDS and 32 staging registers; with at most one workgroup per CU that costs nothing).
-template <int TM, int KC>
-__global__ void __launch_bounds__(256)
-panel_kernel(PanelArgs a)
-{
-    constexpr int LDT = TM + 16;
-    extern __shared__ double panel_smem[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    (void)panel_strip<TM, KC>(a, blockIdx.x, panel_smem, panel_smem + 2 * KC * LDT, (unsigned *)(panel_smem + TM), wave,
-                              nullptr, 0u);
-}
-
-// The panel below an engine-factored 256 x 256 diagonal block as ONE tile-parallel product (COCONS_PANEL_MODE=3):
-//     X(rows, 0..255) = B(rows, 0..255) Wf^T,      Wf = inverse of the block's factor (EngineArgs::wfull),
-// one workgroup per 64 x 64 tile of X, K = 64 (jt + 1) for the tile's 64-column group jt (Wf is lower triangular) -- no
-// dependent chain and four times the workgroups of the strip forms above, so the launch lasts one short tile instead of
-// three latency-bound stages (15 us against 45-50).  B is NOT read in place (a tile of X would overwrite what the tiles to
-// its right still read): the trailing update that precedes the panel stores the panel's columns below the diagonal block
-// into the scratch panel `pin` instead of into the matrix (UpdArgs::redir_*), and this kernel writes X into the matrix.
-struct PanelGemmArgs {
-    double *A; size_t lda;
-    int c0, row0;            // first column of the block; first row below it (workgroup b: rows row0 + 64 (b >> 2) ..)
-    const double *pin;       // B: element (global row, panel column c) at pin[row + c * lda]
-    const double *wf;        // 256 x 256, leading dimension 256
-    unsigned *wflag; unsigned need;   // the engine's word for Wf (xr[t] >= 2)
-    unsigned *abort_word;
-    int nstrips;
-};
-
-// 4 waves (2 x 2, each 32 x 32 of the tile), K chunks of 16 through two 20 KB LDS buffers, 40 KB and ~110 registers: four
-// workgroups per CU, so the whole launch (at most ~630 tiles) is resident at once.  On a chip that is otherwise idle a
-// tile's time is memory round trips, not arithmetic: a chunk-by-chunk double buffer measured 2.5 us per chunk (40 us per
-// launch, as long as the three kernels this replaces), so every thread keeps the loads of FOUR chunks in flight.
-__global__ void __launch_bounds__(256)
-panel_gemm_kernel(PanelGemmArgs a)
-{
-    constexpr int TM = 64, KC = 16, LDT = TM + 16, D = 4;
-    constexpr int TPC = 256 / KC, RPT = TM / TPC;              // 16 threads per panel column, 4 rows each
-    static_assert(RPT == 4, "two 16-byte loads per thread, side and chunk");
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    __shared__ double sI[2][KC * LDT];
-    __shared__ double sJ[2][KC * LDT];
-    unsigned *share = (unsigned *)&sI[0][TM];      // padding of the first staged column (see update_kernel)
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int wi = wave & 1, wj = wave >> 1;
-    // workgroups are dealt over the 8 XCDs by block index: the four column groups of a strip go to ONE XCD, back to back, so
-    // that the strip's rows of B are fetched into that XCD's L2 once (not up to four times)
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int strip = (q >> 2) * 8 + xcd, jt = 3 - (q & 3);               // the longest products first
-    if (strip >= a.nstrips) return;
-    if (tid == 0) *share = wait_ge(a.wflag, a.need, a.abort_word, 0x800u) ? 1u : 0u;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const unsigned ok = *share;
-    __syncthreads();
-    if (!ok) return;
-    const int row0 = a.row0 + TM * strip;
-    const int nch = (TM / KC) * (jt + 1);          // K = 64 (jt + 1): Wf is lower triangular; a multiple of D
-    const int kc = tid / TPC, rg = (tid % TPC) * RPT;
-    const double *gI = a.pin + (size_t)(row0 + rg) + (size_t)kc * a.lda;
-    const double *gJ = a.wf + (size_t)(TM * jt + rg) + (size_t)kc * (2 * TILE);
-    const size_t cI = (size_t)KC * a.lda, cJ = (size_t)KC * (2 * TILE);
-    d2 stI[D][2], stJ[D][2];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        stI[d][0] = *(const d2 *)(gI + d * cI);
-        stI[d][1] = *(const d2 *)(gI + d * cI + 2);
-        stJ[d][0] = *(const d2 *)(gJ + d * cJ);
-        stJ[d][1] = *(const d2 *)(gJ + d * cJ + 2);
-    }
-    d4 acc[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-    const int ro = (lane >> 4) * LDT + (lane & 15);
-    for (int c0 = 0; c0 < nch; c0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int ch = c0 + d, cur = d & 1;
-            *(d2 *)(&sI[cur][kc * LDT + rg]) = stI[d][0];
-            *(d2 *)(&sI[cur][kc * LDT + rg + 2]) = stI[d][1];
-            *(d2 *)(&sJ[cur][kc * LDT + rg]) = stJ[d][0];
-            *(d2 *)(&sJ[cur][kc * LDT + rg + 2]) = stJ[d][1];
-            if (ch + D < nch) {
-                stI[d][0] = *(const d2 *)(gI + (size_t)(ch + D) * cI);
-                stI[d][1] = *(const d2 *)(gI + (size_t)(ch + D) * cI + 2);
-                stJ[d][0] = *(const d2 *)(gJ + (size_t)(ch + D) * cJ);
-                stJ[d][1] = *(const d2 *)(gJ + (size_t)(ch + D) * cJ + 2);
-            }
-            __syncthreads();            // (the buffer was last read two chunks ago, before the previous barrier)
-            const double *bI = &sI[cur][ro + 32 * wi];
-            const double *bJ = &sJ[cur][ro + 32 * wj];
-#pragma unroll
-            for (int s4 = 0; s4 < KC / 4; ++s4) {
-                const double p0 = bI[s4 * 4 * LDT], p1 = bI[s4 * 4 * LDT + 16];
-                const double q0 = bJ[s4 * 4 * LDT], q1 = bJ[s4 * 4 * LDT + 16];
-                acc[0][0] = MFMA64(q0, p0, acc[0][0]);
-                acc[0][1] = MFMA64(q1, p0, acc[0][1]);
-                acc[1][0] = MFMA64(q0, p1, acc[1][0]);
-                acc[1][1] = MFMA64(q1, p1, acc[1][1]);
-            }
-        }
-    }
-    double *Cb = a.A + (size_t)(row0 + 32 * wi) + (size_t)(a.c0 + TM * jt + 32 * wj) * a.lda;
-    const unsigned ldab = 8u * (unsigned)a.lda;
-    const unsigned cvo = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldab;
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *(double *)((char *)(Cb + 16 * x) + (cvo + (unsigned)(16 * y + 4 * r) * ldab)) = acc[x][y][r];
-}
-
-void launch_panel_gemm(double *A, size_t lda, int t, int r0, int r1, const double *pin, const double *wfull,
-                       unsigned *wflag, unsigned *abort_word, hipStream_t s)
-{
-    const int nb = (r1 - r0) / 64;
-    if (nb <= 0) return;
-    PanelGemmArgs a;
-    a.A = A; a.lda = lda; a.c0 = t * TILE; a.row0 = r0; a.pin = pin; a.wf = wfull;
-    a.wflag = wflag; a.need = 2u; a.abort_word = abort_word; a.nstrips = nb;
-    hipLaunchKernelGGL(panel_gemm_kernel, dim3(32 * ((nb + 7) / 8)), dim3(256), 0, s, a);
-}
-
-// ---------------------------------------------------------------------------
 // Trailing update: C(ti,tj) -= P(ti,:) P(tj,:)^T over K panel columns.  TM x TM tiles, 4 waves x
 // (TM/2 x TM/2); instantiated with TM = 64 (each wave 2 x 2 MFMA blocks, up to 8 workgroups per CU).
 // Operand tiles stream through LDS in chunks of KC panel columns (KC = 8: 20 KB), register-staged
@@ -1295,30 +637,16 @@ struct UpdArgs {
     unsigned *queue; unsigned ntiles;  // dynamic tile order (lower_only launches): shared counter, zero at launch; tiles in all
     int Hb, ext0;                  // rows: local tile rows < Hb count from ti0 (tj0 when lower_only), the others from ext0
                                    // (band-limited factorisation: band rows, then the right-hand-side rows)
-    unsigned *near; int near_tj0, near_w;   // panel hand-off: every tile in the 64-wide columns [near_tj0, near_tj0 + near_w)
-                                   // -- the NEXT panel's columns -- is stored write-through and then adds 1 to *near, so
-                                   // that the panel kernels (another stream) can start while this launch is still running
-    // panel strips as tasks of THIS launch (lower_only launches): positions [strip_pos, strip_pos + nstrips) of the 1-D task
-    // order are the 64-row strips of the next panel (panel_strip; pan describes it, near_need = what *near counts up to),
-    // everything else a tile; ntiles then counts tiles AND strips
-    int nstrips; unsigned strip_pos, near_need;
-    PanelArgs pan;
     int skew, kblk;                // packed band buffer (kernels.h band_index): C and P are its unshifted base, the operand
                                    // panel is tile column kblk; rows then count from each tile column's own diagonal tile
-    long long redir_off; int redir_ti0;   // redir_ti0 > 0 (lower_only launches): the tiles of the first four 64-wide columns --
-                                   // the NEXT panel's -- in tile rows >= redir_ti0 (below its diagonal block) are stored
-                                   // redir_off elements away from their place in C: into the scratch panel panel_gemm_kernel reads
 };
 
 // ROLE only names the instantiation (0 = trailing update, 1 = in-panel / sharded update) so that
 // profiler summaries keep the dominant trailing launches apart from the narrow ones
-// STRIPS: the instantiation that can take panel strips as tasks (a.nstrips); the plain one must not even contain that path --
-// with it the kernel needs a few bytes of scratch per lane, and a kernel with scratch runs measurably slower and no longer
-// side by side with itself on other streams (batch slots: 590 -> 310 evaluations/s on the taper path)
 // NW: waves per workgroup.  4 (KC = 8): each wave a quarter of the tile, 8 workgroups per CU.  8 (KC = 16, 512 threads):
 // each wave an eighth (32 x 16), 4 workgroups per CU -- the same waves per SIMD, the same work per wave and barrier, but a
 // tile is finished in half the time, so the launch drains for half as long at its end.
-template <int TM, int KC, int ROLE, bool STRIPS = false, int NW = 4>
+template <int TM, int KC, int ROLE, int NW = 4>
 __global__ void __launch_bounds__(64 * NW, 8)
 update_kernel(UpdArgs a)
 {
@@ -1376,36 +704,17 @@ update_kernel(UpdArgs a)
         const int kc = t2 / TPC, rg = (t2 % TPC) * RPT;
         const int ro = (lane >> 4) * LDT + (lane & 15);
         int ti, tj;
-        if (STRIPS && a.nstrips > 0 && L >= a.strip_pos && L < a.strip_pos + (unsigned)a.nstrips) {
-            // a strip of the next panel: its input -- the near tiles of this launch, the engine's tiles -- is complete
-            // or on its way (the strips sit behind the near tiles in the task order, far enough for the engine)
-            __builtin_amdgcn_s_setprio(0);
-            if (!panel_strip<TM, KC>(a.pan, (int)(L - a.strip_pos), &sI[0][0], &sJ[0][0], share, wave, a.near, a.near_need))
-                return;
-            if (!a.queue) break;
-            if (t2 == 0)
-                *share = gridDim.x + __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            L = (unsigned)__builtin_amdgcn_readfirstlane((int)*share);
-            __syncthreads();
-            if (L >= a.ntiles) break;
-            continue;
-        }
-        const unsigned Lt = (STRIPS && a.nstrips > 0 && L >= a.strip_pos) ? L - (unsigned)a.nstrips : L;     // position among the tiles
         if (a.lower_only) {
             // 1-D order over the tiles (ti >= tj) of the trapezoid, column by column: column j (0-based
             // from tj0) holds H - j tiles and starts at j H - j (j-1)/2.  Bisection in integers: L is
             // uniform, so this stays on the scalar unit.
-            // (Taking the next panel's tiles below its diagonal block LAST in this order -- so that the panel product finds
-            // them in the caches -- was measured with the scratch-panel redirect: the product no faster, these launches 3 %
-            // slower.)
             int lo = 0, hi = a.W - 1;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
-                if (mid * a.H - mid * (mid - 1) / 2 <= (int)Lt) lo = mid; else hi = mid - 1;
+                if (mid * a.H - mid * (mid - 1) / 2 <= (int)L) lo = mid; else hi = mid - 1;
             }
             const int j = lo;
-            const int til = j + ((int)Lt - (j * a.H - j * (j - 1) / 2));
+            const int til = j + ((int)L - (j * a.H - j * (j - 1) / 2));
             tj = a.tj0 + j;
             ti = til < a.Hb ? a.tj0 + til : a.ext0 + (til - a.Hb);
         } else {
@@ -1417,9 +726,7 @@ update_kernel(UpdArgs a)
         // does this tile lie inside the diagonal block the engine is waiting for?
         const int sig_Ti = (ti * TM) / TILE - a.sig_tile, sig_Tj = (tj * TM) / TILE - a.sig_tile;
         const bool sig_wg = a.sig != nullptr && sig_Ti >= 0 && sig_Ti <= 1 && sig_Tj >= 0 && sig_Tj <= sig_Ti;
-        // ... or in the columns of the next panel, whose solve (another stream) starts as soon as all of them are done?
-        const bool near_wg = a.near != nullptr && tj >= a.near_tj0 && tj < a.near_tj0 + a.near_w;
-        const bool wt_wg = sig_wg || near_wg;
+        const bool wt_wg = sig_wg;
         // the engine's whole chain starts when these ten tiles are done: let them win the issue arbitration on
         // their CU (beside seven other workgroups a tile takes ~70 us, alone ~10)
         if (sig_wg) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
@@ -1505,8 +812,6 @@ update_kernel(UpdArgs a)
         // round trips; all sixteen at once would cost the 8th wave per SIMD in registers)
         unsigned cve = cvo;
         asm volatile("" : "+v"(cve));
-        // (scalar: the tile indices are uniform) where the results go -- in place, or into the scratch panel
-        double *Cs = (a.redir_ti0 > 0 && tj < a.tj0 + 4 && ti >= a.redir_ti0) ? Cb + a.redir_off : Cb;
 #pragma unroll
         for (int x = 0; x < NB; ++x)
 #pragma unroll
@@ -1519,20 +824,17 @@ update_kernel(UpdArgs a)
                 if (wt_wg) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        store_wt((double *)((char *)(Cs + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)), cv[r]);
+                        store_wt((double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)), cv[r]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        *(double *)((char *)(Cs + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)) = cv[r];
+                        *(double *)((char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb)) = cv[r];
                 }
             }
         if (wt_wg) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t2 == 0) {
-                if (sig_wg) signal_add(a.sig + a.sig_tile + sig_Ti);
-                if (near_wg) signal_add(a.near);
-            }
+            if (t2 == 0) signal_add(a.sig + a.sig_tile + sig_Ti);
         }
         if (!a.queue) break;
         if (t2 == 0) *share = Lnext;
@@ -1541,206 +843,6 @@ update_kernel(UpdArgs a)
         if (L >= a.ntiles) break;
         // (the next write to the word comes after the barriers of the next tile, which no wave passes before
         // all have read it here)
-    }
-}
-
-void launch_panel(double *A, size_t lda, int t, int two, int r0, int r1, const double *winv,
-                  unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s)
-{
-    const int nb = (r1 - r0) / 64;
-    if (nb <= 0) return;
-    PanelArgs a;
-    a.A = A; a.lda = lda; a.c0 = t * TILE; a.two = two; a.row0 = r0;
-    a.w0 = winv + (size_t)(t & 1) * TILE * TILE;
-    a.w1 = winv + (size_t)((t + 1) & 1) * TILE * TILE;
-    a.out0 = out + t; a.xr0 = xr + t; a.out1 = out + t + 1; a.abort_word = abort_word;
-    constexpr int KC = 32;
-    const size_t shm = 4 * (size_t)KC * (64 + 16) * sizeof(double);      // 81,920 B of dynamic LDS (> the 64 KB default)
-    (void)hipFuncSetAttribute((const void *)panel_kernel<64, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL((panel_kernel<64, KC>), dim3(nb), dim3(256), shm, s, a);
-}
-
-// ---------------------------------------------------------------------------
-// Trailing update on v_mfma_f64_4x4x4_4b_f64 -- an ALTERNATIVE to update_kernel kept for comparison
-// (COCONS_UPD_MFMA4=1).  Both fp64 MFMA forms have the same nominal rate (2048 flop / 64 pipe cycles =
-// 512 / 16); issued back to back the 16x16x4 form sustains only 48.7 TFLOP/s chip-wide and the 4x4x4 form
-// 76.2 (tools/probe_mfma_ex.py), but inside a real kernel, interleaved across 8 waves per SIMD, the 16x16x4
-// form keeps the pipe as busy (72 %) as this kernel does (71 %): the instruction is not what limits either
-// (DESIGN.md section 8).  The four-block form multiplies, per block b, a 4x4 slice of each operand:
-//   D[lane 16 i + 4 b + j] += sum_k A[lane 16 k + 4 b + i] * B[lane 16 k + 4 b + j]
-// (mapping determined with one-hot operands, tools/diag/mfma4_layout.hip), i.e. of the 16 x 16 outer
-// product of two 16-row operand slices it delivers only the four diagonal 4x4 blocks.  The other twelve
-// come from operand slices whose 4-row groups are rotated: rows rotated by s in {0,1} and columns by
-// t in {0,2} give every relative rotation 2t - s mod 4 once, so a 16x16 block of C costs 4 instructions
-// (the same 2048 flop as one 16x16x4) fed by 2 + 2 operand reads.  The rotated slices are plain
-// ds_read_b64 with a different per-lane row offset from the same conflict-free LDS image as before.
-// Per wave and k-step of 4: 32x32 of C = 16 instructions (256 pipe cycles) and 8 LDS reads.
-//
-// Accumulator acc[x][y][s][t], lane (i = l >> 4, b = (l >> 2) & 3, j = l & 3) holds
-//   C(row = 16 x + 4 ((b + s) & 3) + j,  col = 16 y + 4 ((b + 2 t) & 3) + i)   of the wave's 32x32 tile.
-#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
-
-#define DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-// wait until at most N LDS operations are outstanding; ties the wait to the registers it guards
-#define WAIT_LGKM(N, P)                                                                  \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                             \
-                 : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(P[5]), "+v"(P[6]), "+v"(P[7]))
-// P = { rows x=0 rot 0, rows x=0 rot 1, cols y=0 rot 0, cols y=0 rot 2, then the same for x = y = 1 }
-#define MFMA_STEP(P)                                                                     \
-    do {                                                                                 \
-        _Pragma("unroll") for (int x = 0; x < 2; ++x)                                    \
-        _Pragma("unroll") for (int y = 0; y < 2; ++y)                                    \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                    \
-            acc[x][y][s][t] = MFMA4(P[4 * y + 2 + t], P[4 * x + s], acc[x][y][s][t]);   \
-    } while (0)
-
-// The kernel: operand chunks go global -> LDS directly (global_load_lds_dwordx4, 1 KB per wave-instruction,
-// no staging registers, no ds_write) into a ring of NS stages that runs NS-1 chunks ahead; one raw
-// s_barrier per chunk, counted vmcnt waits (never 0 inside the loop).  The operand slices are read with
-// hand-placed ds_read_b64 (left to itself the compiler fuses neighbouring reads into ds_read2_b64 /
-// ds_read2st64_b64, which run at half the LDS rate) and explicit lgkmcnt waits: the eight reads of the
-// second k-step of a chunk are in flight while the sixteen instructions of the first issue.  LDS image of one operand side per stage: 8 columns x 64 rows, 512 B
-// per column, UNPADDED (a DMA instruction's 1 KB must be contiguous) and made conflict-free by an XOR
-// swizzle of bit 7 of the row byte for odd columns; the DMA realises it through its per-lane SOURCE address.
-template <int ROLE>
-__global__ void __launch_bounds__(256, 5)
-update4_kernel(UpdArgs a)
-{
-    constexpr int TM = 64, KC = 8, NS = 4;
-    constexpr unsigned SIDE_B = KC * 64 * 8, STAGE_B = 2 * SIDE_B;     // 4 KB per side, 8 KB per stage
-    int ti, tj;
-    if (a.lower_only) {
-        long long L = blockIdx.x;
-        const double hh = 2.0 * a.H + 1.0;
-        int j = (int)((hh - sqrt(hh * hh - 8.0 * (double)L)) * 0.5);
-        while (j > 0 && (long long)j * a.H - (long long)j * (j - 1) / 2 > L) --j;
-        while ((long long)(j + 1) * a.H - (long long)(j + 1) * j / 2 <= L) ++j;
-        const long long c0 = (long long)j * a.H - (long long)j * (j - 1) / 2;
-        tj = a.tj0 + j;
-        ti = a.tj0 + j + (int)(L - c0);
-    } else {
-        ti = a.ti0 + blockIdx.x;
-        tj = a.tj0 + blockIdx.y;
-    }
-    if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;
-    const int sig_Ti = (ti * TM) / TILE - a.sig_tile, sig_Tj = (tj * TM) / TILE - a.sig_tile;
-    const bool sig_wg = a.sig != nullptr && sig_Ti >= 0 && sig_Ti <= 1 && sig_Tj >= 0 && sig_Tj <= sig_Ti;
-    extern __shared__ double upd4_smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave & 1, wj = wave >> 1;
-    if (a.wait_word) {     // operand tile comes from the engine
-        int *wait_ok = (int *)upd4_smem;
-        if (tid == 0) *wait_ok = wait_ge(a.wait_word, 1u, a.abort_word, 0x500u + a.tj0) ? 1 : 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int ok = *wait_ok;
-        __syncthreads();
-        if (!ok) return;
-    }
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)upd4_smem;
-
-    // DMA source: lane l of wave w fills bytes [1024 w + 16 l, +16) of a side image = column k = 2 w + (l >> 5),
-    // physical row bytes 16 (l & 31); with the swizzle that slot holds rows r, r+1, r = 2 (l & 31) ^ (16 (k & 1))
-    const int kd = 2 * wave + (lane >> 5);
-    const int rd = (2 * (lane & 31)) ^ ((lane >> 5) << 4);
-    const double *gI = a.P + (size_t)(ti * TM + rd) + (size_t)kd * a.ldp;
-    const double *gJ = a.P + (size_t)(tj * TM + rd) + (size_t)kd * a.ldp;
-    const size_t cstride = (size_t)KC * a.ldp;
-    const unsigned dma_dst = lds0 + 1024u * (unsigned)wave;
-#define GLDS16(gsrc, ldsdst)                                                                          \
-    do {                                                                                              \
-        unsigned keep_;                                                                               \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep_) : "v"(gsrc), "s"(ldsdst) : "memory");                             \
-    } while (0)
-#define ISSUE_CHUNK(c, stage)                                                                         \
-    do {                                                                                              \
-        const double *pi_ = gI + (size_t)(c) * cstride, *pj_ = gJ + (size_t)(c) * cstride;            \
-        GLDS16(pi_, dma_dst + (unsigned)(stage) * STAGE_B);                                           \
-        GLDS16(pj_, dma_dst + (unsigned)(stage) * STAGE_B + SIDE_B);                                  \
-    } while (0)
-
-    double acc[2][2][2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc[x][y][s][t] = 0.0;
-
-    const int nch = a.K / KC;          // a multiple of NS (K is a multiple of 128)
-#pragma unroll
-    for (int c = 0; c < NS - 1; ++c) ISSUE_CHUNK(c, c);
-
-    // operand read addresses (bytes, stage 0): physical (row, k) = 512 k + ((8 row) ^ (128 (k & 1))), k = kq here
-    const int kq = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
-    const unsigned sw = (unsigned)(kq & 1) << 7;
-    unsigned aP[8];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        aP[4 * x + 0] = lds0 + 512u * kq + ((8u * (unsigned)(32 * wi + 16 * x + 4 * bq + jq)) ^ sw);
-        aP[4 * x + 1] = lds0 + 512u * kq + ((8u * (unsigned)(32 * wi + 16 * x + 4 * ((bq + 1) & 3) + jq)) ^ sw);
-        aP[4 * x + 2] = lds0 + SIDE_B + 512u * kq + ((8u * (unsigned)(32 * wj + 16 * x + 4 * bq + jq)) ^ sw);
-        aP[4 * x + 3] = lds0 + SIDE_B + 512u * kq + ((8u * (unsigned)(32 * wj + 16 * x + 4 * ((bq + 2) & 3) + jq)) ^ sw);
-    }
-    // P = { rows x=0 rot 0, rows x=0 rot 1, cols y=0 rot 0, cols y=0 rot 2, then the same for x = y = 1 }
-#define ISSUE_STEP_D(P, stage, S4)                                                                    \
-    do {                                                                                              \
-        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                              \
-            DSR64(P[q_], aP[q_], (stage) * STAGE_B + (S4) * 2048);                                    \
-    } while (0)
-    for (int c0 = 0; c0 < nch; c0 += NS) {
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            const int c = c0 + st;
-            // chunk c has landed once at most 2 * min(chunks issued after it, NS - 2) DMA instructions are outstanding
-            const int rem = nch - 1 - c;
-            if (rem >= NS - 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (c + NS - 1 < nch) ISSUE_CHUNK(c + NS - 1, (st + NS - 1) % NS);
-            double PA[8], PB[8];
-            ISSUE_STEP_D(PA, st, 0);
-            ISSUE_STEP_D(PB, st, 1);
-            WAIT_LGKM(8, PA);
-            MFMA_STEP(PA);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(PB[0]), "+v"(PB[1]), "+v"(PB[2]), "+v"(PB[3]), "+v"(PB[4]),
-                         "+v"(PB[5]), "+v"(PB[6]), "+v"(PB[7]), "+v"(acc[1][1][1][1]));
-            MFMA_STEP(PB);
-        }
-    }
-    // C -= acc: all sixteen loads first, then the stores
-    double *Cb = a.C + (size_t)(ti * TM + (TM / 2) * wi + jq) + (size_t)(tj * TM + (TM / 2) * wj + kq) * a.ldc;
-    double cv[2][2][2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    cv[x][y][s][t] = Cb[(16 * x + 4 * ((bq + s) & 3)) + (size_t)(16 * y + 4 * ((bq + 2 * t) & 3)) * a.ldc];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    double *p = Cb + (16 * x + 4 * ((bq + s) & 3)) + (size_t)(16 * y + 4 * ((bq + 2 * t) & 3)) * a.ldc;
-                    if (sig_wg) store_wt(p, cv[x][y][s][t] - acc[x][y][s][t]); else *p = cv[x][y][s][t] - acc[x][y][s][t];
-                }
-    if (sig_wg) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) signal_add(a.sig + a.sig_tile + sig_Ti);
     }
 }
 
@@ -1880,48 +982,62 @@ void launch_trmm_lower(const double *A, size_t lda, int n, const double *E, int 
 }
 
 // ---------------------------------------------------------------------------
+// the attribute that allows more than 64 KB of dynamic LDS is per kernel and device: set once, not per launch
+static void set_dynamic_lds_once(const void *kernel, size_t bytes, std::atomic<unsigned long long> &done_mask)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && ((done_mask.load(std::memory_order_relaxed) >> dev) & 1ull)) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (dev >= 0 && dev < 64) done_mask.fetch_or(1ull << dev, std::memory_order_relaxed);
+}
+
 void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, hipStream_t s)
 {
     const size_t shm = (36 + 1) * 256 * sizeof(double);   // 75,776 B of dynamic LDS (> the 64 KB default)
-    // per device and cheap: set on every launch rather than caching a process-wide flag
-    (void)hipFuncSetAttribute((const void *)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    static std::atomic<unsigned long long> attr_done{0};
+    set_dynamic_lds_once((const void *)potrf_tile_kernel, shm, attr_done);
     hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), shm, s, A, lda, c0, dinv, info);
 }
 
-void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile)
+void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile, bool patient)
 {
     // last_tile: not the start-up gate (is the engine resident? 5 ms, code 0x600) but the wait of the reductions for the
     // engine's LAST diagonal tile when no panel kernel has waited for it (code 0x900, the hand-offs' 100 ms bound)
+    // patient: the start-up gate of a handle's FIRST engine-schedule operation -- 50 ms instead of 5: whatever a first
+    // dispatch on a fresh stream may still cost the runtime (the warm-up launch of the handle has paid what it can) must
+    // not be mistaken for "every CU is taken by someone else"
     hipLaunchKernelGGL(engine_gate_kernel, dim3(1), dim3(64), 0, s, alive, abort_word, last_tile ? 0x900u : 0x600u,
-                       last_tile ? ENGINE_TIMEOUT_TICKS : GATE_TIMEOUT_TICKS);
+                       last_tile ? ENGINE_TIMEOUT_TICKS : (patient ? 10 * GATE_TIMEOUT_TICKS : GATE_TIMEOUT_TICKS));
 }
 
-void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
-                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
-                         double *winv, int w_until, int fused, double *wfull, double *wT)
+// Dynamic LDS of the engine.  136 KB: the 128 KB LDS copy of X plus the flag word; leaves room for ONE update workgroup
+// beside the engine.  (Asking for all 160 KB measured 7 % slower trailing updates chip-wide while the engine was
+// resident; 76 .. 152 KB did not.)  The function attribute that allows it is set once per device, not per launch.
+static size_t engine_lds_bytes()
 {
-    if (t0 >= nt) return;
+    static size_t shm = 0;
+    if (!shm) {
+        shm = 136 * 1024;
+        const char *x = getenv("COCONS_ENGINE_LDS");
+        if (x && (size_t)atol(x) >= shm) shm = (size_t)atol(x);
+    }
+    return shm;
+}
+
+// t0 >= nt: the kernel is launched all the same, raises its alive word and leaves at once -- the WARM-UP launch of a
+// handle (api.hip): whatever the first dispatch of this kernel on this stream costs the runtime (queue set-up, code
+// object, LDS configuration) is paid there and not inside the bounded gate of the first engine-schedule operation.
+void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
+                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s)
+{
     EngineArgs e;
     e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
-    e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive; e.winv = winv;
-    e.wfull = wfull; e.wT = wT;
-    e.w_until = (winv || wfull) ? w_until : 0; e.fused = fused;
-    // 136 KB: the 128 KB LDS copy of X plus the flag word; leaves room for ONE update workgroup beside the
-    // engine.  (Asking for all 160 KB measured 7 % slower trailing updates chip-wide while the engine was
-    // resident; 76 .. 152 KB did not.)
-    size_t shm = 136 * 1024;
-    { const char *x = getenv("COCONS_ENGINE_LDS"); if (x && (size_t)atol(x) >= shm) shm = (size_t)atol(x); }
-    const int w = e.w_until > 0 ? (wfull ? 2 : 1) : 0;
-    const bool fu = fused != 0;
-    const void *k = w == 2 ? (const void *)potrf_engine_kernel<false, 2>
-                  : w == 1 ? (fu ? (const void *)potrf_engine_kernel<true, 1> : (const void *)potrf_engine_kernel<false, 1>)
-                           : (fu ? (const void *)potrf_engine_kernel<true, 0> : (const void *)potrf_engine_kernel<false, 0>);
-    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    if (w == 2) hipLaunchKernelGGL((potrf_engine_kernel<false, 2>), dim3(1), dim3(512), shm, s, e);
-    else if (w == 1 && fu) hipLaunchKernelGGL((potrf_engine_kernel<true, 1>), dim3(1), dim3(512), shm, s, e);
-    else if (w == 1) hipLaunchKernelGGL((potrf_engine_kernel<false, 1>), dim3(1), dim3(512), shm, s, e);
-    else if (fu) hipLaunchKernelGGL((potrf_engine_kernel<true, 0>), dim3(1), dim3(512), shm, s, e);
-    else hipLaunchKernelGGL((potrf_engine_kernel<false, 0>), dim3(1), dim3(512), shm, s, e);
+    e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive;
+    const size_t shm = engine_lds_bytes();
+    static std::atomic<unsigned long long> attr_done{0};
+    set_dynamic_lds_once((const void *)potrf_engine_kernel, shm, attr_done);
+    hipLaunchKernelGGL(potrf_engine_kernel, dim3(1), dim3(512), shm, s, e);
 }
 
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
@@ -1942,46 +1058,25 @@ static long long upd_w8_max_tiles = -1;      // 8-wave workgroups only for launc
 void set_update_waves(int nw) { upd_waves = nw == 8 ? 8 : 4; }
 void set_update_w8_max_tiles(int ntiles) { upd_w8_max_tiles = ntiles < 0 ? 0 : ntiles; }
 
-
-// COCONS_UPD_MFMA4=1 selects the 4x4x4 kernel for the updates (static tile order only)
-static bool upd_form4()
-{
-    static int form4 = -1;
-    if (form4 < 0) { const char *e = getenv("COCONS_UPD_MFMA4"); form4 = e ? atoi(e) : 0; }
-    return form4 != 0;
-}
-bool update_alt_form() { return upd_form4(); }
-
-bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
+void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig, int sig_tile,
                         unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
-                        unsigned *near, int near_tiles, const UpdStrips *strips, int skew, int kblk, const UpdRedirect *redir,
-                        int trim64)
+                        int skew, int kblk, int trim64)
 {
     // tile rows [ti0, ti1), or -- band-limited -- [ti0, band_hi) and [ext0, ti1)
     const bool band = band_hi >= 0;
     const int rows_band = (band ? band_hi : ti1) - ti0, rows_ext = band ? ti1 - ext0 : 0;
-    if (rows_band + rows_ext <= 0 || rows_band < 0 || rows_ext < 0 || tj1 <= tj0 || K <= 0) return false;
+    if (rows_band + rows_ext <= 0 || rows_band < 0 || rows_ext < 0 || tj1 <= tj0 || K <= 0) return;
     trim64 = trim64 ? 1 : 0;
     const int rows64 = 2 * (rows_band + rows_ext) - trim64;        // 64-row tiles the launch covers
-    if (rows64 <= 0) return false;
+    if (rows64 <= 0) return;
     if (upd_waves < 0) { const char *e = getenv("COCONS_UPD_WAVES"); set_update_waves(e ? atoi(e) : 8); }
     if (upd_w8_max_tiles < 0) { const char *e = getenv("COCONS_UPD_W8_MAX_TILES"); set_update_w8_max_tiles(e ? atoi(e) : 3500); }
     bool use_w8 = false;
     UpdArgs a;
     a.queue = nullptr; a.ntiles = 0;
-    a.near = near; a.near_tj0 = 2 * tj0; a.near_w = 2 * near_tiles;
-    a.nstrips = 0; a.strip_pos = 0; a.near_need = 0;
-    memset(&a.pan, 0, sizeof a.pan);
     a.skew = skew; a.kblk = kblk;
-    a.redir_off = 0; a.redir_ti0 = 0;
-    if (redir && redir->pin && lower_only && ti0 == tj0 && !band && !skew && world == 1 && tj1 - tj0 >= 2 &&
-        rows_band >= 3 && !(strips && strips->nstrips > 0)) {
-        // element (row, tj0 * 128 + c) of the matrix <-> pin[row + c * lda]
-        a.redir_off = (long long)(redir->pin - A) - (long long)tj0 * TILE * (long long)lda;
-        a.redir_ti0 = 2 * redir->row_tile0;
-    }
     a.Hb = 2 * rows_band; a.ext0 = 2 * ext0;
     a.C = A; a.ldc = lda; a.P = P; a.ldp = ldp; a.K = K;
     a.lower_only = lower_only ? 1 : 0;
@@ -1999,7 +1094,7 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
         else {
             const long long H = rows64, W = 2LL * (tj1 - tj0);
             a.H = (int)H; a.W = (int)W;
-            long long total = W * H - W * (W - 1) / 2;
+            const long long total = W * H - W * (W - 1) / 2;
             static int slots = 0;
             if (!slots) {
                 int dev = 0, cus = 256;
@@ -2007,28 +1102,12 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
                 slots = 8 * cus;
             }
-            // (a strip waits for tiles of this launch: every workgroup must be resident or draw its tasks in order)
-            if (strips && strips->nstrips > 0 && near && !band && world == 1 && !upd_form4() &&
-                (queue || total + strips->nstrips <= slots - 8)) {
-                // the next panel's strips ride in this launch, `lead` tiles behind the near tiles (time for the engine)
-                const long long nnear = (long long)update_near_count(ti0, ti1, near_tiles) - 2LL * near_tiles * trim64;
-                long long pos = nnear + strips->lead;
-                if (pos > total) pos = total;
-                a.nstrips = strips->nstrips; a.strip_pos = (unsigned)pos; a.near_need = (unsigned)nnear;
-                a.pan.A = A; a.pan.lda = lda; a.pan.c0 = tj0 * TILE; a.pan.two = near_tiles > 1 ? 1 : 0;
-                a.pan.row0 = strips->row0;
-                a.pan.w0 = strips->winv + (size_t)(tj0 & 1) * TILE * TILE;
-                a.pan.w1 = strips->winv + (size_t)((tj0 + 1) & 1) * TILE * TILE;
-                a.pan.out0 = strips->out + tj0; a.pan.xr0 = strips->xr + tj0; a.pan.out1 = strips->out + tj0 + 1;
-                a.pan.abort_word = abort_word;
-                total += a.nstrips;
-            }
             grid = dim3((unsigned)total, 1);
-            if (queue && world == 1 && !upd_form4()) {
+            if (queue && world == 1) {
                 // dynamic tile order: as many workgroups as the chip holds (8 per CU), tiles off *queue (zero now)
                 // (one CU's worth fewer: the engine owns a CU, and a workgroup that is not resident from the
                 // start would take its first, static tile late)
-                const bool w8 = upd_waves == 8 && K >= 2 * TILE && a.nstrips == 0 && !skew &&
+                const bool w8 = upd_waves == 8 && K >= 2 * TILE && !skew &&
                                 (upd_w8_max_tiles == 0 || total <= upd_w8_max_tiles);
                 use_w8 = w8;
                 const int cap = w8 ? slots / 2 - 4 : slots - 8;       // resident workgroups: 4 or 8 per CU, one CU's worth fewer
@@ -2040,40 +1119,18 @@ bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
         }
     }
     const bool trailing = (K > TILE) && world == 1;     // (the first trailing update has K = 256 - front padding: still role 0)
-    // default: the 16x16x4 kernel (8 waves per SIMD, pipe-bound at the instruction's 48.7 TFLOP/s).
-    // COCONS_UPD_MFMA4=1 selects the 4x4x4 kernel: its instruction peaks at 76 TFLOP/s, but at a 32x32
-    // tile per wave, one barrier per 32 instructions and 5 waves per SIMD the kernel around it lands
-    // where the default does (what it needs next)
-    if (!upd_form4() || skew) {     // (the alternative kernel knows no packed band buffer)
-        if (a.nstrips > 0) hipLaunchKernelGGL((update_kernel<64, 8, 0, true>), grid, dim3(256), 0, s, a);
-        else if (trailing && use_w8 && a.lower_only)
-            hipLaunchKernelGGL((update_kernel<64, 16, 0, false, 8>), grid, dim3(512), 0, s, a);
-
-        else if (trailing) hipLaunchKernelGGL((update_kernel<64, 8, 0>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((update_kernel<64, 8, 1>), grid, dim3(256), 0, s, a);
-    } else {
-        if (trailing) hipLaunchKernelGGL((update4_kernel<0>), grid, dim3(256), 4 * 8192, s, a);
-        else hipLaunchKernelGGL((update4_kernel<1>), grid, dim3(256), 4 * 8192, s, a);
-    }
-    return a.nstrips > 0;
+    if (trailing && use_w8 && a.lower_only) hipLaunchKernelGGL((update_kernel<64, 16, 0, 8>), grid, dim3(512), 0, s, a);
+    else if (trailing) hipLaunchKernelGGL((update_kernel<64, 8, 0>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((update_kernel<64, 8, 1>), grid, dim3(256), 0, s, a);
 }
 
-bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
+void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig, int sig_tile,
                    unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
-                   unsigned *near, int near_tiles, const UpdStrips *strips, int skew, const UpdRedirect *redir, int trim64)
+                   int skew, int trim64)
 {
-    return launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile,
-                              wait_word, abort_word, queue, band_hi, ext0, near, near_tiles, strips, skew, k0 / TILE, redir,
-                              trim64);
-}
-
-// tiles of 64 x 64 in the first `near_tiles` (128-wide) tile columns of the trapezoid launch_update(..., lower_only, ti0 ==
-// tj0, rows up to ti1) covers: what *near counts up to
-unsigned update_near_count(int ti0, int ti1, int near_tiles)
-{
-    const int H = 2 * (ti1 - ti0), W = 2 * near_tiles;
-    return (unsigned)(W * H - W * (W - 1) / 2);
+    launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile,
+                       wait_word, abort_word, queue, band_hi, ext0, skew, k0 / TILE, trim64);
 }
 
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
@@ -2181,6 +1238,7 @@ mfma_f64_probe_ex_kernel(double *out, unsigned long long *stamp, int iters, doub
     if (threadIdx.x == 0) { stamp[2 * blockIdx.x] = c1 - c0; stamp[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 // FORM 3: sixteen accumulators fed from four + four DISTINCT operand registers (no LDS traffic): tells
 // operand-register switching apart from the LDS feed
 __global__ void __launch_bounds__(256)

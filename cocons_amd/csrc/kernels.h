@@ -118,28 +118,10 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
 //   xr[t]    raised to 1 when X = A(t+1,t) L(t)^-T is published.
 // abort_word: set by any party whose bounded wait ran out; everybody leaves when it is non-zero.
 //   alive    raised by the engine once it is resident; launch_engine_gate(alive, ...) holds a stream until then
-// winv != NULL: 2 x 128 x 128 doubles, zero at launch outside what the engine writes -- the engine also publishes
-//   W = L^-1 of every diagonal tile there (by tile parity, column-major, ld 128) BEFORE it raises out[tile]: the operand
-//   of launch_panel
+// t0 >= nt: a warm-up launch -- the kernel raises alive and leaves (first-dispatch costs paid outside any bounded wait)
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
-                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
-                         double *winv = nullptr, int w_until = 0,      // W only for blocks starting at a tile < w_until
-                         int fused = 1,    // the other blocks: strip solve and tile update folded into the first tile's factorisation
-                         double *wfull = nullptr, double *wT = nullptr);   // wfull != NULL: the inverse of the whole 256 x 256 block
-                                           // factor (256 x 256, ld 256, zeroed once by the caller) instead of the tile inverses,
-                                           // complete when xr[t] reaches 2; wT: 128 x 128 scratch
-// Panel of the 256-column block at tile t as ONE tile-parallel product X = B Wf^T (rows [r0, r1), multiples of 64):
-// B from the scratch panel `pin` (element (row, c) at pin[row + c lda]; filled by the preceding trailing update through
-// UpdRedirect), Wf = wfull of launch_potrf_engine, X into the matrix.  Waits for wflag >= 2.
-void launch_panel_gemm(double *A, size_t lda, int t, int r0, int r1, const double *pin, const double *wfull,
-                       unsigned *wflag, unsigned *abort_word, hipStream_t s);
-// Panel of the 256-column block at tile t under the engine schedule, ONE launch: rows [r0, r1) (multiples of 64) of
-// tile columns t and (two != 0) t + 1:   X0 = B0 W(t)^T ;  B1 -= X0 X(t+1,t)^T ;  X1 = B1 W(t+1)^T  -- the panel solve as
-// three small GEMMs per 64-row strip on the update kernel's inner loop and footprint (no dependent chain).  Each
-// stage first waits for the engine's word: out[t] (factor and W of tile t), xr[t] (X(t+1,t)), out[t+1].
-void launch_panel(double *A, size_t lda, int t, int two, int r0, int r1, const double *winv,
-                  unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s);
-void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false);
+                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s);
+void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false, bool patient = false);
 // rows [r0, r1) x cols [c0, c0+128):  X <- X * L(c0)^{-T}, L read from A(c0,c0).
 // wait_word != NULL: the tile comes from the engine -- every workgroup first waits for *wait_word >= 1
 // band_r1 >= 0 (band-limited factorisation): rows [r0, band_r1) and [ext_r0, r1) instead of [r0, r1).
@@ -151,51 +133,26 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
 // wait_word: an operand tile comes from the engine -- every workgroup first waits for *wait_word >= 1.
 // queue: a device word that is ZERO when the launch starts -- the launch then takes about as many workgroups
 // as the chip holds and they draw the tiles of the trapezoid from that counter (lower_only launches).
-// Strips of the NEXT panel as tasks of a trailing-update launch (launch_update's `strips`, with `near`): the 64-row strips
-// from row0 on, nstrips of them, the block's panel as launch_panel computes it, taken by the launch's workgroups `lead`
-// tiles behind the near tiles.  winv / out / xr as for launch_panel.
-struct UpdStrips {
-    int nstrips, row0, lead;
-    const double *winv;
-    unsigned *out, *xr;
-};
-// Trailing update whose results for the NEXT panel's columns (the first two tile columns of the trapezoid), tile rows
-// >= row_tile0, go into the scratch panel `pin` instead of into the matrix (launch_panel_gemm reads them there)
-struct UpdRedirect {
-    double *pin;
-    int row_tile0;
-};
-// (returns true when `strips` were taken into the launch; false: the caller forms the panel itself, e.g. launch_panel)
-bool launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
+void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig = nullptr, int sig_tile = -1,
                    unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
                    int band_hi = -1, int ext0 = 0,       // band_hi >= 0: tile rows [ti0, band_hi) and [ext0, ti1)
-                   unsigned *near = nullptr, int near_tiles = 0, const UpdStrips *strips = nullptr,
                    int skew = 0,           // packed band buffer (band_index; with band_hi / ext0): A is its unshifted base
-                   const UpdRedirect *redir = nullptr,
                    int trim64 = 0);        // 1: the last 64 rows of the row range hold nothing (a 128-row tile of right-hand
                                            // sides of which at most 64 rows are used): they are not updated
-// near / near_tiles (lower_only launches): the tiles in the first near_tiles tile columns -- the next panel -- are stored
-// write-through and each adds 1 to *near when done; update_near_count() says how many there are (the strips of panel mode 2
-// wait for that count inside the launch).
-unsigned update_near_count(int ti0, int ti1, int near_tiles);
-// waves per workgroup of the trailing-update kernel: 4 (default) or 8 (512 threads, KC = 16: half the tile latency)
+// waves per workgroup of the trailing-update kernel: 4 or 8 (512 threads, KC = 16: half the tile latency; default for
+// launches of at most set_update_w8_max_tiles tiles, 0 = every launch)
 void set_update_waves(int nw);
-bool update_alt_form();                 // COCONS_UPD_MFMA4=1: the alternative update kernel (K must be a multiple of 128)
 void set_update_w8_max_tiles(int ntiles);
-void set_update_w8_inpanel(int on);     // ... only for launches of at most this many tiles (0 = every launch)
 // like launch_update but the (i,k) and (j,k) operands come from a separate packed
 // panel buffer P (ldp rows, row index = global row), used by the sharded path.
 // (ptiles, world, rank): when world > 1 only tile columns tj with (tj / ptiles) % world == rank
 // are updated (block-cyclic panel ownership).
-bool launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
+void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig = nullptr, int sig_tile = -1,
                         unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
-                        int band_hi = -1, int ext0 = 0, unsigned *near = nullptr, int near_tiles = 0,
-                        const UpdStrips *strips = nullptr, int skew = 0, int kblk = 0, const UpdRedirect *redir = nullptr,
-                        int trim64 = 0);
-
+                        int band_hi = -1, int ext0 = 0, int skew = 0, int kblk = 0, int trim64 = 0);
 
 // reductions: out[0] = sum_{i<n} log(A(i,i)); out[1 + a*nr + b] = sum_{c<n} A(row0+a,c) A(row0+b,c)
 void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s,

@@ -38,7 +38,8 @@ int cocons_debug_matern(int n, const double *nu, const double *u, double *out);
 int cocons_corun_probe(int bpc_mfma, int bpc_vfma, int iters_mfma, int iters_vfma, double *out4);
 
 /* Schedule switches of the factorisation, settable at run time (the library reads the COCONS_* environment variables
- * of the same meaning once per process): "engine", "panel_mode", "strip_lead", "strip_min", "overlap", "upd_dynamic".
+ * of the same meaning once per process): "engine", "upd_dynamic", "upd_waves", "w8_max_tiles" (and, for the tests,
+ * "gate_sabotage").
  * For timing variants in alternation inside one process (tools/ab_modes.py); results do not depend on them beyond the
  * rounding of a different summation order.                                                                        */
 int cocons_debug_tune(const char *name, int value);

@@ -450,12 +450,13 @@ def test_multi_handle_replica_batch(oracle):
 
 
 @pytest.mark.shared_gpu
-def test_worker_processes_share_one_gpu(tmp_path):
+def test_worker_processes_share_one_gpu(tmp_path, record_property):
     """The reference's own calling pattern on the HIP path: `ncores` worker PROCESSES (here 3), each with a handle of
     its own on the one device, evaluating concurrently at n = 4096 (R/optim.R:117-121, 234-259).  Every value must
     equal the single-process value; each process's engine needs a CU to itself while the others' updates fill the
-    chip, so hand-off time-outs are allowed here -- each costs one repeat on the plain schedule and is counted.  The
-    per-process count and wall time are printed (and recorded in DESIGN.md)."""
+    chip, so hand-off time-outs are allowed here -- each costs one repeat on the plain schedule and is counted; the
+    back-off bounds them (asserted).  Per-process count, last abort code and wall time go into the test record
+    (record_property) and DESIGN.md."""
     import torch.multiprocessing as mp
     import cocons_amd as ca
     from cocons_amd import workloads as wl
@@ -472,8 +473,13 @@ def test_worker_processes_share_one_gpu(tmp_path):
             t["std.dev"][1] += 0.01 * (rank * nevals + e)
             want = fit.neg2loglik_core(t)[0]
             assert abs(res[e] - want) <= 1e-10 * abs(want), (rank, e)
-        print("worker %d: %d evaluations in %.1f ms, engine time-outs %d (last code 0x%x), engine active at the end: %d"
-              % (rank, nevals, 1e3 * res[nevals + 3], int(res[nevals]), int(res[nevals + 1]), int(res[nevals + 2])))
+        line = ("%d evaluations in %.1f ms, engine time-outs %d (last code 0x%x), engine active at the end: %d"
+                % (nevals, 1e3 * res[nevals + 3], int(res[nevals]), int(res[nevals + 1]), int(res[nevals + 2])))
+        print("worker %d: %s" % (rank, line))
+        record_property("worker%d" % rank, line)              # (pytest -q swallows the print; the junit / driver record keeps this)
+        # the back-off bounds what a process can lose: a time-out sends the next 2, 4, ... operations to the plain schedule,
+        # so eleven operations hold at most three
+        assert int(res[nevals]) <= 3, (rank, line)
     single = time.perf_counter() - t0
     print("the same %d evaluations from ONE process, one after the other: %.1f ms" % (world * nevals, 1e3 * single))
     assert fit.engine_state()["retries"] == 0            # alone on the device the engine never times out

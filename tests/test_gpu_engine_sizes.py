@@ -253,9 +253,24 @@ def test_front_padding_n2115_all_entry_points_vs_oracle(oracle):
     th2["nugget"] = np.array([-np.inf, 0.0, 0.0])
     fit2 = ca.CoconsFit(locs2, X2, z[:, 0], wl.SMOOTH_LIMITS)
     try:
-        fit2.neg2loglik_core(th2)          # exactly singular: whether the pivot at the duplicate comes out <= 0 or a rounding
+        v = fit2.neg2loglik_core(th2)[0]   # exactly singular: whether the pivot at the duplicate comes out <= 0 or a rounding
     except ca.CholeskyError as e:          # error above it depends on the schedule (LAPACK's dpotrf is no different); the default
         assert 1 <= e.minor <= n           # schedule reports it, and then in the caller's numbering
+    else:
+        assert np.isfinite(v)              # a rounding error above zero: a finite value, as dpotrf would return
+    fit2.close()
+    # ... and a matrix whose failure is NOT a matter of rounding: fixed smoothness 1 (not one of the closed forms) leaves every
+    # off-diagonal entry equal to the diagonal (SURVEY 8a#6 quirk i), so with constant variance the second pivot is exactly
+    # 1 - 1 * 1 = 0: a report is mandatory and names minor 2
+    th3 = {k: np.zeros(3) for k in th}
+    th3["scale"] = np.array([np.log(0.05), 0.0, 0.0])
+    th3["nugget"] = np.array([-np.inf, 0.0, 0.0])
+    th3["mean"] = np.zeros(3)
+    fit3 = ca.CoconsFit(locs, X, z[:, 0], (1.0, 1.0))
+    with pytest.raises(ca.CholeskyError) as ei:
+        fit3.neg2loglik_core(th3)
+    assert ei.value.minor == 2
+    fit3.close()
 
 
 def test_repeated_evaluations_are_bit_identical():
