@@ -271,6 +271,15 @@ struct cocons_fit {
     int engine_retries;           // time-outs in the life of the handle, each answered by one repeat on the plain schedule
     int engine_last_abort;        // abort word of the last time-out (who gave up: see info_status)
     long long engine_ops;         // operations enqueued on the engine schedule so far (the first one's gate is patient)
+    // dependency-driven schedule (factorize_dag): second buffer shaped like dA, tile inverses, task words, step table
+    double *dP; size_t dP_elems;
+    double *dWt; int dWt_tiles;
+    unsigned *ddag; size_t ddag_words;      // [queue (64 words)] [tdone] [pdone]
+    void *ddag_steps; int dag_nsteps; unsigned dag_ntasks;
+    int dag_key[5];               // (nt, mt, trim, kskip, lead) the step table was built for
+    unsigned long long *ddag_trace; size_t dag_trace_tasks;   // diagnostics (cocons_debug_tune("dag_trace", 1)): 4 stamps per task
+    bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
+    bool dag_used;                // the factorisation enqueued last ran the DAG schedule: its factor is split over dA and dP
     // taper fit (cocons_fit_create_taper): the spam pattern (1-based CSR) with the taper's entries; the
     // -2 log-likelihood is then that of the TAPERED covariance, evaluated through the dense factorisation
     int taper_nnz;                // > 0: taper fit
@@ -343,6 +352,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
         if (f->ev_eng) hipEventDestroy(f->ev_eng);
         hipFree(f->dflags);
+        hipFree(f->dP); hipFree(f->dWt); hipFree(f->ddag); hipFree(f->ddag_steps); hipFree(f->ddag_trace);
         hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_thi);
         if (f->cstream) { hipStreamSynchronize(f->cstream); hipStreamDestroy(f->cstream); }
         for (auto &e : f->ev_main) if (e) hipEventDestroy(e);
@@ -833,6 +843,8 @@ struct FactorView {
     int skew = 0;              // > 0: A is a packed band buffer (kernels.h band_index) of `skew` tile rows per tile column
     int trim = 0;              // 1: the last 64 of the mt * 128 rows hold nothing (the tile of right-hand sides has at most 64
                                // rows in use): no kernel of the factorisation touches them
+    bool dag_ok = false;       // the caller reads the factor through launch_finalize(..., A2 = dP) only: the dependency-driven
+                               // schedule may be used (its factor is split over two buffers)
 };
 
 static FactorView main_view(cocons_fit *f)
@@ -880,6 +892,9 @@ static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
 struct Tunables {
     int engine = 1;          // COCONS_ENGINE: 1 = diagonal blocks are factored by the resident engine beside the updates
     int upd_dynamic = 1;     // COCONS_UPD_DYNAMIC
+    int dag = 0;             // COCONS_DAG: 1 = the dependency-driven schedule (one persistent launch for all updates and panels)
+    int dag_lead = 3600;     // COCONS_DAG_LEAD: far tiles of a step in front of its panel tasks
+    int dag_trace = 0;       // (diagnostics) time stamps per task, cocons_debug_dag_trace
     int gate_sabotage = 0;   // (tests) the next N engine-schedule factorisations wait at the gate for a word nobody raises:
                              // a genuine 5 ms time-out, abort code 0x600, to exercise the fall-back and its book-keeping
     bool init = false;
@@ -891,6 +906,8 @@ static Tunables &tun()
         auto rd = [](const char *name, int &v) { const char *e = getenv(name); if (e) v = atoi(e); };
         rd("COCONS_ENGINE", t.engine);
         rd("COCONS_UPD_DYNAMIC", t.upd_dynamic);
+        rd("COCONS_DAG", t.dag);
+        rd("COCONS_DAG_LEAD", t.dag_lead);
         t.init = true;
     }
     return t;
@@ -903,9 +920,13 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     std::string k(name);
     if (k == "engine") t.engine = value;
     else if (k == "upd_dynamic") t.upd_dynamic = value;
+    else if (k == "dag") t.dag = value;
+    else if (k == "dag_lead") t.dag_lead = value;
+    else if (k == "dag_trace") t.dag_trace = value;
     else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
+    else if (k == "c_wt") set_update_c_wt(value);
     else return fail(-1, "cocons_debug_tune: unknown switch %s", name);
     return 0;
 }
@@ -998,9 +1019,84 @@ static int engine_warm(cocons_fit *f)
     HIPCHK(hipStreamSynchronize(f->stream));
     launch_potrf_engine(nullptr, 0, 0, 0, f->dinv, f->dinfo, f->dflags, f->dflags, f->dflags, (unsigned *)(f->dinfo + 1),
                         f->dflags + 3 * (size_t)f->flags_cap, f->stream2);
+    if (tun().dag)         // the other instantiation of the engine (never dereferences its buffers when t0 >= nt)
+        launch_potrf_engine(nullptr, 0, 0, 0, f->dinv, f->dinfo, f->dflags, f->dflags, f->dflags, (unsigned *)(f->dinfo + 1),
+                            f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dinv, f->dinv);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(f->stream2));
     return 0;
+}
+
+// ---- the dependency-driven schedule (chol.hip: dag_kernel) ---------------------------------------------------------
+static bool dag_wanted(cocons_fit *f, const FactorView &v)
+{
+    return tun().dag != 0 && v.dag_ok && !v.hi && !v.skew && v.nt > 4 && f->world == 1;
+}
+
+// buffers, zeroed task words and the step table of the factorisation of view v (on the main stream, before the engine starts)
+static int dag_prepare(cocons_fit *f, const FactorView &v)
+{
+    const size_t elems = v.lda * (size_t)f->npad;
+    if (f->dP_elems != elems) {
+        HIPCHK(hipStreamSynchronize(f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->dP) { HIPCHK(hipFree(f->dP)); f->dP = nullptr; f->dP_elems = 0; }
+        HIPCHK(hipMalloc(&f->dP, elems * sizeof(double)));
+        HIPCHK(hipMemsetAsync(f->dP, 0, elems * sizeof(double), f->stream));
+        f->dP_elems = elems;
+    }
+    if (f->dWt_tiles < v.nt) {
+        HIPCHK(hipStreamSynchronize(f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->dWt) { HIPCHK(hipFree(f->dWt)); f->dWt = nullptr; }
+        HIPCHK(hipMalloc(&f->dWt, (size_t)v.nt * TILE * TILE * sizeof(double)));
+        HIPCHK(hipMemsetAsync(f->dWt, 0, (size_t)v.nt * TILE * TILE * sizeof(double), f->stream));   // zero above the diagonals, for good
+        f->dWt_tiles = v.nt;
+    }
+    const int kskip = (f->pad0 / 16) * 16;
+    const int key[5] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead};
+    if (memcmp(key, f->dag_key, sizeof key) != 0 || !f->ddag_steps) {
+        std::vector<DagStepHost> steps;
+        const unsigned ntasks = dag_build_steps(v.nt, v.mt, v.trim, kskip, tun().dag_lead, steps);
+        HIPCHK(hipStreamSynchronize(f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->ddag_steps) { HIPCHK(hipFree(f->ddag_steps)); f->ddag_steps = nullptr; }
+        HIPCHK(hipMalloc(&f->ddag_steps, (steps.size() + 1) * sizeof(DagStepHost)));
+        HIPCHK(hipMemcpy(f->ddag_steps, steps.data(), steps.size() * sizeof(DagStepHost), hipMemcpyHostToDevice));
+        f->dag_nsteps = (int)steps.size(); f->dag_ntasks = ntasks;
+        memcpy(f->dag_key, key, sizeof key);
+        const size_t T64 = 2 * (size_t)v.mt;
+        const size_t words = 64 + T64 * (T64 + 1) / 2 + (steps.size() + 2) * T64;
+        if (f->ddag_words < words) {
+            if (f->ddag) { HIPCHK(hipFree(f->ddag)); f->ddag = nullptr; }
+            HIPCHK(hipMalloc(&f->ddag, words * sizeof(unsigned)));
+            f->ddag_words = words;
+        }
+    }
+    HIPCHK(hipMemsetAsync(f->ddag, 0, f->ddag_words * sizeof(unsigned), f->stream));
+    if (tun().dag_trace && f->dag_trace_tasks < f->dag_ntasks) {
+        if (f->ddag_trace) { HIPCHK(hipFree(f->ddag_trace)); f->ddag_trace = nullptr; }
+        HIPCHK(hipMalloc(&f->ddag_trace, (size_t)f->dag_ntasks * 4 * sizeof(unsigned long long)));
+        f->dag_trace_tasks = f->dag_ntasks;
+    }
+    return 0;
+}
+
+// diagnostics: the step table and the per-task stamps of the last DAG factorisation of the handle (dag_trace = 1).
+// steps_out: nsteps x 12 ints (DagStepHost); stamps_out: ntasks x 4 ticks of the 100 MHz clock.  Returns ntasks (or < 0);
+// with null outputs only the sizes: *nsteps_out.
+extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int *steps_out, unsigned long long *stamps_out)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!f->ddag_steps) return fail(-1, "cocons_debug_dag_trace: no DAG factorisation on this handle yet");
+    if (nsteps_out) *nsteps_out = f->dag_nsteps;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (steps_out) HIPCHK(hipMemcpy(steps_out, f->ddag_steps, (size_t)f->dag_nsteps * sizeof(DagStepHost), hipMemcpyDeviceToHost));
+    if (stamps_out) {
+        if (!f->ddag_trace) return fail(-1, "cocons_debug_dag_trace: tracing was off (cocons_debug_tune(\"dag_trace\", 1))");
+        HIPCHK(hipMemcpy(stamps_out, f->ddag_trace, (size_t)f->dag_ntasks * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    return (long long)f->dag_ntasks;
 }
 
 static int engine_start(cocons_fit *f, const FactorView &v)
@@ -1012,8 +1108,11 @@ static int engine_start(cocons_fit *f, const FactorView &v)
     unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
     HIPCHK(hipEventRecord(f->ev_eng, M));
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
+    f->dag_next = dag_wanted(f, v);
+    if (f->dag_next) if (int rc = dag_prepare(f, v)) return rc;
     launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
-                        f->dflags + 3 * (size_t)f->flags_cap, f->stream2);
+                        f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dag_next ? f->dWt : nullptr,
+                        f->dag_next ? f->dP : nullptr);
     f->engine_live = true;
     return 0;
 }
@@ -1045,6 +1144,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     launch_front_identity(v.A, v.lda, f->pad0, mt * TILE, M);
     if (!engine_wanted(f, v)) {
         f->engine_used = false;
+        f->dag_used = false;
         if (int rc = flags_reset(f, nt)) return rc;
         if (v.hi) {
             // band-limited: one tile column per step (factor, solve, update with K = 128) -- inside a narrow envelope
@@ -1086,6 +1186,25 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     if (tun().gate_sabotage > 0) { --tun().gate_sabotage; alive += 1; }      // (tests: a word that stays zero)
     launch_engine_gate(alive, abort_word, M, false, f->engine_ops++ == 0);
     panel_ops(f, v, 0, M);
+    f->dag_used = f->dag_next;
+    if (f->dag_next) {
+        // everything behind the first panel is ONE persistent launch (dag_kernel): tiles of update k + 1 start as soon as
+        // the strips of panel k + 1 they need and their own tile of update k are done; the panels are tile tasks of the same
+        // launch (the engine publishes the tile inverses they multiply with)
+        const size_t T64 = 2 * (size_t)mt;
+        unsigned *queue = f->ddag, *tdone = f->ddag + 64, *pdone = tdone + T64 * (T64 + 1) / 2;
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (ev_upd) {
+            for (int k = 0; k + 2 < nt; k += 2) count_update_flops(f, 2, k + 2);
+            hipEventCreate(&ea); hipEventCreate(&eb);
+            hipEventRecord(ea, M);
+        }
+        launch_dag(v.A, v.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
+                   pdone, (int)T64, in, out, xr, abort_word, M, tun().dag_trace ? f->ddag_trace : nullptr);
+        if (ev_upd) { hipEventRecord(eb, M); ev_upd->push_back(ea); ev_upd->push_back(eb); }
+        if (mt == nt) launch_engine_gate(out + (nt - 1), abort_word, M, true);
+        return 0;
+    }
     // (Running the panel kernels on a stream of their own behind near-tile flags, so that they start in the tail of the
     // update that feeds them, was built and measured in round 3: slower -- a 90 KB-LDS solve is not placed beside eight
     // update workgroups per CU, the event back to the main stream costs 12 us -- and removed; so were three forms of the
@@ -1142,17 +1261,19 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
     // the engine becomes resident while the (short) right-hand-side kernel runs: not earlier -- a second
     // queue with a resident kernel cuts the workgroup dispatch rate of every other launch to a quarter
     // (tools/diag/occupancy_probe.hip), which costs the 12,000-workgroup assembly 6 % -- and not later, see engine_start
-    if (engine_wanted(f, main_view(f)))
-        if (int rc = engine_start(f, main_view(f))) return rc;
     const bool slots = f->nslot >= nrhs && f->nslot > 0;      // the right-hand sides ride in the matrix's last tile
-    assemble_rhs(f, mean, use_trend, xb, nxb, 0, f->npad, zero_rest, slots);
-    if (stage_events) hipEventRecord(f->ev[1], f->stream);
     FactorView fv = main_view(f);
     if (slots) fv.mt = fv.nt;                         // no rows under the matrix
     else fv.trim = (f->rhs_act - nrhs >= 64) ? 1 : 0; // at most 64 of the 128 rows under the matrix are in use
+    fv.dag_ok = true;                                 // (the reductions below read the factor from both buffers)
+    if (engine_wanted(f, fv))
+        if (int rc = engine_start(f, fv)) return rc;
+    assemble_rhs(f, mean, use_trend, xb, nxb, 0, f->npad, zero_rest, slots);
+    if (stage_events) hipEventRecord(f->ev[1], f->stream);
     if (int rc = factorize(f, fv, ev_upd)) return rc;
     if (stage_events) hipEventRecord(f->ev[2], f->stream);
-    launch_finalize(f->dA, f->lda, f->n, slots ? f->n : f->npad, nrhs, f->dout, f->stream, f->skew, f->npad);
+    launch_finalize(f->dA, f->lda, f->n, slots ? f->n : f->npad, nrhs, f->dout, f->stream, f->skew, f->npad,
+                    f->dag_used ? f->dP : nullptr);
     HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, (size_t)(2 + nrhs * nrhs) * sizeof(double),       // info words + outputs
                           hipMemcpyDeviceToHost, f->stream));
     if (stage_events) hipEventRecord(f->ev[3], f->stream);

@@ -463,8 +463,60 @@ struct EngineArgs {
     unsigned *in, *out, *xr; // per-tile flag words
     unsigned *abort_word;
     unsigned *alive;         // raised once the workgroup is resident (see engine_gate_kernel)
+    double *wbuf;            // DAG schedule: W = L^-1 of diagonal tile t goes to wbuf + t * 128 * 128 (column-major, ld 128,
+                             // zero above the diagonal for good), published BEFORE out[t]: operand of the panel tasks
+    double *pbuf;            // DAG schedule: X = A(t+1,t) L(t)^-T is stored into this second buffer too (same index as in A)
 };
 
+// W = L^-1 of the 128 x 128 tile whose factor (block-packed) and Q operands (all eight diagonal blocks) are in LDS:
+// the strip solve of the engine applied to the identity -- wave w takes rows 16 w .. of I, X = I L^-T = W^T, an upper
+// triangular strip -- stored transposed, write-through, column-major with leading dimension 128.  168 MFMAs on the
+// longest strip (wave 0), ~5 us; the explicit inverse of a TRIANGULAR tile costs the solve that uses it a forward error
+// of eps cond(L) = eps sqrt(cond(Sigma block)), far inside the eps cond(Sigma) any Cholesky of Sigma carries.
+__device__ __noinline__ void engine_tile_inverse(double *W, int wave, int lane)
+{
+    // (out of line: inlined twice into the engine it pushed the kernel past its registers.  The LDS image is reached
+    // through the kernel's dynamic-LDS symbol, so the reads stay ds_read -- a pointer argument would make them flat.)
+    extern __shared__ double smem[];
+    const double *S = smem, *QALL = smem + 37 * 256;
+    d4 B[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) B[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int a = lane & 15, kq = lane >> 4;
+    d4 I16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) I16[r] = (a == 4 * r + kq) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < wave) continue;                      // wave-uniform: the strip is zero left of its diagonal block
+        if (j == wave) B[j] = I16;
+        d4 L = lds_blk(S + (j * (j + 1) / 2 + j) * 256, lane);
+        double Q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Q[s] = QALL[j * 256 + s * 64 + lane];
+        trsm16(B[j], L, Q);
+        d4 NX = -B[j];
+#pragma unroll
+        for (int jj = j + 1; jj < 8; ++jj) {
+            d4 Lb = lds_blk(S + (jj * (jj + 1) / 2 + j) * 256, lane);
+            blk_mma(B[jj], NX, Lb);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < wave) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int wr = 16 * j + 4 * r + kq, wc = 16 * wave + a;      // W(wr, wc) = W^T(wc, wr)
+            const double v = wr >= wc ? B[j][r] : 0.0;
+            store_wt(W + wr + (size_t)wc * TILE, v);
+        }
+    }
+}
+
+// DAG: the instantiation for the dependency-driven schedule (dag_kernel): tile inverses and the second copy of X.  The
+// classic instantiation does not contain those paths at all (they would cost it registers).
+template <bool DAG>
 __global__ void __launch_bounds__(512)
 potrf_engine_kernel(EngineArgs e)
 {
@@ -484,6 +536,7 @@ potrf_engine_kernel(EngineArgs e)
         if (*okp == 0) return;
         potrf_tile_body<true>(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem, QALL);
         __syncthreads();
+        if (DAG) engine_tile_inverse(e.wbuf + (size_t)t * TILE * TILE, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t);
@@ -528,6 +581,15 @@ potrf_engine_kernel(EngineArgs e)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     store_wt((double *)((char *)const_cast<double *>(Sb) + (lo + (unsigned)(16 * j + 4 * r) * ldab)), B[j][r]);
+            if (DAG) {
+                double *Pb = e.pbuf + (size_t)(c1 + 16 * wave) + (size_t)c0 * lda;
+                asm volatile("" : "+v"(lo));
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        store_wt((double *)((char *)Pb + (lo + (unsigned)(16 * j + 4 * r) * ldab)), B[j][r]);
+            }
             __syncthreads();                       // every wave is done with the image of L(t)
 #pragma unroll
             for (int j = 0; j < 8; ++j) lds_blk_store(XS + (wave * 8 + j) * 256, lane, B[j]);
@@ -550,7 +612,11 @@ potrf_engine_kernel(EngineArgs e)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // X in LDS is dead; the tile is re-read from memory
-        potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, nullptr);
+        potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, DAG ? QALL : nullptr);
+        if (DAG) {
+            __syncthreads();
+            engine_tile_inverse(e.wbuf + (size_t)(t + 1) * TILE * TILE, wave, lane);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t + 1);
@@ -637,6 +703,7 @@ struct UpdArgs {
     unsigned *queue; unsigned ntiles;  // dynamic tile order (lower_only launches): shared counter, zero at launch; tiles in all
     int Hb, ext0;                  // rows: local tile rows < Hb count from ti0 (tj0 when lower_only), the others from ext0
                                    // (band-limited factorisation: band rows, then the right-hand-side rows)
+    int c_wt;                      // every C tile is read with L2-bypassing loads and stored write-through (set_update_c_wt)
     int skew, kblk;                // packed band buffer (kernels.h band_index): C and P are its unshifted base, the operand
                                    // panel is tile column kblk; rows then count from each tile column's own diagonal tile
 };
@@ -726,7 +793,7 @@ update_kernel(UpdArgs a)
         // does this tile lie inside the diagonal block the engine is waiting for?
         const int sig_Ti = (ti * TM) / TILE - a.sig_tile, sig_Tj = (tj * TM) / TILE - a.sig_tile;
         const bool sig_wg = a.sig != nullptr && sig_Ti >= 0 && sig_Ti <= 1 && sig_Tj >= 0 && sig_Tj <= sig_Ti;
-        const bool wt_wg = sig_wg;
+        const bool wt_wg = sig_wg || a.c_wt;
         // the engine's whole chain starts when these ten tiles are done: let them win the issue arbitration on
         // their CU (beside seven other workgroups a tile takes ~70 us, alone ~10)
         if (sig_wg) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
@@ -818,8 +885,10 @@ update_kernel(UpdArgs a)
             for (int y = 0; y < NBY; ++y) {
                 d4 cv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    cv[r] = *(const double *)((const char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb));
+                for (int r = 0; r < 4; ++r) {
+                    const double *cp = (const double *)((const char *)(Cb + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldcb));
+                    cv[r] = a.c_wt ? load_wt(cp) : *cp;
+                }
                 cv -= acc[x][y];
                 if (wt_wg) {
 #pragma unroll
@@ -834,7 +903,7 @@ update_kernel(UpdArgs a)
         if (wt_wg) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t2 == 0) signal_add(a.sig + a.sig_tile + sig_Ti);
+            if (t2 == 0 && sig_wg) signal_add(a.sig + a.sig_tile + sig_Ti);
         }
         if (!a.queue) break;
         if (t2 == 0) *share = Lnext;
@@ -843,6 +912,279 @@ update_kernel(UpdArgs a)
         if (L >= a.ntiles) break;
         // (the next write to the word comes after the barriers of the next tile, which no wave passes before
         // all have read it here)
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The dependency-driven factorisation behind the first panel: ONE persistent launch for all trailing updates AND all
+// panels (round 4).  Until round 3 every block step was update launch | solve | in-panel update | solve, four kernel
+// boundaries at which the chip drains (42 us per update launch, 39 of them) and between which ~150 latency-bound
+// workgroups of one wave per SIMD have the chip to themselves (56 us per block).  Here the whole thing is a list of
+// 64 x 64 TILE TASKS of one and the same form
+//        acc(64 x 64) = sum_{k < K} I(i, k) J(j, k)            then   C -= acc   or   X = acc,
+// drawn in order from one counter by as many workgroups as the chip holds, each task waiting (bounded) for the words
+// that say its inputs are complete.  Per update step s (panel s applied to the trailing matrix), in this order:
+//   near tiles   the update tiles in the next panel's columns, the ten inside its diagonal block first -- they feed the
+//                engine (as before) and the panel tasks;
+//   far tiles    `lead` of them, then
+//   panel tasks  of panel s + 1, six per 64-row strip below its diagonal block: with W = L^-1 of the two diagonal tiles
+//                from the engine (potrf_engine_kernel<true>)
+//                   T1 (two 64-column halves)  X0 = B0 W(t)^T         K = 64 (h + 1): W is lower triangular
+//                   T2 (two halves)            B1 -= X0 X(t+1,t)^T    K = 128, X(t+1,t) is the engine's
+//                   T3 (two halves)            X1 = B1 W(t+1)^T
+//                no dependent chain inside a task, the update tile's inner loop, footprint and occupancy;
+//   far tiles    the rest.
+// Every dependency points to an EARLIER task of the list (or to the engine, which depends on earlier tasks only), and a
+// task is only drawn by a resident workgroup: the earliest unfinished task can always run -- no deadlock, whatever the
+// placement.  What waits for what:
+//   update tile (s; i, j)   before its product: the strips i and j of panel s complete (pdone >= need; step 0: formed by
+//                           earlier kernels); before its epilogue: its own tile through step s - 1 (tdone >= s);
+//   T1 (strip i)            out[t] (tile t factored, W(t) published), the two near tiles of row i in tile column t;
+//   T2                      both T1 of the strip, xr[t] (X(t+1,t) published), its C tile through step s (before the epilogue);
+//   T3                      both T2 of the strip, out[t+1].
+// Memory (per-XCD L2s are not coherent inside a launch):  every version of a C tile -- update results, B0, B1 -- is
+// written write-through and read with L2-bypassing loads (sc1), by whoever touches it (measured: as fast as cached
+// accesses, each byte is used once);  everything that is read MANY times -- the finished panels X0 | X1, X(t+1,t), the
+// tile inverses -- is written write-through into memory NO ONE has read since the launch began (a second buffer P shaped
+// like the matrix; one W per tile), so plain cached loads cannot find a stale line.  The factor therefore ends up split:
+// diagonal blocks in A, everything below them in P (from panel 1 on): launch_finalize takes both.
+struct DagStep {
+    unsigned base;          // index of the step's first task
+    unsigned near;          // near tiles: the first `near` tiles of the trapezoid's column-major order
+    unsigned tpos, nT;      // position inside the step of the first panel task, panel tasks
+    int H, W;               // trapezoid of the update in 64-tiles: H rows from tile row tj0 down, W columns from tj0
+    int tj0;                // = 2 t: first 64-row = first 64-column of the trapezoid (t = first tile of the next block)
+    int k0, K;              // the panel: columns [k0, k0 + K)
+    int nstrip, two;        // next panel: 64-row strips below its diagonal block; the block has a second tile
+    int need;               // pdone count at which a strip of THIS step's panel is complete (step 0: unused)
+};
+
+struct DagArgs {
+    double *A; size_t lda;
+    double *P;                       // second buffer, indexed like A
+    const double *Wt;                // tile inverses: Wt + t * 128 * 128
+    const DagStep *steps; int nsteps;
+    unsigned ntasks;
+    unsigned *queue;                 // task counter (zero at launch)
+    unsigned *tdone;                 // per 64-tile (i >= j) at i (i + 1) / 2 + j: update steps applied
+    unsigned *pdone; int pstride;    // per panel p and strip (row64 - first row64 below block p's predecessor ... see dag_kernel)
+    unsigned *sig;                   // the engine's in[] words
+    unsigned *out, *xr;              // the engine's out[] / xr[] words
+    unsigned *abort_word;
+    unsigned long long *trace;       // diagnostics (may be null): per task 4 stamps of the 100 MHz clock -- drawn, inputs
+                                     // complete, product done and previous C version there, stored and signalled
+};
+
+__global__ void __launch_bounds__(256, 8)
+dag_kernel(DagArgs a)
+{
+    constexpr int TM = 64, KC = 8, LDT = TM + 16, TPC = 256 / KC, RPT = TM / TPC;
+    static_assert(RPT == 2, "one 16-byte load per thread, side and chunk");
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    __shared__ double sI[2][KC * LDT];
+    __shared__ double sJ[2][KC * LDT];
+    unsigned *share = (unsigned *)&sI[0][TM];          // (padding of the first staged column: see update_kernel)
+    const int tid = threadIdx.x;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const DagStep *__restrict__ steps = a.steps;
+    const unsigned ldab = 8u * (unsigned)a.lda;
+    // EVERY task comes off the counter, the first one too (update_kernel hands out the first tile by block index: 2040
+    // workgroups asking one word at the same instant cost ~8 us -- once per factorisation here, not per launch): whatever
+    // part of the grid the chip holds at a given moment (another process may own CUs) then works on the LOWEST undrawn
+    // tasks, and every dependency points downwards in the order -- no placement can deadlock
+    if (tid == 0) share[1] = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    unsigned L = (unsigned)__builtin_amdgcn_readfirstlane((int)share[1]);
+    __syncthreads();
+    if (L >= a.ntasks) return;
+    for (;;) {
+        // ---- which task: all of this is wave-uniform and stays on the scalar unit
+        int lo = 0, hi = a.nsteps - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (steps[mid].base <= L) lo = mid; else hi = mid - 1;
+        }
+        const int s = lo;
+        const DagStep st = steps[s];
+        const unsigned q = L - st.base;
+        if (a.trace && tid == 0) a.trace[4 * (size_t)L] = __builtin_amdgcn_s_memrealtime();
+        const int t = st.tj0 >> 1;                           // first 128-tile of the next block
+        const bool isT = q >= st.tpos && q < st.tpos + st.nT;
+        const double *gIb, *gJb;
+        unsigned ldib, ldjb;                                 // leading dimensions in bytes
+        int K, i_wt = 0, store_only = 0;
+        double *Cb;                                          // the task's 64 x 64 output tile
+        unsigned *w0 = nullptr, *w1 = nullptr, *w2 = nullptr, *we = nullptr, *dn;
+        unsigned n0 = 0, n1 = 0, n2 = 0, ne = 0, dval = 0;   // dval != 0: store dval to *dn; 0: add 1
+        int sigT = -1;                                       // >= 0: the tile lies in the next diagonal block: raise sig[sigT]
+        int prio = 0;
+        if (!isT) {
+            const int qt = (int)(q < st.tpos ? q : q - st.nT);
+            int jl = 0, jh = st.W - 1;
+            while (jl < jh) {
+                const int mid = (jl + jh + 1) >> 1;
+                if (mid * st.H - mid * (mid - 1) / 2 <= qt) jl = mid; else jh = mid - 1;
+            }
+            const int tj = st.tj0 + jl, ti = tj + (qt - (jl * st.H - jl * (jl - 1) / 2));
+            const double *Ps = s == 0 ? a.A : a.P;
+            gIb = Ps + (size_t)ti * TM + (size_t)st.k0 * a.lda;
+            gJb = Ps + (size_t)tj * TM + (size_t)st.k0 * a.lda;
+            ldib = ldab; ldjb = ldab; K = st.K;
+            Cb = a.A + (size_t)ti * TM + (size_t)tj * TM * a.lda;
+            if (s > 0) {
+                w0 = a.pdone + (size_t)s * a.pstride + (ti - st.tj0); n0 = (unsigned)st.need;
+                w1 = a.pdone + (size_t)s * a.pstride + (tj - st.tj0); n1 = (unsigned)st.need;
+            }
+            we = a.tdone + (ti * (ti + 1) / 2 + tj); ne = (unsigned)s;
+            dn = we; dval = (unsigned)s + 1u;
+            const int Ti = (ti >> 1) - t, Tj = (tj >> 1) - t;
+            if (Ti >= 0 && Ti <= 1 && Tj >= 0 && Tj <= Ti) { sigT = t + Ti; prio = 3; }
+        } else {
+            const unsigned u = q - st.tpos;
+            const int per = 2 * st.nstrip;
+            const int stage = (int)(u / (unsigned)per), rem = (int)(u % (unsigned)per);
+            const int strip = rem >> 1, h = rem & 1;
+            const int row64 = st.tj0 + (st.two ? 4 : 2) + strip;
+            const size_t c_t = (size_t)t * TILE, c_t1 = c_t + TILE;
+            dn = a.pdone + (size_t)(s + 1) * a.pstride + strip;
+            prio = 2;
+            if (stage == 0) {            // T1: X0(:, half h of tile t) = B0 W(t)^T
+                gIb = a.A + (size_t)row64 * TM + c_t * a.lda; ldib = ldab; i_wt = 1;
+                gJb = a.Wt + (size_t)t * TILE * TILE + TM * h; ldjb = 8u * TILE;
+                K = TM * (h + 1);
+                Cb = a.P + (size_t)row64 * TM + (c_t + TM * h) * a.lda; store_only = 1;
+                w0 = a.out + t; n0 = 1u;
+                w1 = a.tdone + (row64 * (row64 + 1) / 2 + 2 * t); n1 = (unsigned)s + 1u;
+                w2 = w1 + 1; n2 = n1;
+            } else if (stage == 1) {     // T2: B1(:, half h of tile t + 1) -= X0 X(t+1,t)^T
+                gIb = a.P + (size_t)row64 * TM + c_t * a.lda; ldib = ldab;
+                gJb = a.P + (c_t1 + TM * h) + c_t * a.lda; ldjb = ldab;
+                K = TILE;
+                Cb = a.A + (size_t)row64 * TM + (c_t1 + TM * h) * a.lda;
+                w0 = dn; n0 = 2u;
+                w1 = a.xr + t; n1 = 1u;
+                we = a.tdone + (row64 * (row64 + 1) / 2 + 2 * (t + 1) + h); ne = (unsigned)s + 1u;
+            } else {                     // T3: X1(:, half h of tile t + 1) = B1 W(t+1)^T
+                gIb = a.A + (size_t)row64 * TM + c_t1 * a.lda; ldib = ldab; i_wt = 1;
+                gJb = a.Wt + (size_t)(t + 1) * TILE * TILE + TM * h; ldjb = 8u * TILE;
+                K = TM * (h + 1);
+                Cb = a.P + (size_t)row64 * TM + (c_t1 + TM * h) * a.lda; store_only = 1;
+                w0 = dn; n0 = 4u;
+                w1 = a.out + t + 1; n1 = 1u;
+            }
+        }
+        if (prio == 3) __builtin_amdgcn_s_setprio(3);
+        else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
+
+        // ---- inputs of the product complete?  (one lane; the words are nearly always there already)
+        if (w0) {
+            if (tid == 0) {
+                bool ok = wait_ge<false>(w0, n0, a.abort_word, 0xa00u + (unsigned)s);
+                if (ok && w1) ok = wait_ge<false>(w1, n1, a.abort_word, 0xb00u + (unsigned)s);
+                if (ok && w2) ok = wait_ge<false>(w2, n2, a.abort_word, 0xc00u + (unsigned)s);
+                *share = ok ? 1u : 0u;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned ok = *share;
+            __syncthreads();
+            if (!ok) return;
+        }
+
+        if (a.trace && tid == 0) a.trace[4 * (size_t)L + 1] = __builtin_amdgcn_s_memrealtime();
+        // per-thread offsets from a laundered lane index (see update_kernel: hoisted, they spill)
+        int lane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        const int wave = wave_s, t2 = 64 * wave + lane;
+        const int wi = wave & 1, wj = wave >> 1;
+        const int kc = t2 / TPC, rg = (t2 % TPC) * RPT;
+        const int ro = (lane >> 4) * LDT + (lane & 15);
+        const char *pI = (const char *)gIb + (8u * (unsigned)rg + (unsigned)kc * ldib);
+        const char *pJ = (const char *)gJb + (8u * (unsigned)rg + (unsigned)kc * ldjb);
+        const unsigned cIb = (unsigned)KC * ldib, cJb = (unsigned)KC * ldjb;
+        const int nch = K / KC;
+        d2 stI, stJ;
+        d4 acc[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+        if (i_wt) { stI[0] = load_wt((const double *)pI); stI[1] = load_wt((const double *)pI + 1); }
+        else stI = *(const d2 *)pI;
+        stJ = *(const d2 *)pJ;
+        *(d2 *)(&sI[0][kc * LDT + rg]) = stI;
+        *(d2 *)(&sJ[0][kc * LDT + rg]) = stJ;
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+            const int cur = ch & 1;
+            if (ch + 1 < nch) {
+                const char *qI = pI + (unsigned)(ch + 1) * cIb;
+                const char *qJ = pJ + (unsigned)(ch + 1) * cJb;
+                if (i_wt) { stI[0] = load_wt((const double *)qI); stI[1] = load_wt((const double *)qI + 1); }
+                else stI = *(const d2 *)qI;
+                stJ = *(const d2 *)qJ;
+            }
+            const double *bI = &sI[cur][ro + (TM / 2) * wi];
+            const double *bJ = &sJ[cur][ro + (TM / 2) * wj];
+#pragma unroll
+            for (int k4 = 0; k4 < KC / 4; ++k4) {
+                const double p0 = bI[k4 * 4 * LDT], p1 = bI[k4 * 4 * LDT + 16];
+                const double q0 = bJ[k4 * 4 * LDT], q1 = bJ[k4 * 4 * LDT + 16];
+                acc[0][0] = MFMA64(q0, p0, acc[0][0]);
+                acc[0][1] = MFMA64(q1, p0, acc[0][1]);
+                acc[1][0] = MFMA64(q0, p1, acc[1][0]);
+                acc[1][1] = MFMA64(q1, p1, acc[1][1]);
+            }
+            if (ch + 1 < nch) {
+                *(d2 *)(&sI[cur ^ 1][kc * LDT + rg]) = stI;
+                *(d2 *)(&sJ[cur ^ 1][kc * LDT + rg]) = stJ;
+            }
+            __syncthreads();
+        }
+        // ---- the next task is asked for now (see update_kernel), and the C tile's previous version must be there
+        if (t2 == 0) {
+            unsigned ok = 1u;
+            if (we) ok = wait_ge<false>(we, ne, a.abort_word, 0xd00u + (unsigned)s) ? 1u : 0u;
+            const unsigned Ln = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            share[0] = ok; share[1] = Ln;
+            if (a.trace) a.trace[4 * (size_t)L + 2] = __builtin_amdgcn_s_memrealtime();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned okE = share[0];
+        const unsigned Lnext = share[1];
+        if (!okE) return;
+        // ---- epilogue: the wave's 32 x 32 part of the tile, one accumulator block at a time (loads first, then stores)
+        double *Cw = Cb + (size_t)((TM / 2) * wi) + (size_t)((TM / 2) * wj) * a.lda;
+        unsigned cve = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldab;
+        asm volatile("" : "+v"(cve));
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                d4 cv;
+                if (store_only) cv = acc[x][y];
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cv[r] = load_wt((const double *)((const char *)(Cw + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldab)));
+                    cv -= acc[x][y];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    store_wt((double *)((char *)(Cw + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldab)), cv[r]);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t2 == 0) {
+            if (sigT >= 0) signal_add(a.sig + sigT);
+            if (dval) __hip_atomic_store(dn, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_add(dn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.trace) a.trace[4 * (size_t)L + 3] = __builtin_amdgcn_s_memrealtime();
+        }
+        L = (unsigned)__builtin_amdgcn_readfirstlane((int)Lnext);
+        if (L >= a.ntasks) break;
     }
 }
 
@@ -864,8 +1206,11 @@ __device__ __forceinline__ double block_sum(double v, double *red)
 // block b < nr*nr: Gram entry (b / nr, b % nr) over columns [c0,c1) and < n;
 // block nr*nr: sum of log of the diagonal over the same columns.
 __global__ void __launch_bounds__(1024)
-finalize_kernel(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr, double *out, int skew, int npad)
+finalize_kernel(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr, double *out, int skew, int npad,
+                const double *A2)
 {
+    // A2 != NULL (dense layout only): the factor of the dependency-driven schedule -- the part of a column BELOW the 256 x 256
+    // diagonal block it runs through lives in A2 (from the second block on), everything else in A (dag_kernel)
     __shared__ double red[16];
     const int b = blockIdx.x;
     const int hi = c1 < n ? c1 : n;
@@ -890,8 +1235,13 @@ finalize_kernel(const double *A, size_t lda, int c0, int c1, int n, int row0, in
 #pragma unroll
             for (int q = 0; q < U; ++q) {
                 const bool in = c + q * step < hi;
-                va[q] = in ? A[band_index(ra, c + q * step, lda, skew, npad)] : 0.0;
-                vb[q] = in ? A[band_index(rb, c + q * step, lda, skew, npad)] : 0.0;
+                const int cc = c + q * step;
+                int below0 = 2 * TILE * (cc / (2 * TILE) + 1);                // first row below column cc's diagonal block
+                if (npad > 0 && below0 > npad) below0 = npad;                 // (a last block of one tile)
+                const double *Sa = (A2 && cc >= 2 * TILE && ra >= below0) ? A2 : A;
+                const double *Sb = (A2 && cc >= 2 * TILE && rb >= below0) ? A2 : A;
+                va[q] = in ? Sa[band_index(ra, cc, lda, skew, npad)] : 0.0;
+                vb[q] = in ? Sb[band_index(rb, cc, lda, skew, npad)] : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < U; ++q) s += va[q] * vb[q];
@@ -1029,15 +1379,23 @@ static size_t engine_lds_bytes()
 // handle (api.hip): whatever the first dispatch of this kernel on this stream costs the runtime (queue set-up, code
 // object, LDS configuration) is paid there and not inside the bounded gate of the first engine-schedule operation.
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
-                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s)
+                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
+                         double *wbuf, double *pbuf)
 {
     EngineArgs e;
     e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
     e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive;
+    e.wbuf = wbuf; e.pbuf = pbuf;
     const size_t shm = engine_lds_bytes();
-    static std::atomic<unsigned long long> attr_done{0};
-    set_dynamic_lds_once((const void *)potrf_engine_kernel, shm, attr_done);
-    hipLaunchKernelGGL(potrf_engine_kernel, dim3(1), dim3(512), shm, s, e);
+    if (wbuf && pbuf) {
+        static std::atomic<unsigned long long> attr_done{0};
+        set_dynamic_lds_once((const void *)potrf_engine_kernel<true>, shm, attr_done);
+        hipLaunchKernelGGL(potrf_engine_kernel<true>, dim3(1), dim3(512), shm, s, e);
+    } else {
+        static std::atomic<unsigned long long> attr_done{0};
+        set_dynamic_lds_once((const void *)potrf_engine_kernel<false>, shm, attr_done);
+        hipLaunchKernelGGL(potrf_engine_kernel<false>, dim3(1), dim3(512), shm, s, e);
+    }
 }
 
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
@@ -1057,6 +1415,8 @@ static int upd_waves = -1;
 static long long upd_w8_max_tiles = -1;      // 8-wave workgroups only for launches of at most this many tiles (0 = all)
 void set_update_waves(int nw) { upd_waves = nw == 8 ? 8 : 4; }
 void set_update_w8_max_tiles(int ntiles) { upd_w8_max_tiles = ntiles < 0 ? 0 : ntiles; }
+static int upd_c_wt = 0;
+void set_update_c_wt(int on) { upd_c_wt = on ? 1 : 0; }
 
 void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
@@ -1076,7 +1436,7 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     bool use_w8 = false;
     UpdArgs a;
     a.queue = nullptr; a.ntiles = 0;
-    a.skew = skew; a.kblk = kblk;
+    a.skew = skew; a.kblk = kblk; a.c_wt = upd_c_wt;
     a.Hb = 2 * rows_band; a.ext0 = 2 * ext0;
     a.C = A; a.ldc = lda; a.P = P; a.ldp = ldp; a.K = K;
     a.lower_only = lower_only ? 1 : 0;
@@ -1124,6 +1484,62 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     else hipLaunchKernelGGL((update_kernel<64, 8, 1>), grid, dim3(256), 0, s, a);
 }
 
+// ---- the dependency-driven schedule: table of steps (host) and launch --------------------------------------------
+// Steps for a factorisation with nt column tiles and mt row tiles (trim64: the last 64 rows hold nothing), first panel
+// (tiles 0, 1) already formed in place; kskip leading columns of it are unit vectors (front padding) and are skipped.
+// lead: far tiles of a step in front of its panel tasks.  Returns the number of tasks.
+unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, std::vector<DagStepHost> &out)
+{
+    out.clear();
+    unsigned base = 0;
+    int prev_two = 1;
+    for (int k = 0; k + 2 < nt; k += 2) {
+        const int t = k + 2;
+        DagStepHost st;
+        st.tj0 = 2 * t;
+        st.H = 2 * (mt - t) - (trim64 ? 1 : 0);
+        st.W = 2 * (nt - t);
+        st.two = t + 1 < nt ? 1 : 0;
+        const long long tiles = (long long)st.W * st.H - (long long)st.W * (st.W - 1) / 2;
+        const int nc = std::min(st.W, st.two ? 4 : 2);
+        st.near = (unsigned)(nc * st.H - nc * (nc - 1) / 2);
+        st.nstrip = std::max(0, st.H - (st.two ? 4 : 2));
+        st.nT = (unsigned)(st.nstrip * (st.two ? 6 : 2));
+        const long long far = tiles - st.near;
+        st.tpos = st.near + (unsigned)std::min<long long>(far, lead);
+        st.k0 = k * TILE + (k == 0 ? kskip : 0);
+        st.K = 2 * TILE - (k == 0 ? kskip : 0);
+        st.need = prev_two ? 6 : 2;
+        st.base = base;
+        base += (unsigned)tiles + st.nT;
+        prev_two = st.two;
+        out.push_back(st);
+    }
+    return base;
+}
+
+void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
+                unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *sig, unsigned *out, unsigned *xr,
+                unsigned *abort_word, hipStream_t s, unsigned long long *trace)
+{
+    static_assert(sizeof(DagStepHost) == sizeof(DagStep), "host and device step records");
+    if (nsteps <= 0 || ntasks == 0) return;
+    DagArgs a;
+    a.A = A; a.lda = lda; a.P = P; a.Wt = Wt;
+    a.steps = (const DagStep *)dsteps; a.nsteps = nsteps; a.ntasks = ntasks;
+    a.queue = queue; a.tdone = tdone; a.pdone = pdone; a.pstride = pstride;
+    a.sig = sig; a.out = out; a.xr = xr; a.abort_word = abort_word; a.trace = trace;
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = 8 * cus;
+    }
+    const unsigned cap = (unsigned)(slots - 8);          // one CU's worth fewer: the engine owns a CU
+    hipLaunchKernelGGL(dag_kernel, dim3(ntasks < cap ? ntasks : cap), dim3(256), 0, s, a);
+}
+
 void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig, int sig_tile,
                    unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
@@ -1136,12 +1552,15 @@ void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int t
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
                           double *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(1024), 0, s, A, lda, c0, c1, n, row0, nr, out, 0, 0);
+    hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(1024), 0, s, A, lda, c0, c1, n, row0, nr, out, 0, 0,
+                       (const double *)nullptr);
 }
 
-void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s, int skew, int npad)
+void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s, int skew, int npad,
+                     const double *A2)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(1024), 0, s, A, lda, 0, n, n, row0, nr, out, skew, npad);
+    hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(1024), 0, s, A, lda, 0, n, n, row0, nr, out, skew, npad,
+                       skew ? (const double *)nullptr : A2);
 }
 
 size_t row_reduce_scratch_doubles(int n, int m)

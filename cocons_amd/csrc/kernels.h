@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <vector>
 #include "../../include/cocons_hip.h"
 
 namespace cocons {
@@ -119,8 +120,11 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
 // abort_word: set by any party whose bounded wait ran out; everybody leaves when it is non-zero.
 //   alive    raised by the engine once it is resident; launch_engine_gate(alive, ...) holds a stream until then
 // t0 >= nt: a warm-up launch -- the kernel raises alive and leaves (first-dispatch costs paid outside any bounded wait)
+// wbuf, pbuf != NULL: the engine of the DAG schedule (launch_dag) -- it also publishes W = L^-1 of every diagonal tile t at
+// wbuf + t * 128 * 128 (zeroed once by the caller; complete before out[t]) and a second copy of X in pbuf (shaped like A)
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
-                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s);
+                         unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
+                         double *wbuf = nullptr, double *pbuf = nullptr);
 void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false, bool patient = false);
 // rows [r0, r1) x cols [c0, c0+128):  X <- X * L(c0)^{-T}, L read from A(c0,c0).
 // wait_word != NULL: the tile comes from the engine -- every workgroup first waits for *wait_word >= 1
@@ -144,6 +148,7 @@ void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int t
 // launches of at most set_update_w8_max_tiles tiles, 0 = every launch)
 void set_update_waves(int nw);
 void set_update_w8_max_tiles(int ntiles);
+void set_update_c_wt(int on);           // (experiment) every C tile through L2-bypassing loads and write-through stores
 // like launch_update but the (i,k) and (j,k) operands come from a separate packed
 // panel buffer P (ldp rows, row index = global row), used by the sharded path.
 // (ptiles, world, rank): when world > 1 only tile columns tj with (tj / ptiles) % world == rank
@@ -154,9 +159,23 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
                         unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
                         int band_hi = -1, int ext0 = 0, int skew = 0, int kblk = 0, int trim64 = 0);
 
+// ---- dependency-driven schedule (chol.hip: dag_kernel) -- ONE persistent launch for every trailing update and every
+// panel behind the first one.  DagStepHost mirrors the device record (see DagStep in chol.hip for the meaning).
+struct DagStepHost {
+    unsigned base, near, tpos, nT;
+    int H, W, tj0, k0, K, nstrip, two, need;
+};
+unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, std::vector<DagStepHost> &out);
+// dsteps: DEVICE copy of the table.  queue, tdone (2 mt (2 mt + 1) / 2 words), pdone ((nsteps + 1) * pstride words,
+// pstride >= 2 mt): zero at launch.  sig / out / xr: the engine's words (launch_potrf_engine with wbuf = Wt, pbuf = P).
+void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
+                unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *sig, unsigned *out, unsigned *xr,
+                unsigned *abort_word, hipStream_t s, unsigned long long *trace = nullptr);
+
 // reductions: out[0] = sum_{i<n} log(A(i,i)); out[1 + a*nr + b] = sum_{c<n} A(row0+a,c) A(row0+b,c)
 void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s,
-                     int skew = 0, int npad = 0);          // packed band source (band_index)
+                     int skew = 0, int npad = 0,           // packed band source (band_index)
+                     const double *A2 = nullptr);          // factor of the DAG schedule: below the diagonal blocks it lives in A2
 // partial version over columns [c0,c1) accumulating into out (atomic adds), sharded path
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
                           double *out, hipStream_t s);

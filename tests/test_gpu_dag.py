@@ -1,0 +1,122 @@
+"""The dependency-driven schedule (COCONS_DAG / cocons_debug_tune("dag", 1): ONE persistent launch for every trailing update
+and every panel behind the first one, chol.hip dag_kernel) against the classic engine schedule and the CPU oracle, on the
+sizes where its special cases live: a last block of one tile (odd number of tiles), front padding with the right-hand
+sides in slot rows, right-hand sides under the matrix (n a multiple of 128), two realisations, Profile / REML borders."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tune(name, value):
+    from cocons_amd import _lib
+    L = _lib.load()
+    _lib.check(L.cocons_debug_tune(name.encode(), int(value)), "cocons_debug_tune")
+
+
+@pytest.fixture
+def dag_on():
+    _tune("dag", 1)
+    yield
+    _tune("dag", int(os.environ.get("COCONS_DAG", "0")))
+
+
+def _grid(gx, gy):
+    from cocons_amd import workloads as wl
+    xs, ys = np.linspace(0, 1, gx), np.linspace(0, 1, gy)
+    locs = np.array([(x, y) for y in ys for x in xs])
+    return locs, wl.design_from_locs(locs)
+
+
+@pytest.mark.parametrize("gx,gy", [(28, 25), (33, 31), (45, 47), (50, 47), (64, 64), (72, 64)])
+def test_dag_vs_classic_and_oracle(oracle, dag_on, gx, gy):
+    """n = 700 (6 tiles), 1023 (8 tiles, slots), 2115 (17 tiles: last block of one tile), 2350 (19 tiles), 4096 (32 tiles, no
+    padding: right-hand sides in a tile row under the matrix), 4608 (36 tiles): same value as the classic schedule to
+    1e-11, as the CPU path to 1e-9 where the oracle finishes in seconds; engine never timed out; DAG really ran."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, sc = _grid(gx, gy)
+    n = locs.shape[0]
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.1, -0.2, 0.05])
+    rng = np.random.default_rng(n)
+    z = rng.standard_normal((n, 2)) + (X @ np.array([0.2, 0.3, -0.1]))[:, None]
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    v_dag, parts_dag = fit.neg2loglik_core(th)
+    v_dag2 = fit.neg2loglik_core(th)[0]
+    assert v_dag2 == v_dag                                   # same bits: no schedule-dependent order of summation
+    st = fit.engine_state()
+    assert st["retries"] == 0 and st["active"]
+    _tune("dag", 0)
+    v_cl, parts_cl = fit.neg2loglik_core(th)
+    _tune("dag", 1)
+    assert abs(v_dag - v_cl) <= 1e-11 * abs(v_cl), (v_dag, v_cl)
+    assert np.allclose(parts_dag, parts_cl, rtol=1e-9, atol=0)
+    if n <= 2400:
+        S = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+        info, ld, quad, _ = oracle.chol_ld(S, z - (X @ th["mean"])[:, None])
+        want = sum(n * math.log(2 * math.pi) + 2 * ld + float(quad[k]) for k in range(2))
+        assert abs(v_dag - want) <= 1e-9 * abs(want)
+    fit.close()
+
+
+def test_dag_profile_reml_and_failure(oracle, dag_on):
+    """Profile and REML objectives (q = 3 extra border rows) and a matrix that is not positive definite under the DAG
+    schedule, n = 2115."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, sc = _grid(45, 47)
+    n = locs.shape[0]
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal(n) + X @ np.array([0.1, 0.4, -0.3])
+    pq = wl.par_pos_full()
+    tq = wl.theta_vector_from_lists(th, pq)
+    lam = (0.1, 0.0, 0.3)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, x_betas=X)
+    got = ca.GetNeg2loglikelihoodProfile(tq, pq, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam, fit=fit)
+    want = oracle.GetNeg2loglikelihoodProfile(tq, pq, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam)
+    assert abs(got - want) <= 1e-8 * abs(want)
+    got = ca.GetNeg2loglikelihoodREML(tq, pq, locs, X, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    want = oracle.GetNeg2loglikelihoodREML(tq, pq, locs, X, X, wl.SMOOTH_LIMITS, z, n, lam)
+    assert abs(got - want) <= 1e-8 * abs(want)
+    assert fit.engine_state()["retries"] == 0
+    fit.close()
+    th3 = {k: np.zeros(3) for k in th}
+    th3["scale"] = np.array([np.log(0.05), 0.0, 0.0])
+    th3["nugget"] = np.array([-np.inf, 0.0, 0.0])
+    fit3 = ca.CoconsFit(locs, X, z, (1.0, 1.0))
+    with pytest.raises(ca.CholeskyError) as ei:
+        fit3.neg2loglik_core(th3)
+    assert ei.value.minor == 2
+    fit3.close()
+
+
+def test_dag_changing_parameters_stay_reproducible(dag_on):
+    """Alternating parameter vectors on one handle (the second buffer and the tile inverses are rewritten every evaluation):
+    every value equals the first evaluation of the same parameters bit for bit."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, sc = _grid(50, 47)
+    X = sc["std.covs"]
+    z = wl.synthetic_z(locs.shape[0])
+    ths = []
+    for i in range(4):
+        t = wl.theta_full()
+        t["scale"][0] += 0.05 * i
+        t["std.dev"][1] -= 0.03 * i
+        ths.append(t)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    first = [fit.neg2loglik_core(t)[0] for t in ths]
+    assert len(set(first)) == 4
+    rng = np.random.default_rng(0)
+    for _ in range(40):
+        i = int(rng.integers(4))
+        assert fit.neg2loglik_core(ths[i])[0] == first[i]
+    assert fit.engine_state()["retries"] == 0
+    fit.close()

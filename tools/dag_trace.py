@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Where the time of the dependency-driven factorisation (dag_kernel) goes: per-task stamps of one evaluation
+(cocons_debug_dag_trace) summarised per step and per task kind.
+
+    python tools/dag_trace.py [--n 10000] [--lead 3600]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=10000)
+    ap.add_argument("--lead", type=int, default=3600)
+    ap.add_argument("--every", type=int, default=4, help="print every k-th step")
+    a = ap.parse_args()
+    import cocons_amd as ca
+    from cocons_amd import _lib, workloads as wl
+    L = _lib.load()
+    tune = lambda k, v: _lib.check(L.cocons_debug_tune(k.encode(), int(v)), "tune")
+    tune("dag", 1); tune("dag_lead", a.lead); tune("dag_trace", 1)
+    g = int(round(a.n ** 0.5))
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    th = wl.theta_full()
+    z = wl.synthetic_z(g * g)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    for _ in range(3):
+        fit.neg2loglik_core(th)
+    ns = ctypes.c_int(0)
+    nt = L.cocons_debug_dag_trace(fit._h, ctypes.byref(ns), None, None)
+    assert nt > 0, _lib.last_error()
+    steps = np.zeros((ns.value, 12), dtype=np.int32)
+    st = np.zeros((nt, 4), dtype=np.uint64)
+    rc = L.cocons_debug_dag_trace(fit._h, ctypes.byref(ns), steps.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                  st.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)))
+    assert rc == nt, _lib.last_error()
+    t0 = float(st[:, 0].min())
+    T = (st.astype(np.float64) - t0) * 0.01                    # microseconds
+    total = T[:, 3].max()
+    print("n = %d: %d tasks in %d steps, kernel span %.1f us; slot-time busy %.1f %% of 2040 slots"
+          % (g * g, nt, ns.value, total, 100 * np.sum(T[:, 3] - T[:, 0]) / (2040 * total)))
+    print("%4s %7s %6s | %8s %8s %8s | near: wait  prod  epi | far: wait  prod  epi | T1 wait prod | T2 wait prod | T3 wait prod | T3 last end"
+          % ("step", "tasks", "nT", "start", "end", "span"))
+    kinds_tot = {}
+    for s in range(ns.value):
+        base, near, tpos, nT, H, W, tj0, k0, K, nstrip, two, need = [int(v) for v in steps[s].view(np.uint32)[:4]] + [int(v) for v in steps[s][4:]]
+        nxt = int(steps[s + 1].view(np.uint32)[0]) if s + 1 < ns.value else nt
+        rows = T[base:nxt]
+        q = np.arange(nxt - base)
+        isT = (q >= tpos) & (q < tpos + nT)
+        u = q - tpos
+        stage = np.where(isT, u // max(1, 2 * nstrip), -1)
+        isnear = (~isT) & (q < near)
+        isfar = (~isT) & ~isnear
+
+        def stats(m):
+            if not m.any():
+                return (0.0, 0.0, 0.0)
+            r = rows[m]
+            return (np.mean(r[:, 1] - r[:, 0]), np.mean(r[:, 2] - r[:, 1]), np.mean(r[:, 3] - r[:, 2]))
+        sn, sf = stats(isnear), stats(isfar)
+        sT = [stats(stage == k) for k in range(3)]
+        for name, m in (("near", isnear), ("far", isfar), ("T1", stage == 0), ("T2", stage == 1), ("T3", stage == 2)):
+            if m.any():
+                r = rows[m]
+                d = kinds_tot.setdefault(name, [0, 0.0, 0.0, 0.0])
+                d[0] += int(m.sum()); d[1] += float(np.sum(r[:, 1] - r[:, 0])); d[2] += float(np.sum(r[:, 2] - r[:, 1])); d[3] += float(np.sum(r[:, 3] - r[:, 2]))
+        if s % a.every == 0 or s >= ns.value - 6:
+            t3end = rows[stage == (2 if two else 0), 3].max() if isT.any() else float("nan")
+            print("%4d %7d %6d | %8.1f %8.1f %8.1f | %5.1f %5.1f %5.1f | %5.1f %5.1f %5.1f | %5.1f %5.1f | %5.1f %5.1f | %5.1f %5.1f | %8.1f"
+                  % (s, nxt - base, nT, rows[:, 0].min(), rows[:, 3].max(), rows[:, 3].max() - rows[:, 0].min(),
+                     sn[0], sn[1], sn[2], sf[0], sf[1], sf[2], sT[0][0], sT[0][1] + sT[0][2], sT[1][0], sT[1][1] + sT[1][2],
+                     sT[2][0], sT[2][1] + sT[2][2], t3end))
+    print("totals per kind: count, slot-ms waiting for inputs, in the product (+ wait for the previous C version), in the epilogue")
+    for k, d in kinds_tot.items():
+        print("  %-5s %7d  %9.2f %9.2f %9.2f" % (k, d[0], d[1] * 1e-3, d[2] * 1e-3, d[3] * 1e-3))
+    fit.close()
+
+
+if __name__ == "__main__":
+    main()
