@@ -276,10 +276,11 @@ struct cocons_fit {
     double *dWt; int dWt_tiles;
     unsigned *ddag; size_t ddag_words;      // [queue (64 words)] [tdone] [pdone]
     void *ddag_steps; int dag_nsteps; unsigned dag_ntasks;
-    int dag_key[5];               // (nt, mt, trim, kskip, lead) the step table was built for
+    int dag_key[6];               // (nt, mt, trim, kskip, lead, min_tiles) the step table was built for
     unsigned long long *ddag_trace; size_t dag_trace_tasks;   // diagnostics (cocons_debug_tune("dag_trace", 1)): 4 stamps per task
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
     bool dag_used;                // the factorisation enqueued last ran the DAG schedule: its factor is split over dA and dP
+    double dag_flops; int dag_events;   // profile runs: update flops inside the DAG launch; 1 = the first event pair is that launch
     // taper fit (cocons_fit_create_taper): the spam pattern (1-based CSR) with the taper's entries; the
     // -2 log-likelihood is then that of the TAPERED covariance, evaluated through the dense factorisation
     int taper_nnz;                // > 0: taper fit
@@ -892,8 +893,11 @@ static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
 struct Tunables {
     int engine = 1;          // COCONS_ENGINE: 1 = diagonal blocks are factored by the resident engine beside the updates
     int upd_dynamic = 1;     // COCONS_UPD_DYNAMIC
-    int dag = 0;             // COCONS_DAG: 1 = the dependency-driven schedule (one persistent launch for all updates and panels)
+    int dag = 1;             // COCONS_DAG: 1 = the head of the factorisation under the dependency-driven schedule (one persistent
+                             // launch for its updates and panels, dag_kernel); 0 = the classic schedule throughout
     int dag_lead = 3600;     // COCONS_DAG_LEAD: far tiles of a step in front of its panel tasks
+    int dag_min_tiles = 4000;  // COCONS_DAG_MIN_TILES: the DAG launch covers the leading steps of at least this many update tiles
+                             // (n = 10^4: 19 of the 39 steps, 90 % of the flops; below n ~ 6000 no step at all)
     int dag_trace = 0;       // (diagnostics) time stamps per task, cocons_debug_dag_trace
     int gate_sabotage = 0;   // (tests) the next N engine-schedule factorisations wait at the gate for a word nobody raises:
                              // a genuine 5 ms time-out, abort code 0x600, to exercise the fall-back and its book-keeping
@@ -908,6 +912,7 @@ static Tunables &tun()
         rd("COCONS_UPD_DYNAMIC", t.upd_dynamic);
         rd("COCONS_DAG", t.dag);
         rd("COCONS_DAG_LEAD", t.dag_lead);
+        rd("COCONS_DAG_MIN_TILES", t.dag_min_tiles);
         t.init = true;
     }
     return t;
@@ -922,6 +927,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "upd_dynamic") t.upd_dynamic = value;
     else if (k == "dag") t.dag = value;
     else if (k == "dag_lead") t.dag_lead = value;
+    else if (k == "dag_min_tiles") t.dag_min_tiles = value;
     else if (k == "dag_trace") t.dag_trace = value;
     else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
@@ -1021,7 +1027,7 @@ static int engine_warm(cocons_fit *f)
                         f->dflags + 3 * (size_t)f->flags_cap, f->stream2);
     if (tun().dag)         // the other instantiation of the engine (never dereferences its buffers when t0 >= nt)
         launch_potrf_engine(nullptr, 0, 0, 0, f->dinv, f->dinfo, f->dflags, f->dflags, f->dflags, (unsigned *)(f->dinfo + 1),
-                            f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dinv, f->dinv);
+                            f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dinv, f->dinv, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(f->stream2));
     return 0;
@@ -1054,10 +1060,10 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         f->dWt_tiles = v.nt;
     }
     const int kskip = (f->pad0 / 16) * 16;
-    const int key[5] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead};
+    const int key[6] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles};
     if (memcmp(key, f->dag_key, sizeof key) != 0 || !f->ddag_steps) {
         std::vector<DagStepHost> steps;
-        const unsigned ntasks = dag_build_steps(v.nt, v.mt, v.trim, kskip, tun().dag_lead, steps);
+        const unsigned ntasks = dag_build_steps(v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, steps);
         HIPCHK(hipStreamSynchronize(f->stream));
         HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->ddag_steps) { HIPCHK(hipFree(f->ddag_steps)); f->ddag_steps = nullptr; }
@@ -1066,7 +1072,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         f->dag_nsteps = (int)steps.size(); f->dag_ntasks = ntasks;
         memcpy(f->dag_key, key, sizeof key);
         const size_t T64 = 2 * (size_t)v.mt;
-        const size_t words = 64 + T64 * (T64 + 1) / 2 + (steps.size() + 2) * T64;
+        const size_t words = 64 + T64 * (T64 + 1) / 2 + (steps.size() + 2) * T64 + steps.size() + 64;
         if (f->ddag_words < words) {
             if (f->ddag) { HIPCHK(hipFree(f->ddag)); f->ddag = nullptr; }
             HIPCHK(hipMalloc(&f->ddag, words * sizeof(unsigned)));
@@ -1076,7 +1082,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
     HIPCHK(hipMemsetAsync(f->ddag, 0, f->ddag_words * sizeof(unsigned), f->stream));
     if (tun().dag_trace && f->dag_trace_tasks < f->dag_ntasks) {
         if (f->ddag_trace) { HIPCHK(hipFree(f->ddag_trace)); f->ddag_trace = nullptr; }
-        HIPCHK(hipMalloc(&f->ddag_trace, (size_t)f->dag_ntasks * 4 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&f->ddag_trace, ((size_t)f->dag_ntasks * 4 + 8 * (size_t)(v.nt + 2)) * sizeof(unsigned long long)));   // + the engine's
         f->dag_trace_tasks = f->dag_ntasks;
     }
     return 0;
@@ -1084,8 +1090,10 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
 
 // diagnostics: the step table and the per-task stamps of the last DAG factorisation of the handle (dag_trace = 1).
 // steps_out: nsteps x 12 ints (DagStepHost); stamps_out: ntasks x 4 ticks of the 100 MHz clock.  Returns ntasks (or < 0);
-// with null outputs only the sizes: *nsteps_out.
-extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int *steps_out, unsigned long long *stamps_out)
+// with null outputs only the sizes: *nsteps_out.  engine_out (may be null): 8 stamps per tile pair, (nt + 2) / 2 pairs ... room
+// for 8 * (nt + 2) values (see EngineArgs::trace).
+extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int *steps_out, unsigned long long *stamps_out,
+                                            unsigned long long *engine_out)
 {
     if (int rc = fit_check(f)) return rc;
     if (!f->ddag_steps) return fail(-1, "cocons_debug_dag_trace: no DAG factorisation on this handle yet");
@@ -1095,6 +1103,9 @@ extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int 
     if (stamps_out) {
         if (!f->ddag_trace) return fail(-1, "cocons_debug_dag_trace: tracing was off (cocons_debug_tune(\"dag_trace\", 1))");
         HIPCHK(hipMemcpy(stamps_out, f->ddag_trace, (size_t)f->dag_ntasks * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (engine_out)
+            HIPCHK(hipMemcpy(engine_out, f->ddag_trace + 4 * (size_t)f->dag_ntasks, 8 * (size_t)(f->nt + 2) * sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost));
     }
     return (long long)f->dag_ntasks;
 }
@@ -1109,10 +1120,14 @@ static int engine_start(cocons_fit *f, const FactorView &v)
     HIPCHK(hipEventRecord(f->ev_eng, M));
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
     f->dag_next = dag_wanted(f, v);
-    if (f->dag_next) if (int rc = dag_prepare(f, v)) return rc;
+    if (f->dag_next) {
+        if (int rc = dag_prepare(f, v)) return rc;
+        if (f->dag_nsteps < 2) f->dag_next = false;          // too small a problem for a head worth the launch: classic throughout
+    }
     launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
                         f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dag_next ? f->dWt : nullptr,
-                        f->dag_next ? f->dP : nullptr);
+                        f->dag_next ? f->dP : nullptr, f->dag_next ? 2 * f->dag_nsteps : 0,
+                        (f->dag_next && tun().dag_trace && f->ddag_trace) ? f->ddag_trace + 4 * (size_t)f->dag_ntasks : nullptr);
     f->engine_live = true;
     return 0;
 }
@@ -1187,23 +1202,28 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     launch_engine_gate(alive, abort_word, M, false, f->engine_ops++ == 0);
     panel_ops(f, v, 0, M);
     f->dag_used = f->dag_next;
+    int k_first = 0;                 // first block step the classic loop below runs in full
     if (f->dag_next) {
-        // everything behind the first panel is ONE persistent launch (dag_kernel): tiles of update k + 1 start as soon as
-        // the strips of panel k + 1 they need and their own tile of update k are done; the panels are tile tasks of the same
-        // launch (the engine publishes the tile inverses they multiply with)
+        // the head of the factorisation -- the steps whose update fills the chip several times over -- is ONE persistent
+        // launch (dag_kernel): tiles of update k + 1 start as soon as the strips of panel k + 1 they need and their own tile of
+        // update k are done, and the panels between them are tile tasks of the same launch (the engine publishes the tile
+        // inverses they multiply with).  Behind the head a step is bound by its dependency chain, and there the classic
+        // sequence below has the shorter one: it takes over with the panel behind the last DAG step.
         const size_t T64 = 2 * (size_t)mt;
         unsigned *queue = f->ddag, *tdone = f->ddag + 64, *pdone = tdone + T64 * (T64 + 1) / 2;
+        unsigned *pall = pdone + ((size_t)f->dag_nsteps + 2) * T64;
         hipEvent_t ea = nullptr, eb = nullptr;
         if (ev_upd) {
-            for (int k = 0; k + 2 < nt; k += 2) count_update_flops(f, 2, k + 2);
+            const double before = f->upd_flops;
+            for (int s = 0; s < f->dag_nsteps; ++s) count_update_flops(f, 2, 2 * s + 2);
+            f->dag_flops = f->upd_flops - before;
             hipEventCreate(&ea); hipEventCreate(&eb);
             hipEventRecord(ea, M);
         }
         launch_dag(v.A, v.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
-                   pdone, (int)T64, in, out, xr, abort_word, M, tun().dag_trace ? f->ddag_trace : nullptr);
-        if (ev_upd) { hipEventRecord(eb, M); ev_upd->push_back(ea); ev_upd->push_back(eb); }
-        if (mt == nt) launch_engine_gate(out + (nt - 1), abort_word, M, true);
-        return 0;
+                   pdone, (int)T64, pall, in, out, xr, abort_word, M, tun().dag_trace ? f->ddag_trace : nullptr);
+        if (ev_upd) { hipEventRecord(eb, M); ev_upd->push_back(ea); ev_upd->push_back(eb); f->dag_events = 1; }
+        k_first = 2 * f->dag_nsteps;
     }
     // (Running the panel kernels on a stream of their own behind near-tile flags, so that they start in the tail of the
     // update that feeds them, was built and measured in round 3: slower -- a 90 KB-LDS solve is not placed beside eight
@@ -1211,14 +1231,16 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     // panel as products with explicit inverses published by the engine (round 3's COCONS_PANEL_MODE 1-3: +-1 %, deleted
     // in round 4))
     const int rend = mt * TILE - 64 * v.trim;         // one past the last row any panel kernel touches
-    for (int k = 0; k + 2 < nt; k += 2) {
+    for (int k = k_first > 0 ? k_first - 2 : 0; k + 2 < nt; k += 2) {
         const int t = k + 2;
         const bool two = t + 1 < nt;                 // the block has a second tile
         const int r0 = two ? t + 2 : t + 1;          // first tile row below the diagonal block
-        if (ev_upd) count_update_flops(f, 2, t);
         const int hb = band_hi(v, t);                // rows of block t's panel: [r0, hb) and the rows under the matrix
         const int br = hb >= 0 ? hb * TILE : -1, er = nt * TILE;
-        timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k));
+        if (k >= k_first) {                          // (the update with the last DAG step's panel was that launch's)
+            if (ev_upd) count_update_flops(f, 2, t);
+            timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k));
+        }
         launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048, M,
                          out + t, abort_word, br, er);
         if (two) {
@@ -1273,7 +1295,7 @@ static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, 
     if (int rc = factorize(f, fv, ev_upd)) return rc;
     if (stage_events) hipEventRecord(f->ev[2], f->stream);
     launch_finalize(f->dA, f->lda, f->n, slots ? f->n : f->npad, nrhs, f->dout, f->stream, f->skew, f->npad,
-                    f->dag_used ? f->dP : nullptr);
+                    f->dag_used ? f->dP : nullptr, f->dag_used ? 2 * TILE * f->dag_nsteps : 0);
     HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, (size_t)(2 + nrhs * nrhs) * sizeof(double),       // info words + outputs
                           hipMemcpyDeviceToHost, f->stream));
     if (stage_events) hipEventRecord(f->ev[3], f->stream);
@@ -1596,9 +1618,11 @@ extern "C" int cocons_fit_profile(cocons_fit *f, const double *theta, const doub
     if (int rc = no_taper(f, "cocons_fit_profile")) return rc;
     if (!theta || !mean || !ms || reps < 1) return fail(-1, "cocons_fit_profile: bad argument");
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    double dag_ms = 0.0;
     for (int it = 0; it < reps; ++it) {
         std::vector<hipEvent_t> ev;
         f->upd_flops = 0.0;
+        f->dag_flops = 0.0; f->dag_events = 0;
         if (int rc = enqueue_eval(f, theta, mean, true, nullptr, 0, &ev, true)) return rc;
         HIPCHK(hipStreamSynchronize(f->stream));
         float t01, t12, t23, t03;
@@ -1612,6 +1636,7 @@ extern "C" int cocons_fit_profile(cocons_fit *f, const double *theta, const doub
             float t;
             HIPCHK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
             sum += t;
+            if (i == 0 && f->dag_events) dag_ms += t;
         }
         acc[6] += sum;
         acc[5] = (double)(ev.size() / 2);
@@ -1622,6 +1647,8 @@ extern "C" int cocons_fit_profile(cocons_fit *f, const double *theta, const doub
     ms[6] = acc[6] / reps;
     ms[4] = acc[5] > 0 ? ms[6] / acc[5] : 0.0;
     ms[7] = f->upd_flops;
+    ms[8] = dag_ms / reps;
+    ms[9] = f->dag_flops;
     int st = info_status(f);
     if (engine_retry(f, st)) return cocons_fit_profile(f, theta, mean, reps, ms);
     return st;

@@ -466,6 +466,10 @@ struct EngineArgs {
     double *wbuf;            // DAG schedule: W = L^-1 of diagonal tile t goes to wbuf + t * 128 * 128 (column-major, ld 128,
                              // zero above the diagonal for good), published BEFORE out[t]: operand of the panel tasks
     double *pbuf;            // DAG schedule: X = A(t+1,t) L(t)^-T is stored into this second buffer too (same index as in A)
+    int dag_until;           // ... for the diagonal tiles t < dag_until only (the head of the factorisation runs the DAG schedule, the
+                             // chain-bound rest the classic one, which needs neither)
+    unsigned long long *trace;   // diagnostics (may be null): 8 stamps of the 100 MHz clock per tile pair t / 2 -- in[t] seen,
+                             // tile t factored, out[t] raised, in[t+1] seen, xr[t] raised, tile t+1 updated, factored, out[t+1] raised
 };
 
 // W = L^-1 of the 128 x 128 tile whose factor (block-packed) and Q operands (all eight diagonal blocks) are in LDS:
@@ -534,18 +538,24 @@ potrf_engine_kernel(EngineArgs e)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
+        unsigned long long *tr = (DAG && e.trace) ? e.trace + 8 * (size_t)(t >> 1) : nullptr;
+        if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
         potrf_tile_body<true>(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem, QALL);
         __syncthreads();
-        if (DAG) engine_tile_inverse(e.wbuf + (size_t)t * TILE * TILE, wave, lane);
+        if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
+        const bool dag_blk = DAG && t < e.dag_until;
+        if (dag_blk) engine_tile_inverse(e.wbuf + (size_t)t * TILE * TILE, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t);
+        if (tr && tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
         if (t + 1 >= e.nt) return;
 
         if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
+        if (tr && tid == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
         const int c0 = t * TILE, c1 = (t + 1) * TILE;
         {   // X = A(t+1,t) L(t)^-T : this wave's 16 x 128 strip
             // (addresses: a wave-uniform base and ONE 32-bit per-lane offset, re-derived for the stores -- thirty-two
@@ -581,7 +591,7 @@ potrf_engine_kernel(EngineArgs e)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     store_wt((double *)((char *)const_cast<double *>(Sb) + (lo + (unsigned)(16 * j + 4 * r) * ldab)), B[j][r]);
-            if (DAG) {
+            if (dag_blk) {
                 double *Pb = e.pbuf + (size_t)(c1 + 16 * wave) + (size_t)c0 * lda;
                 asm volatile("" : "+v"(lo));
 #pragma unroll
@@ -597,6 +607,7 @@ potrf_engine_kernel(EngineArgs e)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.xr + t);
+        if (tr && tid == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
         // A(t+1,t+1) -= X X^T : lower blocks b = wave, wave + 8, ...
         for (int bb = wave; bb < 36; bb += 8) {
             const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
@@ -612,14 +623,17 @@ potrf_engine_kernel(EngineArgs e)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // X in LDS is dead; the tile is re-read from memory
-        potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, DAG ? QALL : nullptr);
-        if (DAG) {
+        if (tr && tid == 0) tr[5] = __builtin_amdgcn_s_memrealtime();
+        potrf_tile_body<true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, dag_blk ? QALL : nullptr);
+        if (dag_blk) {
             __syncthreads();
+            if (tr && tid == 0) tr[6] = __builtin_amdgcn_s_memrealtime();
             engine_tile_inverse(e.wbuf + (size_t)(t + 1) * TILE * TILE, wave, lane);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) signal_add(e.out + t + 1);
+        if (tr && tid == 0) tr[7] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -967,7 +981,8 @@ struct DagArgs {
     unsigned ntasks;
     unsigned *queue;                 // task counter (zero at launch)
     unsigned *tdone;                 // per 64-tile (i >= j) at i (i + 1) / 2 + j: update steps applied
-    unsigned *pdone; int pstride;    // per panel p and strip (row64 - first row64 below block p's predecessor ... see dag_kernel)
+    unsigned *pdone; int pstride;    // per panel p and strip: panel tasks finished
+    unsigned *pall;                  // per panel p: strips complete (a workgroup that has seen pall[p] = all of them asks no more)
     unsigned *sig;                   // the engine's in[] words
     unsigned *out, *xr;              // the engine's out[] / xr[] words
     unsigned *abort_word;
@@ -988,6 +1003,7 @@ dag_kernel(DagArgs a)
     const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
     const DagStep *__restrict__ steps = a.steps;
     const unsigned ldab = 8u * (unsigned)a.lda;
+    int known = 0;                                     // panels 0 .. known are known to be complete (scalar, per workgroup)
     // EVERY task comes off the counter, the first one too (update_kernel hands out the first tile by block index: 2040
     // workgroups asking one word at the same instant cost ~8 us -- once per factorisation here, not per launch): whatever
     // part of the grid the chip holds at a given moment (another process may own CUs) then works on the LOWEST undrawn
@@ -1031,9 +1047,12 @@ dag_kernel(DagArgs a)
             gJb = Ps + (size_t)tj * TM + (size_t)st.k0 * a.lda;
             ldib = ldab; ldjb = ldab; K = st.K;
             Cb = a.A + (size_t)ti * TM + (size_t)tj * TM * a.lda;
-            if (s > 0) {
-                w0 = a.pdone + (size_t)s * a.pstride + (ti - st.tj0); n0 = (unsigned)st.need;
-                w1 = a.pdone + (size_t)s * a.pstride + (tj - st.tj0); n1 = (unsigned)st.need;
+            if (s > known) {
+                // (first the word that says the WHOLE panel is there: in the head of the factorisation it nearly always is, and
+                // then this workgroup asks nothing more for the rest of the step -- two polls per tile were 5 % of its time)
+                w0 = a.pall + s; n0 = (unsigned)st.H;
+                w1 = a.pdone + (size_t)s * a.pstride + (ti - st.tj0); n1 = (unsigned)st.need;
+                w2 = a.pdone + (size_t)s * a.pstride + (tj - st.tj0); n2 = (unsigned)st.need;
             }
             we = a.tdone + (ti * (ti + 1) / 2 + tj); ne = (unsigned)s;
             dn = we; dval = (unsigned)s + 1u;
@@ -1080,16 +1099,26 @@ dag_kernel(DagArgs a)
         // ---- inputs of the product complete?  (one lane; the words are nearly always there already)
         if (w0) {
             if (tid == 0) {
-                bool ok = wait_ge<false>(w0, n0, a.abort_word, 0xa00u + (unsigned)s);
-                if (ok && w1) ok = wait_ge<false>(w1, n1, a.abort_word, 0xb00u + (unsigned)s);
-                if (ok && w2) ok = wait_ge<false>(w2, n2, a.abort_word, 0xc00u + (unsigned)s);
-                *share = ok ? 1u : 0u;
+                unsigned ok;
+                if (!isT) {
+                    // update tile: whole panel there (2)?  else its two strips (1)
+                    if (__hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n0) ok = 2u;
+                    else ok = (wait_ge<false>(w1, n1, a.abort_word, 0xb00u + (unsigned)s) &&
+                               wait_ge<false>(w2, n2, a.abort_word, 0xc00u + (unsigned)s)) ? 1u : 0u;
+                } else {
+                    bool o = wait_ge<false>(w0, n0, a.abort_word, 0xa00u + (unsigned)s);
+                    if (o && w1) o = wait_ge<false>(w1, n1, a.abort_word, 0xb00u + (unsigned)s);
+                    if (o && w2) o = wait_ge<false>(w2, n2, a.abort_word, 0xc00u + (unsigned)s);
+                    ok = o ? 1u : 0u;
+                }
+                *share = ok;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            const unsigned ok = *share;
+            const unsigned ok = (unsigned)__builtin_amdgcn_readfirstlane((int)*share);
             __syncthreads();
             if (!ok) return;
+            if (ok == 2u) known = s;
         }
 
         if (a.trace && tid == 0) a.trace[4 * (size_t)L + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1144,9 +1173,9 @@ dag_kernel(DagArgs a)
         }
         // ---- the next task is asked for now (see update_kernel), and the C tile's previous version must be there
         if (t2 == 0) {
+            const unsigned Ln = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight during the poll)
             unsigned ok = 1u;
             if (we) ok = wait_ge<false>(we, ne, a.abort_word, 0xd00u + (unsigned)s) ? 1u : 0u;
-            const unsigned Ln = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             share[0] = ok; share[1] = Ln;
             if (a.trace) a.trace[4 * (size_t)L + 2] = __builtin_amdgcn_s_memrealtime();
         }
@@ -1180,7 +1209,8 @@ dag_kernel(DagArgs a)
         if (t2 == 0) {
             if (sigT >= 0) signal_add(a.sig + sigT);
             if (dval) __hip_atomic_store(dn, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else __hip_atomic_fetch_add(dn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (__hip_atomic_fetch_add(dn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (st.two ? 6u : 2u))
+                __hip_atomic_fetch_add(a.pall + s + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the strip is complete
             if (a.trace) a.trace[4 * (size_t)L + 3] = __builtin_amdgcn_s_memrealtime();
         }
         L = (unsigned)__builtin_amdgcn_readfirstlane((int)Lnext);
@@ -1207,10 +1237,10 @@ __device__ __forceinline__ double block_sum(double v, double *red)
 // block nr*nr: sum of log of the diagonal over the same columns.
 __global__ void __launch_bounds__(1024)
 finalize_kernel(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr, double *out, int skew, int npad,
-                const double *A2)
+                const double *A2, int a2_cols)
 {
     // A2 != NULL (dense layout only): the factor of the dependency-driven schedule -- the part of a column BELOW the 256 x 256
-    // diagonal block it runs through lives in A2 (from the second block on), everything else in A (dag_kernel)
+    // diagonal block it runs through lives in A2 (columns [256, a2_cols): the panels its tasks formed), everything else in A
     __shared__ double red[16];
     const int b = blockIdx.x;
     const int hi = c1 < n ? c1 : n;
@@ -1238,8 +1268,9 @@ finalize_kernel(const double *A, size_t lda, int c0, int c1, int n, int row0, in
                 const int cc = c + q * step;
                 int below0 = 2 * TILE * (cc / (2 * TILE) + 1);                // first row below column cc's diagonal block
                 if (npad > 0 && below0 > npad) below0 = npad;                 // (a last block of one tile)
-                const double *Sa = (A2 && cc >= 2 * TILE && ra >= below0) ? A2 : A;
-                const double *Sb = (A2 && cc >= 2 * TILE && rb >= below0) ? A2 : A;
+                const bool in2 = A2 && cc >= 2 * TILE && cc < a2_cols;
+                const double *Sa = (in2 && ra >= below0) ? A2 : A;
+                const double *Sb = (in2 && rb >= below0) ? A2 : A;
                 va[q] = in ? Sa[band_index(ra, cc, lda, skew, npad)] : 0.0;
                 vb[q] = in ? Sb[band_index(rb, cc, lda, skew, npad)] : 0.0;
             }
@@ -1380,12 +1411,12 @@ static size_t engine_lds_bytes()
 // object, LDS configuration) is paid there and not inside the bounded gate of the first engine-schedule operation.
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
-                         double *wbuf, double *pbuf)
+                         double *wbuf, double *pbuf, int dag_until, unsigned long long *trace)
 {
     EngineArgs e;
     e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
     e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive;
-    e.wbuf = wbuf; e.pbuf = pbuf;
+    e.wbuf = wbuf; e.pbuf = pbuf; e.dag_until = dag_until; e.trace = trace;
     const size_t shm = engine_lds_bytes();
     if (wbuf && pbuf) {
         static std::atomic<unsigned long long> attr_done{0};
@@ -1488,13 +1519,18 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
 // Steps for a factorisation with nt column tiles and mt row tiles (trim64: the last 64 rows hold nothing), first panel
 // (tiles 0, 1) already formed in place; kskip leading columns of it are unit vectors (front padding) and are skipped.
 // lead: far tiles of a step in front of its panel tasks.  Returns the number of tasks.
-unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, std::vector<DagStepHost> &out)
+unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, std::vector<DagStepHost> &out)
 {
     out.clear();
     unsigned base = 0;
     int prev_two = 1;
     for (int k = 0; k + 2 < nt; k += 2) {
         const int t = k + 2;
+        {   // the DAG schedule covers the head of the factorisation: steps of at least min_tiles update tiles (behind them a step
+            // is bound by its dependency chain, not by the chip, and the classic schedule's chain is the shorter one)
+            const long long H0 = 2LL * (mt - t) - (trim64 ? 1 : 0), W0 = 2LL * (nt - t);
+            if (W0 * H0 - W0 * (W0 - 1) / 2 < min_tiles) break;
+        }
         DagStepHost st;
         st.tj0 = 2 * t;
         st.H = 2 * (mt - t) - (trim64 ? 1 : 0);
@@ -1515,19 +1551,24 @@ unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, std::v
         prev_two = st.two;
         out.push_back(st);
     }
+    if (!out.empty()) {      // the panel behind the last step is formed by whoever continues (classic kernels): no panel tasks
+        DagStepHost &l = out.back();
+        base -= l.nT;
+        l.nT = 0; l.nstrip = 0;
+    }
     return base;
 }
 
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
-                unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *sig, unsigned *out, unsigned *xr,
-                unsigned *abort_word, hipStream_t s, unsigned long long *trace)
+                unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, unsigned *sig, unsigned *out,
+                unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace)
 {
     static_assert(sizeof(DagStepHost) == sizeof(DagStep), "host and device step records");
     if (nsteps <= 0 || ntasks == 0) return;
     DagArgs a;
     a.A = A; a.lda = lda; a.P = P; a.Wt = Wt;
     a.steps = (const DagStep *)dsteps; a.nsteps = nsteps; a.ntasks = ntasks;
-    a.queue = queue; a.tdone = tdone; a.pdone = pdone; a.pstride = pstride;
+    a.queue = queue; a.tdone = tdone; a.pdone = pdone; a.pstride = pstride; a.pall = pall;
     a.sig = sig; a.out = out; a.xr = xr; a.abort_word = abort_word; a.trace = trace;
     static int slots = 0;
     if (!slots) {
@@ -1553,14 +1594,14 @@ void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, in
                           double *out, hipStream_t s)
 {
     hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(1024), 0, s, A, lda, c0, c1, n, row0, nr, out, 0, 0,
-                       (const double *)nullptr);
+                       (const double *)nullptr, 0);
 }
 
 void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s, int skew, int npad,
-                     const double *A2)
+                     const double *A2, int a2_cols)
 {
     hipLaunchKernelGGL(finalize_kernel, dim3(nr * nr + 1), dim3(1024), 0, s, A, lda, 0, n, n, row0, nr, out, skew, npad,
-                       skew ? (const double *)nullptr : A2);
+                       skew ? (const double *)nullptr : A2, a2_cols);
 }
 
 size_t row_reduce_scratch_doubles(int n, int m)

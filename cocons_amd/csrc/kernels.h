@@ -124,7 +124,8 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
 // wbuf + t * 128 * 128 (zeroed once by the caller; complete before out[t]) and a second copy of X in pbuf (shaped like A)
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
-                         double *wbuf = nullptr, double *pbuf = nullptr);
+                         double *wbuf = nullptr, double *pbuf = nullptr, int dag_until = 0,
+                         unsigned long long *trace = nullptr);
 void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false, bool patient = false);
 // rows [r0, r1) x cols [c0, c0+128):  X <- X * L(c0)^{-T}, L read from A(c0,c0).
 // wait_word != NULL: the tile comes from the engine -- every workgroup first waits for *wait_word >= 1
@@ -165,17 +166,20 @@ struct DagStepHost {
     unsigned base, near, tpos, nT;
     int H, W, tj0, k0, K, nstrip, two, need;
 };
-unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, std::vector<DagStepHost> &out);
+// only the leading steps with at least min_tiles update tiles are taken (the head of the factorisation); the last of them has
+// no panel tasks: the panel behind it is left to the caller's classic kernels
+unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, std::vector<DagStepHost> &out);
 // dsteps: DEVICE copy of the table.  queue, tdone (2 mt (2 mt + 1) / 2 words), pdone ((nsteps + 1) * pstride words,
-// pstride >= 2 mt): zero at launch.  sig / out / xr: the engine's words (launch_potrf_engine with wbuf = Wt, pbuf = P).
+// pstride >= 2 mt), pall (nsteps + 1 words): zero at launch.  sig / out / xr: the engine's words (launch_potrf_engine with wbuf = Wt, pbuf = P).
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
-                unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *sig, unsigned *out, unsigned *xr,
-                unsigned *abort_word, hipStream_t s, unsigned long long *trace = nullptr);
+                unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, unsigned *sig, unsigned *out,
+                unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace = nullptr);
 
 // reductions: out[0] = sum_{i<n} log(A(i,i)); out[1 + a*nr + b] = sum_{c<n} A(row0+a,c) A(row0+b,c)
 void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s,
                      int skew = 0, int npad = 0,           // packed band source (band_index)
-                     const double *A2 = nullptr);          // factor of the DAG schedule: below the diagonal blocks it lives in A2
+                     const double *A2 = nullptr,           // factor of the DAG schedule: below the diagonal blocks the columns
+                     int a2_cols = 0);                     // [256, a2_cols) live in A2
 // partial version over columns [c0,c1) accumulating into out (atomic adds), sharded path
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,
                           double *out, hipStream_t s);

@@ -331,11 +331,11 @@ class CoconsFit:
         """Stage timings (ms) from HIP events on the fit's stream; see cocons_fit_profile."""
         T = theta_table(theta_list)
         mean = np.ascontiguousarray(np.asarray(theta_list["mean"], dtype=np.float64))
-        ms = np.zeros(8)
+        ms = np.zeros(10)
         _lib.check(self._L.cocons_fit_profile(self._h, _p(T), _p(mean), int(reps), _p(ms)), "cocons_fit_profile")
         return {"assembly_ms": ms[0], "cholesky_ms": ms[1], "reduce_ms": ms[2], "eval_ms": ms[3],
                 "update_avg_ms": ms[4], "update_launches": int(ms[5]), "update_sum_ms": ms[6],
-                "update_flops": ms[7]}
+                "update_flops": ms[7], "dag_ms": ms[8], "dag_flops": ms[9]}
 
 
 class CoconsTaperFit(CoconsFit):

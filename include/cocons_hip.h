@@ -198,8 +198,10 @@ int cocons_chol_solve(int n, const double *A, int nrhs, const double *rhs,
  * (+solve, fused), ms[2]=reductions, ms[3]=whole evaluation, ms[4]=average duration
  * of one trailing-update (MFMA) launch, ms[5]=number of such launches per
  * evaluation, ms[6]=sum of trailing-update launch durations per evaluation,
- * ms[7]=algorithmic flops of those launches (K m (m+1) + 2 K r m each; m = trailing order).
- * `ms` must hold 8 doubles.                                                       */
+ * ms[7]=algorithmic flops of those launches (K m (m+1) + 2 K r m each; m = trailing order),
+ * ms[8]=duration of the ONE persistent launch that runs the head of the factorisation under the
+ * dependency-driven schedule (it is also the first of the launches counted in ms[5..7]; 0 when the
+ * classic schedule ran), ms[9]=the update flops inside it.  `ms` must hold 10 doubles.           */
 int cocons_fit_profile(cocons_fit *fit, const double *theta, const double *mean,
                        int reps, double *ms);
 

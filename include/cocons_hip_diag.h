@@ -48,7 +48,8 @@ int cocons_debug_tune(const char *name, int value);
  * fit handle: steps_out = nsteps x 12 ints (base, near, tpos, nT, H, W, tj0, k0, K, nstrip, two, need), stamps_out =
  * ntasks x 4 ticks of the 100 MHz clock (drawn, inputs complete, product done, stored).  Returns ntasks; null outputs: sizes only. */
 struct cocons_fit;
-long long cocons_debug_dag_trace(struct cocons_fit *fit, int *nsteps_out, int *steps_out, unsigned long long *stamps_out);
+long long cocons_debug_dag_trace(struct cocons_fit *fit, int *nsteps_out, int *steps_out, unsigned long long *stamps_out,
+                                 unsigned long long *engine_out);   /* engine_out (may be null): 8 stamps per pair of tiles, room for 8 (nt + 2) */
 
 #ifdef __cplusplus
 }

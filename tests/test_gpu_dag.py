@@ -19,9 +19,12 @@ def _tune(name, value):
 
 @pytest.fixture
 def dag_on():
+    """The DAG schedule for EVERY step (dag_min_tiles = 0: by default only the head of a large factorisation takes it)."""
     _tune("dag", 1)
+    _tune("dag_min_tiles", 0)
     yield
-    _tune("dag", int(os.environ.get("COCONS_DAG", "0")))
+    _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
+    _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "4000")))
 
 
 def _grid(gx, gy):
@@ -120,3 +123,33 @@ def test_dag_changing_parameters_stay_reproducible(dag_on):
         assert fit.neg2loglik_core(ths[i])[0] == first[i]
     assert fit.engine_state()["retries"] == 0
     fit.close()
+
+
+@pytest.mark.parametrize("g,min_tiles", [(64, 1000), (100, 6000)])
+def test_dag_head_then_classic(g, min_tiles):
+    """The shipped form: the DAG launch for the head of the factorisation (steps of at least `min_tiles` update tiles), the
+    classic schedule behind it -- n = 4096 with a three-step head, and the benchmark size with the default threshold -- against
+    the classic schedule throughout; bit-reproducible, engine never timed out."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    z = wl.synthetic_z(g * g)
+    th = wl.theta_full()
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    _tune("dag", 0)
+    v_cl = fit.neg2loglik_core(th)[0]
+    _tune("dag", 1)
+    _tune("dag_min_tiles", min_tiles)
+    try:
+        v = fit.neg2loglik_core(th)[0]
+        assert fit.neg2loglik_core(th)[0] == v
+        st = fit.profile_stages(th, reps=1)
+        assert st["dag_ms"] > 0 and st["dag_flops"] > 0            # the head really ran as one launch
+        assert abs(v - v_cl) <= 1e-11 * abs(v_cl), (v, v_cl)
+        es = fit.engine_state()
+        assert es["retries"] == 0 and es["active"]
+    finally:
+        _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
+        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "4000")))
+        fit.close()

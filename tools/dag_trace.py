@@ -34,53 +34,77 @@ def main():
     for _ in range(3):
         fit.neg2loglik_core(th)
     ns = ctypes.c_int(0)
-    nt = L.cocons_debug_dag_trace(fit._h, ctypes.byref(ns), None, None)
+    nt = L.cocons_debug_dag_trace(fit._h, ctypes.byref(ns), None, None, None)
     assert nt > 0, _lib.last_error()
     steps = np.zeros((ns.value, 12), dtype=np.int32)
     st = np.zeros((nt, 4), dtype=np.uint64)
+    eng = np.zeros((8 * (2 * ns.value + 8),), dtype=np.uint64)
+    ntile = (g * g + 127) // 128
+    eng = np.zeros((8 * (ntile + 2),), dtype=np.uint64)
     rc = L.cocons_debug_dag_trace(fit._h, ctypes.byref(ns), steps.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
-                                  st.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)))
+                                  st.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)),
+                                  eng.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)))
     assert rc == nt, _lib.last_error()
     t0 = float(st[:, 0].min())
     T = (st.astype(np.float64) - t0) * 0.01                    # microseconds
+    E = (eng.astype(np.float64).reshape(-1, 8) - t0) * 0.01
     total = T[:, 3].max()
     print("n = %d: %d tasks in %d steps, kernel span %.1f us; slot-time busy %.1f %% of 2040 slots"
           % (g * g, nt, ns.value, total, 100 * np.sum(T[:, 3] - T[:, 0]) / (2040 * total)))
-    print("%4s %7s %6s | %8s %8s %8s | near: wait  prod  epi | far: wait  prod  epi | T1 wait prod | T2 wait prod | T3 wait prod | T3 last end"
-          % ("step", "tasks", "nT", "start", "end", "span"))
+    print("per step: tasks; [start end] of the step; far tiles: mean wait / product / epilogue; then the CHAIN of the step (us, absolute):")
+    print("  diagR = the 10 diagonal-block tiles have their inputs, diagE = last of them stored (product time in brackets);")
+    print("  engine: tile t factored +inverse-> out[t]; xr; tile t+1 factored +inverse-> out[t+1];  T3c = T3 of the first four strips done")
     kinds_tot = {}
+    prev_t3c = 0.0
     for s in range(ns.value):
-        base, near, tpos, nT, H, W, tj0, k0, K, nstrip, two, need = [int(v) for v in steps[s].view(np.uint32)[:4]] + [int(v) for v in steps[s][4:]]
+        base, near, tpos, nT = [int(v) for v in steps[s].view(np.uint32)[:4]]
+        H, W, tj0, k0, K, nstrip, two, need = [int(v) for v in steps[s][4:]]
         nxt = int(steps[s + 1].view(np.uint32)[0]) if s + 1 < ns.value else nt
         rows = T[base:nxt]
         q = np.arange(nxt - base)
         isT = (q >= tpos) & (q < tpos + nT)
         u = q - tpos
         stage = np.where(isT, u // max(1, 2 * nstrip), -1)
+        strip = np.where(isT, (u % max(1, 2 * nstrip)) // 2, -1)
         isnear = (~isT) & (q < near)
         isfar = (~isT) & ~isnear
+        # diagonal-block tiles: column jl < 4, row offset jl + r < 4
+        isdiag = np.zeros_like(isnear)
+        off = 0
+        for jl in range(min(W, 4)):
+            cnt = H - jl
+            for r in range(min(cnt, 4 - jl)):
+                isdiag[off + r] = True
+            off += cnt
 
         def stats(m):
             if not m.any():
                 return (0.0, 0.0, 0.0)
             r = rows[m]
             return (np.mean(r[:, 1] - r[:, 0]), np.mean(r[:, 2] - r[:, 1]), np.mean(r[:, 3] - r[:, 2]))
-        sn, sf = stats(isnear), stats(isfar)
-        sT = [stats(stage == k) for k in range(3)]
-        for name, m in (("near", isnear), ("far", isfar), ("T1", stage == 0), ("T2", stage == 1), ("T3", stage == 2)):
+        sf = stats(isfar)
+        for name, m in (("diag", isdiag), ("near", isnear & ~isdiag), ("far", isfar), ("T1", stage == 0), ("T2", stage == 1), ("T3", stage == 2)):
             if m.any():
                 r = rows[m]
                 d = kinds_tot.setdefault(name, [0, 0.0, 0.0, 0.0])
                 d[0] += int(m.sum()); d[1] += float(np.sum(r[:, 1] - r[:, 0])); d[2] += float(np.sum(r[:, 2] - r[:, 1])); d[3] += float(np.sum(r[:, 3] - r[:, 2]))
         if s % a.every == 0 or s >= ns.value - 6:
-            t3end = rows[stage == (2 if two else 0), 3].max() if isT.any() else float("nan")
-            print("%4d %7d %6d | %8.1f %8.1f %8.1f | %5.1f %5.1f %5.1f | %5.1f %5.1f %5.1f | %5.1f %5.1f | %5.1f %5.1f | %5.1f %5.1f | %8.1f"
-                  % (s, nxt - base, nT, rows[:, 0].min(), rows[:, 3].max(), rows[:, 3].max() - rows[:, 0].min(),
-                     sn[0], sn[1], sn[2], sf[0], sf[1], sf[2], sT[0][0], sT[0][1] + sT[0][2], sT[1][0], sT[1][1] + sT[1][2],
-                     sT[2][0], sT[2][1] + sT[2][2], t3end))
+            dg = rows[isdiag]
+            e = E[(tj0 // 2) // 2]
+            last_stage = 2 if two else 0
+            m3 = (stage == last_stage) & (strip < 4)
+            t3c = rows[m3, 3].max() if m3.any() else float("nan")
+            print("%3d %6d [%7.1f %7.1f] far %4.1f/%4.1f/%4.1f | diagR %7.1f diagE %7.1f (%4.1f) | eng %7.1f ->%7.1f; xr %7.1f; %7.1f ->%7.1f | T3c %7.1f | period %6.1f"
+                  % (s, nxt - base, rows[:, 0].min(), rows[:, 3].max(), sf[0], sf[1], sf[2], dg[:, 1].max(), dg[:, 3].max(),
+                     np.mean(dg[:, 3] - dg[:, 1]), e[1], e[2], e[4], e[6], e[7], t3c, t3c - prev_t3c))
+            prev_t3c = t3c
+        else:
+            last_stage = 2 if two else 0
+            m3 = (stage == last_stage) & (strip < 4)
+            prev_t3c = rows[m3, 3].max() if m3.any() else prev_t3c
     print("totals per kind: count, slot-ms waiting for inputs, in the product (+ wait for the previous C version), in the epilogue")
     for k, d in kinds_tot.items():
-        print("  %-5s %7d  %9.2f %9.2f %9.2f" % (k, d[0], d[1] * 1e-3, d[2] * 1e-3, d[3] * 1e-3))
+        print("  %-5s %7d  %9.2f %9.2f %9.2f   mean product %.1f us" % (k, d[0], d[1] * 1e-3, d[2] * 1e-3, d[3] * 1e-3, d[2] / max(1, d[0])))
     fit.close()
 
 
