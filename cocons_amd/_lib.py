@@ -21,6 +21,7 @@ UNIQUE_ID_BYTES = 128
 BCAST_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p)
 # int (*)(void *user, double *host_inout, int count, int op)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p)
 c_int = ctypes.c_int
 c_vp = ctypes.c_void_p
 
@@ -77,16 +78,9 @@ SIGNATURES = {
     "cocons_multi_neg2loglik_batch": (c_int, [c_vp, c_int, c_dp, c_dp, c_dp, ctypes.POINTER(c_int)]),
     "cocons_multi_comm_ranks": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "cocons_fit_comm_info": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
-    "cocons_shard_begin": (c_int, [c_vp, c_dp, c_dp, c_int, c_int]),
-    "cocons_shard_panel_factor": (c_int, [c_vp, c_int]),
-    "cocons_shard_panel_buffer": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(ctypes.c_longlong)]),
-    "cocons_shard_panel_apply": (c_int, [c_vp, c_int]),
-    "cocons_shard_panel_apply_range": (c_int, [c_vp, c_int, c_int, c_int]),
-    "cocons_shard_finish": (c_int, [c_vp, c_dp, ctypes.POINTER(c_int)]),
-    "cocons_shard_num_panels": (c_int, [c_vp]),
-    "cocons_shard_panel_owner": (c_int, [c_int, c_int]),
-    "cocons_shard_exchange_bytes": (ctypes.c_longlong, [c_vp]),
-    "cocons_shard_set_exchange": (c_int, [c_vp, c_vp, c_vp, ctypes.c_longlong]),
+    "cocons_shard_block_owner": (c_int, [c_int, c_int]),
+    "cocons_shard_num_blocks": (c_int, [c_vp]),
+    "cocons_fit_set_allgather": (c_int, [c_vp, c_vp]),
     "cocons_fit_stream": (c_vp, [c_vp]),
     "cocons_fit_set_stream": (c_int, [c_vp, c_vp]),
     "cocons_fit_sync": (c_int, [c_vp]),

@@ -135,6 +135,7 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t);
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     ncclResult_t (*GroupStart)();
     ncclResult_t (*GroupEnd)();
     const char *(*GetErrorString)(ncclResult_t);
@@ -185,6 +186,7 @@ static RcclApi *rccl_api()
         RSYM(CommDestroy, "ncclCommDestroy")
         RSYM(Broadcast, "ncclBroadcast")
         RSYM(AllReduce, "ncclAllReduce")
+        RSYM(AllGather, "ncclAllGather")
         RSYM(GroupStart, "ncclGroupStart")
         RSYM(GroupEnd, "ncclGroupEnd")
         RSYM(GetErrorString, "ncclGetErrorString")
@@ -299,9 +301,10 @@ struct cocons_fit {
     bool comm_own;                // the communicator was created by cocons_fit_comm_init (destroy it with the fit)
     cocons_bcast_fn cb_bcast;
     cocons_allreduce_fn cb_allreduce;
+    cocons_allgather_fn cb_allgather;
+    struct ShardState *shard;     // plan, buffers and events of the sharded evaluation (row-block ownership)
     void *cb_user;
     hipStream_t cstream;          // stream the panel broadcasts are issued on
-    hipEvent_t ev_main[2], ev_comm[2];   // per exchange buffer: pack / last reader done, broadcast done
     double *dcoll;                // device staging of the final all-reduce (RCCL)
     double upd_flops;             // algorithmic flops of the event-timed trailing updates (profile runs)
     // host copies of the inputs + lazily created clones: the slots of cocons_neg2loglik_batch
@@ -310,6 +313,8 @@ struct cocons_fit {
     bool sorted;                  // observations are stored in Morton order (see fit_create_impl)
     cocons_fit *unsorted;         // lazily created clone in the ORIGINAL order (marginal simulation)
 };
+
+static void shard_state_free(struct ShardState *S);
 
 static int fit_check(cocons_fit *f)
 {
@@ -356,8 +361,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         hipFree(f->dP); hipFree(f->dWt); hipFree(f->ddag); hipFree(f->ddag_steps); hipFree(f->ddag_trace);
         hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_thi);
         if (f->cstream) { hipStreamSynchronize(f->cstream); hipStreamDestroy(f->cstream); }
-        for (auto &e : f->ev_main) if (e) hipEventDestroy(e);
-        for (auto &e : f->ev_comm) if (e) hipEventDestroy(e);
+        shard_state_free(f->shard);
         hipFree(f->dcoll);
         if (f->comm && f->comm_own) rccl_comm_destroy(f->comm);
         if (f->slots) { for (auto c : *f->slots) cocons_fit_destroy(c); delete f->slots; f->slots = nullptr; }
@@ -1023,6 +1027,26 @@ static int engine_warm(cocons_fit *f)
     if (!engine_enabled() || f->nt <= 4) return 0;
     if (int rc = flags_reset(f, f->nt)) return rc;
     HIPCHK(hipStreamSynchronize(f->stream));
+    // The engine's stream must not share a hardware queue with the main stream (HIP multiplexes streams onto a few queues;
+    // which one a stream gets depends on every stream the PROCESS has created): test it, and draw another stream if it
+    // does -- the losers stay alive until a winner is found, so that the next draw lands elsewhere.  No luck: this handle
+    // stays on the plain schedule.
+    {
+        std::vector<hipStream_t> losers;
+        int ok = 0;
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            ok = streams_run_concurrently(f->stream2, f->stream, f->dflags + 3 * (size_t)f->flags_cap + 8);
+            if (ok != 0) break;
+            losers.push_back(f->stream2);
+            f->stream2 = nullptr;
+            if (hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking) != hipSuccess) { ok = -1; break; }
+        }
+        for (hipStream_t l : losers) hipStreamDestroy(l);
+        if (ok < 0) { (void)hipGetLastError(); return fail(-100, "engine_warm: stream self-test failed"); }
+        if (ok == 0) { f->engine_ok = false; return 0; }
+        HIPCHK(hipMemsetAsync(f->dflags, 0, (4 * (size_t)f->flags_cap + 64) * sizeof(unsigned), f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+    }
     launch_potrf_engine(nullptr, 0, 0, 0, f->dinv, f->dinfo, f->dflags, f->dflags, f->dflags, (unsigned *)(f->dinfo + 1),
                         f->dflags + 3 * (size_t)f->flags_cap, f->stream2);
     if (tun().dag)         // the other instantiation of the engine (never dereferences its buffers when t0 >= nt)
@@ -1068,7 +1092,10 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->ddag_steps) { HIPCHK(hipFree(f->ddag_steps)); f->ddag_steps = nullptr; }
         HIPCHK(hipMalloc(&f->ddag_steps, (steps.size() + 1) * sizeof(DagStepHost)));
-        HIPCHK(hipMemcpy(f->ddag_steps, steps.data(), steps.size() * sizeof(DagStepHost), hipMemcpyHostToDevice));
+        // (on the handle's own stream: the library never touches the NULL stream -- a synchronous hipMemcpy here gave it a
+        // hardware queue of its own and shifted every later stream's assignment)
+        HIPCHK(hipMemcpyAsync(f->ddag_steps, steps.data(), steps.size() * sizeof(DagStepHost), hipMemcpyHostToDevice, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
         f->dag_nsteps = (int)steps.size(); f->dag_ntasks = ntasks;
         memcpy(f->dag_key, key, sizeof key);
         const size_t T64 = 2 * (size_t)v.mt;
@@ -2279,11 +2306,22 @@ extern "C" int cocons_chol_solve(int n, const double *Ain, int nrhs, const doubl
 }
 
 // ---------------------------------------------------------------------------
-// column-panel sharded evaluation.  Panel = 2 tiles (256 columns); panels are dealt over the ranks in GROUPS of G
-// consecutive panels, owner(k) = (k / G) % world (COCONS_SHARD_GROUP, default 4).  Inside a group the owner goes on to
-// its next panel while the broadcast of the previous one is still travelling, so per panel the chain is
-// max(factor, broadcast) instead of factor + broadcast; G = 1 is the round-1/2 cyclic deal.
-static const int PT = 2;     // tiles per panel
+// Sharded evaluation: Sigma ROW-BLOCK partitioned over the ranks.  Block b = the 256 rows of the
+// tiles 2b, 2b+1; blocks are dealt in GROUPS of G consecutive blocks, owner(b) = (b / G) mod world (COCONS_SHARD_GROUP,
+// default 4).  A rank assembles, solves and updates ITS rows of every column; per 256-column block k:
+//   owner(k)     factors the 256 x 256 diagonal block (all earlier updates of its rows are local)      [0.5 MB]
+//   broadcast    L_kk (+ the 4x4-inverse operands of its sixteen 16 x 16 diagonal blocks) from owner(k)
+//   every rank   solves ITS rows of the panel, X = B L_kk^-T, in place (solve | in-panel update | solve, row-filtered)
+//   owner(k+1)   updates its diagonal block (k+1,k+1) with its own rows of X -- local data -- factors it and starts the
+//                broadcast of L_(k+1,k+1): the chain diagonal block -> diagonal block never waits for the bulk exchange
+//   all-gather   of the solved rows, packed by owner (every rank contributes B_k / world; on point-to-point links every
+//                link then carries B_k / world instead of the whole panel a broadcast would push through each)
+//   every rank   updates ITS rows of the trailing matrix with the gathered panel (the column side of a tile belongs to
+//                another rank in general: both operands come from the gathered buffer through a per-tile offset table)
+// The right-hand sides are rows under the matrix = part of the last block's row block: their owner ends up with
+// L^-1 (z - X beta) in place and every rank with every L_kk, so the reductions need no data exchange beyond the usual
+// all-reduce of (1 + r^2) doubles and the failing minor.
+static const int PT = 2;     // tiles per block
 
 static int shard_group()
 {
@@ -2294,196 +2332,169 @@ static int shard_group()
     }();
     return g;
 }
-static inline int shard_owner(int k, int world) { return (k / shard_group()) % world; }
+static inline int shard_owner(int b, int world) { return (b / shard_group()) % world; }
 
-extern "C" int cocons_shard_panel_owner(int k, int world) { return (k < 0 || world < 1) ? -1 : shard_owner(k, world); }
+extern "C" int cocons_shard_block_owner(int b, int world) { return (b < 0 || world < 1) ? -1 : shard_owner(b, world); }
+extern "C" int cocons_shard_num_blocks(cocons_fit *f) { return f ? (f->nt + PT - 1) / PT : -1; }
 
-extern "C" int cocons_shard_num_panels(cocons_fit *f) { return f ? (f->nt + PT - 1) / PT : -1; }
+static const size_t LKK_DOUBLES = (size_t)PT * TILE * PT * TILE + 2 * 2048;     // diagonal block + Q operands of its two tiles
 
-// rows a packed panel carries: the matrix rows plus the right-hand-side rows the sharded evaluation
-// uses (r rows rounded up to a tile) -- NOT the buffer's leading dimension, which an earlier
-// cocons_predict_dense on the same handle may have grown
-static inline size_t shard_rows(cocons_fit *f) { return (size_t)f->npad + round_up(f->r > 0 ? f->r : 1, TILE); }
+// host-side plan of one evaluation's exchange: per block k the rows below it, dealt to their owners and packed
+struct ShardPlan {
+    int nt = 0, mt = 0, world = 0, group = 0;
+    std::vector<int> tlo;            // per block: first 64-row tile below the block
+    std::vector<int> ncols;          // per block: its columns (256, or 128 for a last block of one tile)
+    std::vector<long long> srows;    // per block: rows per slot S_k (64 x the largest number of tiles any rank owns below)
+    std::vector<int> pmap;           // nb x T64: element offset of 64-row tile ti in the gathered buffer of block k (-1: above)
+    std::vector<int> cnt;            // nb x world: tiles rank w owns below block k
+    size_t max_elems = 0;            // largest gathered buffer
+};
 
-extern "C" long long cocons_shard_exchange_bytes(cocons_fit *f)
+static void shard_make_plan(ShardPlan &P, int nt, int mt, int world, int group)
 {
-    if (!f) return -1;
-    return (long long)(shard_rows(f) * PT * TILE * sizeof(double));
-}
-
-// the caller may hand in two exchange buffers it owns (e.g. torch tensors, so that
-// torch.distributed can broadcast them); otherwise the library allocates them.
-extern "C" int cocons_shard_set_exchange(cocons_fit *f, void *buf0, void *buf1, long long bytes)
-{
-    if (int rc = fit_check(f)) return rc;
-    if (bytes < cocons_shard_exchange_bytes(f)) return fail(-1, "cocons_shard_set_exchange: buffer too small");
-    if (f->xbuf_own) { hipFree(f->xbuf[0]); hipFree(f->xbuf[1]); f->xbuf_own = false; }
-    f->xbuf[0] = (double *)buf0; f->xbuf[1] = (double *)buf1; f->xbuf_bytes = (size_t)bytes;
-    return 0;
-}
-
-extern "C" int cocons_shard_begin(cocons_fit *f, const double *theta, const double *mean, int rank, int world)
-{
-    if (int rc = fit_check(f)) return rc;
-    if (int rc = no_taper(f, "cocons_shard_begin")) return rc;
-    if (!theta || !mean || world < 1 || rank < 0 || rank >= world) return fail(-1, "cocons_shard_begin: bad argument");
-    if (f->r < 1) return fail(-1, "cocons_shard_begin: fit has no z");
-    f->rank = rank; f->world = world; f->nrhs_cur = f->r;
-    if (int rc = fit_alloc_matrix(f, f->r)) return rc;
-    if ((size_t)f->npad + f->rhs_act != shard_rows(f)) return fail(-1, "cocons_shard_begin: inconsistent right-hand-side rows");
-    if (f->xbuf[0] && f->xbuf_bytes < (size_t)cocons_shard_exchange_bytes(f))
-        return fail(-1, "cocons_shard_begin: exchange buffer too small");
-    if (!f->xbuf[0]) {
-        size_t bytes = (size_t)cocons_shard_exchange_bytes(f);
-        HIPCHK(hipMalloc(&f->xbuf[0], bytes));
-        HIPCHK(hipMalloc(&f->xbuf[1], bytes));
-        f->xbuf_bytes = bytes; f->xbuf_own = true;
-    }
-    if (int rc = reset_info(f)) return rc;
-    const int np = cocons_shard_num_panels(f);
-    // per-location vectors are replicated; each rank assembles only its own column panels
-    bool first = true;
-    for (int k = 0; k < np; ++k) {
-        if (shard_owner(k, world) != rank) continue;
-        int c0 = k * PT * TILE, c1 = c0 + PT * TILE;
-        if (c1 > f->npad) c1 = f->npad;
-        if (first) { assemble_sigma(f, theta, 0, c0, c1); first = false; }
-        else {
-            // loc params already on the device: pair kernel only
-            ModeSel ms = select_mode(theta, f->p, f->smooth_limits, 0);
-            PairArgs pa;
-            memset(&pa, 0, sizeof pa);
-            pa.n = f->n; pa.m = f->n; pa.rows = f->dloc; pa.cols = f->dloc;
-            pa.stride = f->npad; pa.stride_rows = f->npad; pa.out = f->dA; pa.ld = f->lda;
-            pa.nrows_out = f->npad; pa.ncols_out = c1; pa.bj0 = c0 / 64;
-            pa.gr = ms.gr; pa.nu_fixed = ms.nu_fixed;
-            launch_pair_sym(ms.mode, false, pa, f->stream);
+    P.nt = nt; P.mt = mt; P.world = world; P.group = group;
+    const int nb = (nt + PT - 1) / PT, T64 = 2 * mt;
+    P.tlo.assign(nb, 0); P.ncols.assign(nb, 0); P.srows.assign(nb, 0);
+    P.pmap.assign((size_t)nb * T64, -1); P.cnt.assign((size_t)nb * world, 0);
+    P.max_elems = 0;
+    for (int k = 0; k < nb; ++k) {
+        const int w = (nt - k * PT) < PT ? (nt - k * PT) : PT;
+        P.ncols[k] = w * TILE;
+        P.tlo[k] = 2 * (k * PT + w);
+        int *c = &P.cnt[(size_t)k * world];
+        for (int ti = P.tlo[k]; ti < T64; ++ti) c[((ti / 4) / group) % world]++;
+        int mx = 0;
+        for (int r = 0; r < world; ++r) mx = c[r] > mx ? c[r] : mx;
+        P.srows[k] = 64LL * mx;
+        std::vector<int> pos(world, 0);
+        for (int ti = P.tlo[k]; ti < T64; ++ti) {
+            const int o = ((ti / 4) / group) % world;
+            P.pmap[(size_t)k * T64 + ti] = (int)((long long)o * P.srows[k] * P.ncols[k] + 64LL * pos[o]++);
         }
-        assemble_rhs(f, mean, true, nullptr, 0, c0, c1);
+        const size_t el = (size_t)world * (size_t)P.srows[k] * (size_t)P.ncols[k];
+        if (el > P.max_elems) P.max_elems = el;
     }
-    HIPCHK(hipGetLastError());
-    return 0;
 }
 
-static inline size_t panel_rows(cocons_fit *f, int k) { return shard_rows(f) - (size_t)k * PT * TILE; }
+struct ShardState {
+    ShardPlan plan;
+    int *d_pmap = nullptr;
+    double *lkk[2] = {nullptr, nullptr};
+    hipEvent_t ev_main_L = nullptr, ev_comm_L[2] = {nullptr, nullptr}, ev_main_X[2] = {nullptr, nullptr},
+               ev_comm_X[2] = {nullptr, nullptr};
+};
 
-extern "C" int cocons_shard_panel_buffer(cocons_fit *f, int k, void **dev_ptr, long long *bytes)
+static void shard_state_free(ShardState *S)
 {
-    if (!f || k < 0 || k >= cocons_shard_num_panels(f)) return fail(-1, "cocons_shard_panel_buffer: bad argument");
-    int w = (f->nt - k * PT) < PT ? (f->nt - k * PT) : PT;
-    if (dev_ptr) *dev_ptr = f->xbuf[k & 1];
-    if (bytes) *bytes = (long long)(panel_rows(f, k) * (size_t)w * TILE * sizeof(double));
-    return 0;
-}
-
-extern "C" int cocons_shard_panel_factor(cocons_fit *f, int k)
-{
-    if (int rc = fit_check(f)) return rc;
-    const int np = cocons_shard_num_panels(f);
-    if (k < 0 || k >= np) return fail(-1, "cocons_shard_panel_factor: bad panel");
-    const int mt = f->nt + f->rhs_act / TILE;
-    const int t0 = k * PT;
-    hipStream_t s = f->stream;
-    double *A = f->dA;
-    if (k == 0) launch_front_identity(A, f->lda, f->pad0, mt * TILE, s);      // (see factorize; pad0 < 128: inside panel 0)
-    launch_potrf_tile(A, f->lda, t0 * TILE, f->dinv, f->dinfo, s);
-    launch_trsm_tile(A, f->lda, t0 * TILE, (t0 + 1) * TILE, mt * TILE, f->dinv, s);
-    int w = 1;
-    if (t0 + 1 < f->nt) {
-        w = 2;
-        launch_update(A, f->lda, t0 * TILE, TILE, t0 + 1, mt, t0 + 1, t0 + 2, true, s);
-        launch_potrf_tile(A, f->lda, (t0 + 1) * TILE, f->dinv + 8 * 256, f->dinfo, s);
-        launch_trsm_tile(A, f->lda, (t0 + 1) * TILE, (t0 + 2) * TILE, mt * TILE, f->dinv + 8 * 256, s);
+    if (!S) return;
+    hipFree(S->d_pmap); hipFree(S->lkk[0]); hipFree(S->lkk[1]);
+    if (S->ev_main_L) hipEventDestroy(S->ev_main_L);
+    for (int b = 0; b < 2; ++b) {
+        if (S->ev_comm_L[b]) hipEventDestroy(S->ev_comm_L[b]);
+        if (S->ev_main_X[b]) hipEventDestroy(S->ev_main_X[b]);
+        if (S->ev_comm_X[b]) hipEventDestroy(S->ev_comm_X[b]);
     }
-    // pack rows [t0*128, npad + rhs rows) of the panel's columns into the exchange buffer (ld = rows)
-    size_t rows = panel_rows(f, k);
-    if (rows * (size_t)w * TILE * sizeof(double) > f->xbuf_bytes || mt * TILE != (int)shard_rows(f))
-        return fail(-1, "cocons_shard_panel_factor: exchange buffer too small for this panel");
-    HIPCHK(hipMemcpy2DAsync(f->xbuf[k & 1], rows * sizeof(double),
-                            A + (size_t)t0 * TILE + (size_t)t0 * TILE * f->lda, f->lda * sizeof(double),
-                            rows * sizeof(double), (size_t)w * TILE, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipGetLastError());
-    return 0;
+    delete S;
 }
-
-// update the rank's OWN panels j in [j0, j1) (j > k) with the received panel k; j1 < 0 = all
-static int shard_apply_range(cocons_fit *f, int k, int j0, int j1)
-{
-    if (int rc = fit_check(f)) return rc;
-    const int np = cocons_shard_num_panels(f);
-    if (k < 0 || k >= np) return fail(-1, "cocons_shard_panel_apply: bad panel");
-    if (j1 < 0 || j1 > np) j1 = np;
-    if (j0 < k + 1) j0 = k + 1;
-    if (j0 >= j1) return 0;
-    const int mt = f->nt + f->rhs_act / TILE;
-    const int t0 = k * PT;
-    const int w = (f->nt - t0) < PT ? (f->nt - t0) : PT;
-    int c0 = j0 * PT, c1 = j1 * PT;               // tile-column range
-    if (c1 > f->nt) c1 = f->nt;
-    if (c0 >= c1) return 0;
-    size_t rows = panel_rows(f, k);
-    // operand pointer such that P[row + kk*rows] addresses GLOBAL row `row`
-    const double *P = f->xbuf[k & 1] - (size_t)t0 * TILE;
-    launch_update_from(f->dA, f->lda, P, rows, w * TILE, c0, mt, c0, c1, true, f->stream,
-                       PT * shard_group(), f->world, f->rank);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int cocons_shard_panel_apply(cocons_fit *f, int k) { return shard_apply_range(f, k, k + 1, -1); }
-
-extern "C" int cocons_shard_panel_apply_range(cocons_fit *f, int k, int j0, int j1)
-{
-    return shard_apply_range(f, k, j0, j1);
-}
-
-// partial[0] = sum over OWN columns of log(diag); partial[1 + a*r + b] = own-column part of the
-// Gram matrix of the rhs rows.  The caller sums the partials over ranks (all-reduce) and takes
-// the minimum of info (0x7f7f7f7f = ok).
-extern "C" int cocons_shard_finish(cocons_fit *f, double *partial, int *info)
-{
-    if (int rc = fit_check(f)) return rc;
-    const int np = cocons_shard_num_panels(f);
-    const int nr = f->nrhs_cur, len = 1 + nr * nr;
-    int cnt = 0;
-    for (int k = 0; k < np; ++k) {
-        if (shard_owner(k, f->world) != f->rank) continue;
-        int c0 = k * PT * TILE, c1 = c0 + PT * TILE;
-        if ((size_t)(cnt + 1) * len > f->out_cap) return fail(-1, "cocons_shard_finish: reduction buffer too small");
-        launch_finalize_cols(f->dA, f->lda, c0, c1, f->n, f->npad, nr, f->dout + (size_t)cnt * len, f->stream);
-        ++cnt;
-    }
-    if (cnt > 0)
-        HIPCHK(hipMemcpyAsync(f->hout, f->dout, (size_t)cnt * len * sizeof(double), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipStreamSynchronize(f->stream));
-    for (int i = 0; i < len; ++i) partial[i] = 0.0;
-    for (int c = 0; c < cnt; ++c)
-        for (int i = 0; i < len; ++i) partial[i] += f->hout[(size_t)c * len + i];
-    if (info) *info = *f->hinfo;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------
-// native sharded evaluation: the schedule of cocons_shard_* above, driven from inside the library, with
-// the panel broadcasts on a communication stream of their own.
-//
-// Per panel k (256 columns), exchange buffer b = k & 1:
-//   main stream M :  [owner] update + factor + pack panel k            -> record ev_main[b]
-//   comm stream C :  wait ev_main[b] ; broadcast buffer b from owner(k) -> record ev_comm[b]
-//   main stream M :  wait ev_comm[b] ; apply panel k to the own panels right of it
-// The owner of panel k+1 applies panel k to that panel FIRST, factors it and hands it to C before it applies
-// panel k to the rest, so the broadcast of k+1 travels while every rank is busy with the update of panel k
-// (two panels in flight; ev_main[b] also covers the last reader of buffer b, panel k-1's update).
-// Comm budget at n = 10^4: 40 panels, <= 20.7 MB each, 0.41 GB per evaluation.
 
 extern "C" int cocons_fit_world(cocons_fit *f) { return (f && f->coll_kind) ? f->coll_world : 1; }
 
+// buffers, plan and events of the sharded evaluation on this handle (world ranks)
+static int shard_prepare(cocons_fit *f, int rank, int world)
+{
+    f->rank = rank; f->world = world; f->nrhs_cur = f->r;
+    if (int rc = fit_alloc_matrix(f, f->r)) return rc;
+    const int mt = f->nt + f->rhs_act / TILE;
+    if (!f->shard) f->shard = new ShardState();
+    ShardState *S = f->shard;
+    if (S->plan.nt != f->nt || S->plan.mt != mt || S->plan.world != world || S->plan.group != shard_group()) {
+        HIPCHK(hipStreamSynchronize(f->stream));
+        if (f->cstream) HIPCHK(hipStreamSynchronize(f->cstream));
+        shard_make_plan(S->plan, f->nt, mt, world, shard_group());
+        if (S->d_pmap) { HIPCHK(hipFree(S->d_pmap)); S->d_pmap = nullptr; }
+        HIPCHK(hipMalloc(&S->d_pmap, S->plan.pmap.size() * sizeof(int)));
+        HIPCHK(hipMemcpyAsync(S->d_pmap, S->plan.pmap.data(), S->plan.pmap.size() * sizeof(int), hipMemcpyHostToDevice, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+        const size_t bytes = S->plan.max_elems * sizeof(double);
+        if (f->xbuf_bytes < bytes) {
+            if (f->xbuf_own) { hipFree(f->xbuf[0]); hipFree(f->xbuf[1]); }
+            f->xbuf[0] = f->xbuf[1] = nullptr;
+            HIPCHK(hipMalloc(&f->xbuf[0], bytes));
+            HIPCHK(hipMalloc(&f->xbuf[1], bytes));
+            HIPCHK(hipMemsetAsync(f->xbuf[0], 0, bytes, f->stream));      // (slot padding is exchanged too: no NaN patterns)
+            HIPCHK(hipMemsetAsync(f->xbuf[1], 0, bytes, f->stream));
+            f->xbuf_bytes = bytes; f->xbuf_own = true;
+        }
+    }
+    for (int b = 0; b < 2; ++b) {
+        if (!S->lkk[b]) HIPCHK(hipMalloc(&S->lkk[b], LKK_DOUBLES * sizeof(double)));
+        if (!S->ev_comm_L[b]) HIPCHK(hipEventCreateWithFlags(&S->ev_comm_L[b], hipEventDisableTiming));
+        if (!S->ev_main_X[b]) HIPCHK(hipEventCreateWithFlags(&S->ev_main_X[b], hipEventDisableTiming));
+        if (!S->ev_comm_X[b]) HIPCHK(hipEventCreateWithFlags(&S->ev_comm_X[b], hipEventDisableTiming));
+    }
+    if (!S->ev_main_L) HIPCHK(hipEventCreateWithFlags(&S->ev_main_L, hipEventDisableTiming));
+    return 0;
+}
+
+// assemble this rank's rows of Sigma (lower triangle) and, on their owner, the right-hand-side rows under the matrix
+static int shard_begin(cocons_fit *f, const double *theta, const double *mean, int rank, int world)
+{
+    if (int rc = no_taper(f, "sharded evaluation")) return rc;
+    if (f->r < 1) return fail(-1, "sharded evaluation: fit has no z");
+    if (int rc = shard_prepare(f, rank, world)) return rc;
+    if (int rc = reset_info(f)) return rc;
+    ThetaVecs tv;
+    make_theta_vecs(theta, f->p, tv);
+    ModeSel ms = select_mode(theta, f->p, f->smooth_limits, 0);
+    LocArgs la;
+    la.n = f->n; la.p = f->p; la.X = f->dX; la.ldx = f->n; la.locs = f->dlocs; la.ldl = f->n;
+    la.out = f->dloc; la.stride = f->npad; la.smooth_kind = ms.smooth_kind;
+    la.smooth_min = f->smooth_limits[0]; la.smooth_max = f->smooth_limits[1];
+    la.th = tv;
+    launch_loc_params(la, f->stream);                  // (replicated: O(n p))
+    PairArgs pa;
+    pa.n = f->n; pa.m = f->n; pa.rows = f->dloc; pa.cols = f->dloc;
+    pa.stride = f->npad; pa.stride_rows = f->npad; pa.out = f->dA; pa.ld = f->lda;
+    pa.nrows_out = f->npad; pa.ncols_out = f->npad;
+    pa.bj0 = f->pad0 / 64; pa.H = 0; pa.blocked = 0;
+    pa.gr = ms.gr; pa.nu_fixed = ms.nu_fixed;
+    pa.pad_diag = f->nslot > 0 ? 1e300 : 1.0;
+    pa.own_world = world; pa.own_rank = rank; pa.own_group = shard_group();
+    launch_pair_sym(ms.mode, false, pa, f->stream);
+    const int mt = f->nt + f->rhs_act / TILE;
+    if (shard_owner(f->nt / PT, world) == rank)         // the rows under the matrix belong to the block of tile row nt
+        assemble_rhs(f, mean, true, nullptr, 0, 0, f->npad);
+    launch_front_identity(f->dA, f->lda, f->pad0, mt * TILE, f->stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// the owner factors the diagonal block of block k in place and packs it (with the Q operands) for the broadcast
+static int shard_factor_diag(cocons_fit *f, int k)
+{
+    ShardState *S = f->shard;
+    const int t = k * PT, w = S->plan.ncols[k] / TILE;
+    hipStream_t s = f->stream;
+    double *A = f->dA, *q0 = f->dinv, *q1 = f->dinv + 2048;
+    launch_potrf_tile(A, f->lda, t * TILE, q0, f->dinfo, s);
+    if (w == 2) {
+        launch_trsm_tile(A, f->lda, t * TILE, (t + 1) * TILE, (t + 2) * TILE, q0, s);
+        launch_update(A, f->lda, t * TILE, TILE, t + 1, t + 2, t + 1, t + 2, true, s);
+        launch_potrf_tile(A, f->lda, (t + 1) * TILE, q1, f->dinfo, s);
+    }
+    double *L = S->lkk[k & 1];
+    HIPCHK(hipMemcpy2DAsync(L, (size_t)PT * TILE * sizeof(double), A + (size_t)t * TILE + (size_t)t * TILE * f->lda,
+                            f->lda * sizeof(double), (size_t)w * TILE * sizeof(double), (size_t)w * TILE,
+                            hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(L + (size_t)PT * TILE * PT * TILE, f->dinv, 2 * 2048 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipEventRecord(S->ev_main_L, s));
+    return 0;
+}
+
+// ---- collectives: RCCL on the communication stream, or the caller's transport ----
 static int coll_prepare(cocons_fit *f)
 {
     if (!f->cstream) HIPCHK(hipStreamCreateWithFlags(&f->cstream, hipStreamNonBlocking));
-    for (auto &e : f->ev_main) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : f->ev_comm) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (!f->dcoll) HIPCHK(hipMalloc(&f->dcoll, (size_t)(2 + (COCONS_P_MAX + f->r) * (COCONS_P_MAX + f->r)) * sizeof(double)));
     return 0;
 }
@@ -2532,54 +2543,132 @@ extern "C" int cocons_fit_set_collectives(cocons_fit *f, int rank, int world, co
     return coll_prepare(f);
 }
 
-static inline long long shard_panel_bytes(cocons_fit *f, int k)
+extern "C" int cocons_fit_set_allgather(cocons_fit *f, cocons_allgather_fn allgather)
 {
-    const int w = (f->nt - k * PT) < PT ? (f->nt - k * PT) : PT;
-    return (long long)(panel_rows(f, k) * (size_t)w * TILE * sizeof(double));
+    if (int rc = fit_check(f)) return rc;
+    if (f->coll_kind != 2) return fail(-1, "cocons_fit_set_allgather: call cocons_fit_set_collectives first");
+    f->cb_allgather = allgather;
+    return 0;
 }
 
-// hand panel k (already packed on the owner) to the communication stream
-static int coll_bcast_panel(cocons_fit *f, int k, bool in_group)
+// broadcast of L_kk (packed by shard_factor_diag on its owner) on the communication stream
+static int coll_bcast_L(cocons_fit *f, int k, bool in_group)
 {
+    ShardState *S = f->shard;
     const int b = k & 1, owner = shard_owner(k, f->coll_world);
-    const long long bytes = shard_panel_bytes(f, k);
-    HIPCHK(hipEventRecord(f->ev_main[b], f->stream));
-    HIPCHK(hipStreamWaitEvent(f->cstream, f->ev_main[b], 0));
+    // (a receiver needs no event: the buffer's last reader on the main stream, the unpack of L_(k-2), precedes the pack that the
+    // all-gather of step k-1 -- the operation in front of this one on the communication stream -- has waited for)
+    if (f->coll_rank == owner) HIPCHK(hipStreamWaitEvent(f->cstream, S->ev_main_L, 0));
     if (f->coll_kind == 1) {
         RcclApi *R = rccl_api();
-        NCCLCHK(R->Broadcast(f->xbuf[b], f->xbuf[b], (size_t)(bytes / 8), ncclDouble, owner, f->comm, f->cstream));
-        if (!in_group) HIPCHK(hipEventRecord(f->ev_comm[b], f->cstream));
+        NCCLCHK(R->Broadcast(S->lkk[b], S->lkk[b], LKK_DOUBLES, ncclDouble, owner, f->comm, f->cstream));
+        if (!in_group) HIPCHK(hipEventRecord(S->ev_comm_L[b], f->cstream));
     } else {
-        if (f->cb_bcast(f->cb_user, f->xbuf[b], bytes, owner, (void *)f->cstream) != 0)
+        if (f->cb_bcast(f->cb_user, S->lkk[b], (long long)(LKK_DOUBLES * sizeof(double)), owner, (void *)f->cstream) != 0)
             return fail(-6, "caller-provided broadcast failed");
-        HIPCHK(hipEventRecord(f->ev_comm[b], f->cstream));
+        HIPCHK(hipEventRecord(S->ev_comm_L[b], f->cstream));
     }
     return 0;
 }
 
-// one rank's part of schedule step k: everything between "panel k has arrived" and "panel k is applied".
-// The owner of panel k has the packed panel in its exchange buffer already: it does not wait for its own broadcast
-// to complete before it goes on -- only for the broadcast of panel k-1, whose buffer the next pack overwrites (the
-// local readers of that buffer are earlier work of the main stream).  So inside a group of consecutive panels of one
-// owner the broadcast of k travels while k+1 is being factored.
-static int shard_step_pre(cocons_fit *f, int k, int np)
+// all-gather of the solved rows of panel k: every rank's slot of the owner-packed buffer
+static int coll_allgather_X(cocons_fit *f, int k, bool in_group)
 {
-    const int W = f->coll_world;
-    if (f->coll_rank != shard_owner(k, W)) HIPCHK(hipStreamWaitEvent(f->stream, f->ev_comm[k & 1], 0));
-    else if (k >= 1) HIPCHK(hipStreamWaitEvent(f->stream, f->ev_comm[(k - 1) & 1], 0));
-    const int nxt = k + 1;
-    if (nxt < np && f->coll_rank == shard_owner(nxt, W)) {
-        if (int rc = shard_apply_range(f, k, nxt, nxt + 1)) return rc;      // only the columns of panel k+1 ...
-        if (int rc = cocons_shard_panel_factor(f, nxt)) return rc;          // ... factor and pack it
+    ShardState *S = f->shard;
+    const int b = k & 1;
+    const size_t cnt = (size_t)S->plan.srows[k] * (size_t)S->plan.ncols[k];
+    HIPCHK(hipStreamWaitEvent(f->cstream, S->ev_main_X[b], 0));
+    if (f->coll_kind == 1) {
+        RcclApi *R = rccl_api();
+        NCCLCHK(R->AllGather(f->xbuf[b] + (size_t)f->coll_rank * cnt, f->xbuf[b], cnt, ncclDouble, f->comm, f->cstream));
+        if (!in_group) HIPCHK(hipEventRecord(S->ev_comm_X[b], f->cstream));
+    } else {
+        if (!f->cb_allgather) return fail(-6, "caller-provided transport has no all-gather (cocons_fit_set_allgather)");
+        if (f->cb_allgather(f->cb_user, f->xbuf[b], (long long)(cnt * sizeof(double)), (void *)f->cstream) != 0)
+            return fail(-6, "caller-provided all-gather failed");
+        HIPCHK(hipEventRecord(S->ev_comm_X[b], f->cstream));
     }
     return 0;
 }
 
-static int shard_step_post(cocons_fit *f, int k, int np)
+// One rank's part of step k up to the exchange of the solved rows:
+//   L_kk in place (received: unpacked) | solve the own rows below | [owner of block k+1] diagonal block k+1 updated with
+//   its own rows, factored, packed | own rows packed into the gathered buffer
+static int shard_step_pre(cocons_fit *f, int k, int nb)
 {
-    const int nxt = k + 1;
-    if (nxt < np && f->coll_rank == shard_owner(nxt, f->coll_world)) return shard_apply_range(f, k, nxt + 1, -1);
-    return shard_apply_range(f, k, k + 1, -1);
+    ShardState *S = f->shard;
+    const ShardPlan &P = S->plan;
+    const int W = f->coll_world, rank = f->coll_rank, G = shard_group();
+    const int t = k * PT, w = P.ncols[k] / TILE, tn = t + w;           // tn: first tile below / right of the block
+    const int mt = P.mt;
+    hipStream_t s = f->stream;
+    double *A = f->dA;
+    if (rank != shard_owner(k, W)) {
+        HIPCHK(hipStreamWaitEvent(s, S->ev_comm_L[k & 1], 0));
+        const double *L = S->lkk[k & 1];
+        HIPCHK(hipMemcpy2DAsync(A + (size_t)t * TILE + (size_t)t * TILE * f->lda, f->lda * sizeof(double), L,
+                                (size_t)PT * TILE * sizeof(double), (size_t)w * TILE * sizeof(double), (size_t)w * TILE,
+                                hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(f->dinv, L + (size_t)PT * TILE * PT * TILE, 2 * 2048 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    if (tn >= mt) return 0;                                            // nothing below the block
+    if (P.cnt[(size_t)k * W + rank] > 0) {
+        launch_trsm_tile(A, f->lda, t * TILE, tn * TILE, mt * TILE, f->dinv, s, nullptr, nullptr, -1, 0, W, rank, G);
+        if (w == 2) {
+            launch_update_from(A, f->lda, A + (size_t)t * TILE * f->lda, f->lda, TILE, tn, mt, t + 1, t + 2, false, s, G, W, rank);
+            launch_trsm_tile(A, f->lda, (t + 1) * TILE, tn * TILE, mt * TILE, f->dinv + 2048, s, nullptr, nullptr, -1, 0, W, rank, G);
+        }
+    }
+    if (tn >= P.nt) return 0;                                          // last block: only right-hand-side rows below, no exchange
+    if (k + 1 < nb && rank == shard_owner(k + 1, W)) {
+        const int w1 = P.ncols[k + 1] / TILE;
+        launch_update(A, f->lda, t * TILE, w * TILE, tn, tn + w1, tn, tn + w1, true, s);     // own rows of X: local
+        if (int rc = shard_factor_diag(f, k + 1)) return rc;
+    }
+    const long long slot = (long long)P.srows[k] * P.ncols[k];
+    launch_pack_rows(A, f->lda, t * TILE, w * TILE, f->xbuf[k & 1], (size_t)P.srows[k], S->d_pmap + (size_t)k * 2 * mt, P.tlo[k],
+                     2 * mt, slot * rank, slot * (rank + 1), s);
+    HIPCHK(hipEventRecord(S->ev_main_X[k & 1], s));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ... and behind it: the own rows of the trailing matrix updated with the gathered panel
+static int shard_step_post(cocons_fit *f, int k, int nb)
+{
+    ShardState *S = f->shard;
+    const ShardPlan &P = S->plan;
+    const int W = f->coll_world, rank = f->coll_rank, G = shard_group();
+    const int t = k * PT, w = P.ncols[k] / TILE, tn = t + w;
+    if (tn >= P.nt) return 0;
+    HIPCHK(hipStreamWaitEvent(f->stream, S->ev_comm_X[k & 1], 0));
+    if (P.cnt[(size_t)k * W + rank] > 0) {
+        // (the owner of block k + 1 has updated that diagonal block with its own rows already: shard_step_pre)
+        const bool ahead = k + 1 < nb && rank == shard_owner(k + 1, W);
+        const int skip_lo = ahead ? 2 * tn : 0, skip_hi = ahead ? 2 * (tn + P.ncols[k + 1] / TILE) : 0;
+        launch_update_from(f->dA, f->lda, f->xbuf[k & 1], (size_t)P.srows[k], w * TILE, tn, P.mt, tn, P.nt, true, f->stream,
+                           G, W, rank, nullptr, -1, nullptr, nullptr, nullptr, -1, 0, 0, 0, 0,
+                           S->d_pmap + (size_t)k * 2 * P.mt, skip_lo, skip_hi);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// the reductions: the owner of the right-hand-side rows has L^-1 rhs in place and -- like everybody -- every L_kk
+static int shard_finish(cocons_fit *f, double *partial, int *info)
+{
+    const int nr = f->nrhs_cur, len = 1 + nr * nr;
+    for (int i = 0; i < len; ++i) partial[i] = 0.0;
+    const bool mine = shard_owner(f->nt / PT, f->coll_world) == f->coll_rank;
+    if (mine) {
+        launch_finalize(f->dA, f->lda, f->n, f->npad, nr, f->dout, f->stream);
+        HIPCHK(hipMemcpyAsync(f->hout, f->dout, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+    }
+    HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (mine) for (int i = 0; i < len; ++i) partial[i] = f->hout[i];
+    if (info) *info = *f->hinfo;
+    return 0;
 }
 
 static int sharded_eval_impl(cocons_fit *f, const double *theta, const double *mean, double *sum_logliks, double *parts);
@@ -2602,41 +2691,9 @@ static int sharded_eval(cocons_fit *f, const double *theta, const double *mean, 
     return rc;
 }
 
-static int sharded_eval_impl(cocons_fit *f, const double *theta, const double *mean, double *sum_logliks, double *parts)
+static int shard_collect(cocons_fit *f, std::vector<double> &part, double minfo, double *sum_logliks, double *parts)
 {
-    const int rank = f->coll_rank, world = f->coll_world;
-    if (int rc = cocons_shard_begin(f, theta, mean, rank, world)) return rc;
-    const int np = cocons_shard_num_panels(f);
-    if (rank == 0)
-        if (int rc = cocons_shard_panel_factor(f, 0)) return rc;
-    if (int rc = coll_bcast_panel(f, 0, false)) return rc;
-    for (int k = 0; k < np; ++k) {
-        if (int rc = shard_step_pre(f, k, np)) return rc;
-        if (k + 1 < np)
-            if (int rc = coll_bcast_panel(f, k + 1, false)) return rc;
-        if (int rc = shard_step_post(f, k, np)) return rc;
-    }
-    const int nr = f->r, len = 1 + nr * nr;
-    std::vector<double> part(len + 1);
-    int info = 0;
-    if (int rc = cocons_shard_finish(f, part.data(), &info)) return rc;
-    HIPCHK(hipStreamSynchronize(f->cstream));
-    double minfo = (double)info;                       // 0x7f7f7f7f = no failing minor (exact in a double)
-    if (world > 1) {
-        if (f->coll_kind == 1) {
-            RcclApi *R = rccl_api();
-            HIPCHK(hipMemcpyAsync(f->dcoll, part.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice, f->cstream));
-            HIPCHK(hipMemcpyAsync(f->dcoll + len, &minfo, sizeof(double), hipMemcpyHostToDevice, f->cstream));
-            NCCLCHK(R->AllReduce(f->dcoll, f->dcoll, (size_t)len, ncclDouble, ncclSum, f->comm, f->cstream));
-            NCCLCHK(R->AllReduce(f->dcoll + len, f->dcoll + len, 1, ncclDouble, ncclMin, f->comm, f->cstream));
-            HIPCHK(hipMemcpyAsync(part.data(), f->dcoll, (size_t)(len + 1) * sizeof(double), hipMemcpyDeviceToHost, f->cstream));
-            HIPCHK(hipStreamSynchronize(f->cstream));
-            minfo = part[len];
-        } else {
-            if (f->cb_allreduce(f->cb_user, part.data(), len, 0) != 0 || f->cb_allreduce(f->cb_user, &minfo, 1, 1) != 0)
-                return fail(-6, "caller-provided all-reduce failed");
-        }
-    }
+    const int nr = f->r;
     if (minfo != (double)0x7f7f7f7f) {
         int st = (int)minfo;
         st -= f->pad0;
@@ -2654,6 +2711,45 @@ static int sharded_eval_impl(cocons_fit *f, const double *theta, const double *m
     if (parts) parts[0] = part[0];
     *sum_logliks = total;
     return 0;
+}
+
+static int sharded_eval_impl(cocons_fit *f, const double *theta, const double *mean, double *sum_logliks, double *parts)
+{
+    const int rank = f->coll_rank, world = f->coll_world;
+    if (int rc = shard_begin(f, theta, mean, rank, world)) return rc;
+    const int nb = cocons_shard_num_blocks(f);
+    if (rank == shard_owner(0, world))
+        if (int rc = shard_factor_diag(f, 0)) return rc;
+    if (int rc = coll_bcast_L(f, 0, false)) return rc;
+    for (int k = 0; k < nb; ++k) {
+        if (int rc = shard_step_pre(f, k, nb)) return rc;
+        const bool exchange = k * PT + f->shard->plan.ncols[k] / TILE < f->nt;
+        if (exchange) if (int rc = coll_allgather_X(f, k, false)) return rc;
+        if (k + 1 < nb) if (int rc = coll_bcast_L(f, k + 1, false)) return rc;
+        if (int rc = shard_step_post(f, k, nb)) return rc;
+    }
+    const int nr = f->r, len = 1 + nr * nr;
+    std::vector<double> part(len + 1);
+    int info = 0;
+    if (int rc = shard_finish(f, part.data(), &info)) return rc;
+    HIPCHK(hipStreamSynchronize(f->cstream));
+    double minfo = (double)info;                       // 0x7f7f7f7f = no failing minor (exact in a double)
+    if (world > 1) {
+        if (f->coll_kind == 1) {
+            RcclApi *R = rccl_api();
+            HIPCHK(hipMemcpyAsync(f->dcoll, part.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice, f->cstream));
+            HIPCHK(hipMemcpyAsync(f->dcoll + len, &minfo, sizeof(double), hipMemcpyHostToDevice, f->cstream));
+            NCCLCHK(R->AllReduce(f->dcoll, f->dcoll, (size_t)len, ncclDouble, ncclSum, f->comm, f->cstream));
+            NCCLCHK(R->AllReduce(f->dcoll + len, f->dcoll + len, 1, ncclDouble, ncclMin, f->comm, f->cstream));
+            HIPCHK(hipMemcpyAsync(part.data(), f->dcoll, (size_t)(len + 1) * sizeof(double), hipMemcpyDeviceToHost, f->cstream));
+            HIPCHK(hipStreamSynchronize(f->cstream));
+            minfo = part[len];
+        } else {
+            if (f->cb_allreduce(f->cb_user, part.data(), len, 0) != 0 || f->cb_allreduce(f->cb_user, &minfo, 1, 1) != 0)
+                return fail(-6, "caller-provided all-reduce failed");
+        }
+    }
+    return shard_collect(f, part, minfo, sum_logliks, parts);
 }
 
 // ---- one process, several GPUs ---------------------------------------------------------------------
@@ -2719,31 +2815,43 @@ extern "C" int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *thet
     RcclApi *R = rccl_api();
     if (!R) return -1;
     const int W = m->ndev;
-    for (int d = 0; d < W; ++d)
-        if (int rc = cocons_shard_begin(m->fits[d], theta, mean, d, W)) return rc;
-    const int np = cocons_shard_num_panels(m->fits[0]);
-    auto group_bcast = [&](int k) -> int {
+    for (int d = 0; d < W; ++d) {
+        if (int rc = fit_check(m->fits[d])) return rc;
+        if (int rc = shard_begin(m->fits[d], theta, mean, d, W)) return rc;
+    }
+    const int nb = cocons_shard_num_blocks(m->fits[0]);
+    auto grouped = [&](int k, bool gather) -> int {
         NCCLCHK(R->GroupStart());
         for (int d = 0; d < W; ++d) {
             if (int rc = fit_check(m->fits[d])) return rc;
-            if (int rc = coll_bcast_panel(m->fits[d], k, true)) return rc;
+            if (int rc = gather ? coll_allgather_X(m->fits[d], k, true) : coll_bcast_L(m->fits[d], k, true)) return rc;
         }
         NCCLCHK(R->GroupEnd());
         for (int d = 0; d < W; ++d) {
             if (int rc = fit_check(m->fits[d])) return rc;
-            HIPCHK(hipEventRecord(m->fits[d]->ev_comm[k & 1], m->fits[d]->cstream));
+            ShardState *S = m->fits[d]->shard;
+            HIPCHK(hipEventRecord(gather ? S->ev_comm_X[k & 1] : S->ev_comm_L[k & 1], m->fits[d]->cstream));
         }
         return 0;
     };
-    if (int rc = cocons_shard_panel_factor(m->fits[0], 0)) return rc;
-    if (int rc = group_bcast(0)) return rc;
-    for (int k = 0; k < np; ++k) {
-        for (int d = 0; d < W; ++d)
-            if (int rc = shard_step_pre(m->fits[d], k, np)) return rc;
-        if (k + 1 < np)
-            if (int rc = group_bcast(k + 1)) return rc;
-        for (int d = 0; d < W; ++d)
-            if (int rc = shard_step_post(m->fits[d], k, np)) return rc;
+    {
+        cocons_fit *f0 = m->fits[shard_owner(0, W)];
+        if (int rc = fit_check(f0)) return rc;
+        if (int rc = shard_factor_diag(f0, 0)) return rc;
+    }
+    if (int rc = grouped(0, false)) return rc;
+    for (int k = 0; k < nb; ++k) {
+        for (int d = 0; d < W; ++d) {
+            if (int rc = fit_check(m->fits[d])) return rc;
+            if (int rc = shard_step_pre(m->fits[d], k, nb)) return rc;
+        }
+        const bool exchange = k * PT + m->fits[0]->shard->plan.ncols[k] / TILE < m->fits[0]->nt;
+        if (exchange) if (int rc = grouped(k, true)) return rc;
+        if (k + 1 < nb) if (int rc = grouped(k + 1, false)) return rc;
+        for (int d = 0; d < W; ++d) {
+            if (int rc = fit_check(m->fits[d])) return rc;
+            if (int rc = shard_step_post(m->fits[d], k, nb)) return rc;
+        }
     }
     cocons_fit *f0 = m->fits[0];
     const int nr = f0->r, len = 1 + nr * nr;
@@ -2751,26 +2859,13 @@ extern "C" int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *thet
     int info_min = 0x7f7f7f7f;
     for (int d = 0; d < W; ++d) {
         int info = 0;
-        if (int rc = cocons_shard_finish(m->fits[d], part.data(), &info)) return rc;
+        if (int rc = fit_check(m->fits[d])) return rc;
+        if (int rc = shard_finish(m->fits[d], part.data(), &info)) return rc;
         HIPCHK(hipStreamSynchronize(m->fits[d]->cstream));
         for (int i = 0; i < len; ++i) tot[i] += part[i];
         if (info < info_min) info_min = info;
     }
-    if (info_min != 0x7f7f7f7f) {
-        g_err = "leading minor not positive";
-        info_min -= f0->pad0;
-        if (info_min < 1) info_min = 1;
-        return info_min > f0->n_user ? f0->n_user : info_min;
-    }
-    double total = 0.0;
-    for (int c = 0; c < nr; ++c) {
-        const double quad = tot[1 + c * nr + c];
-        total += f0->n_user * LOG_2PI + 2 * tot[0] + quad;
-        if (parts) parts[1 + c] = quad;
-    }
-    if (parts) parts[0] = tot[0];
-    *sum_logliks = total;
-    return 0;
+    return shard_collect(f0, tot, (double)info_min, sum_logliks, parts);
 }
 
 // Dense kriging with the m prediction locations split over the devices of the handle (BASELINE config C5:

@@ -100,6 +100,8 @@ pair_sym_kernel(PairArgs a)
         bj = a.bj0 + j;
         bi = a.bj0 + j + (int)(L - c0);
     }
+    // sharded evaluation: a rank assembles the tile rows of its own 256-row blocks only
+    if (a.own_world > 1 && (((bi * TS) / (2 * TILE) / a.own_group) % a.own_world) != a.own_rank) return;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n = a.n;

@@ -653,12 +653,16 @@ engine_gate_kernel(unsigned *alive, unsigned *abort_word, unsigned code, unsigne
 // LDS holds the 36 lower 16x16 blocks of L and the 8 x 4 Q operands.
 __global__ void __launch_bounds__(256)
 trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsigned *wait_word, unsigned *abort_word,
-                 int nb1, int e0)
+                 int nb1, int e0, int own_world, int own_rank, int own_group)
 {
     __shared__ double SL[36 * 256];
     __shared__ double QS[8 * 256];
     __shared__ int ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (own_world > 1) {     // sharded evaluation: only the strips of this rank's 256-row blocks
+        const int row = (int)blockIdx.x < nb1 ? r0 + 64 * (int)blockIdx.x : e0 + 64 * ((int)blockIdx.x - nb1);
+        if (((row / (2 * TILE) / own_group) % own_world) != own_rank) return;
+    }
     if (wait_word) {     // the diagonal tile comes from the engine, which may still be at work
         if (tid == 0) ok = wait_ge(wait_word, 1u, abort_word, 0x300u + c0 / TILE) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -713,7 +717,12 @@ struct UpdArgs {
     unsigned *sig; int sig_tile;   // engine hand-off: workgroups inside the diagonal block (tiles sig_tile, sig_tile+1)
                                    // add 1 to sig[sig_tile] (tile (t,t)) or sig[sig_tile+1] (tiles (t+1,t), (t+1,t+1))
     unsigned *wait_word, *abort_word;  // engine hand-off: every workgroup first waits for *wait_word >= 1
-    int ptiles, world, rank;       // sharded path: only 128-tile columns whose panel (tj128 / ptiles) is owned
+    int ptiles, world, rank;       // sharded path (world > 1): only tiles whose ROW lies in an owned 256-row block: block b
+                                   // belongs to rank (b / ptiles) % world (ptiles = blocks per ownership group)
+    const int *pmap;               // sharded path: element offset of each 64-row tile's rows in P (owner-packed panel); null:
+                                   // the global row index
+    int skip_lo, skip_hi;          // sharded path: tiles with BOTH 64-row and 64-column index in [skip_lo, skip_hi) -- a diagonal
+                                   // block its owner has updated ahead of the exchange -- are not updated (empty range: none)
     unsigned *queue; unsigned ntiles;  // dynamic tile order (lower_only launches): shared counter, zero at launch; tiles in all
     int Hb, ext0;                  // rows: local tile rows < Hb count from ti0 (tj0 when lower_only), the others from ext0
                                    // (band-limited factorisation: band rows, then the right-hand-side rows)
@@ -803,7 +812,9 @@ update_kernel(UpdArgs a)
             ti = til < a.Hb ? a.ti0 + til : a.ext0 + (til - a.Hb);
             tj = a.tj0 + blockIdx.y;
         }
-        if (a.world > 1 && ((tj * TM / TILE / a.ptiles) % a.world) != a.rank) return;   // (static launches only)
+        // sharded path (static launches only): the rows of this rank's 256-row blocks, minus a diagonal block done ahead
+        if (a.world > 1 && ((ti * TM / (2 * TILE) / a.ptiles) % a.world) != a.rank) return;
+        if (ti >= a.skip_lo && ti < a.skip_hi && tj >= a.skip_lo && tj < a.skip_hi) return;
         // does this tile lie inside the diagonal block the engine is waiting for?
         const int sig_Ti = (ti * TM) / TILE - a.sig_tile, sig_Tj = (tj * TM) / TILE - a.sig_tile;
         const bool sig_wg = a.sig != nullptr && sig_Ti >= 0 && sig_Ti <= 1 && sig_Tj >= 0 && sig_Tj <= sig_Ti;
@@ -814,6 +825,7 @@ update_kernel(UpdArgs a)
 
         // rows: global, or -- packed band buffer -- local to the tile column they are read from / written to
         int rowI_P = ti * TM, rowJ_P = tj * TM, rowI_C = ti * TM;
+        if (a.pmap) { rowI_P = a.pmap[ti]; rowJ_P = a.pmap[tj]; }
         if (a.skew) {
             const bool ext = ti >= a.ext0;                          // a row under the matrix
             const int under = a.skew * TILE + (ti - a.ext0) * TM;
@@ -1381,6 +1393,31 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
     hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), shm, s, A, lda, c0, dinv, info);
 }
 
+__global__ void __launch_bounds__(64)
+raise_word_kernel(unsigned *word)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Can a kernel on stream `first` and a kernel launched AFTER it on stream `second` run at the same time?  HIP multiplexes
+// its streams onto a handful of hardware queues, and two streams that share one run strictly one kernel after the other:
+// a resident engine on one of them would then block the very kernels it waits for (seen in round 4: a synchronous copy on
+// the NULL stream shifted the assignment, and a handle's two streams landed on one queue).  A one-lane kernel on `first`
+// waits (bounded: 2 ms) for a word that a kernel on `second` raises; words[0] = the word, words[1] = 1 if the wait ran out.
+// Both streams must be idle; returns 1 (concurrent), 0 (serialised) or -1 (HIP error).
+int streams_run_concurrently(hipStream_t first, hipStream_t second, unsigned *words)
+{
+    if (hipMemsetAsync(words, 0, 2 * sizeof(unsigned), second) != hipSuccess) return -1;
+    if (hipStreamSynchronize(second) != hipSuccess) return -1;
+    hipLaunchKernelGGL(engine_gate_kernel, dim3(1), dim3(64), 0, first, words, words + 1, 1u, 200000ull);
+    hipLaunchKernelGGL(raise_word_kernel, dim3(1), dim3(64), 0, second, words);
+    unsigned h[2] = {0, 0};
+    if (hipStreamSynchronize(first) != hipSuccess || hipStreamSynchronize(second) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h, words, sizeof h, hipMemcpyDeviceToHost, second) != hipSuccess) return -1;
+    if (hipStreamSynchronize(second) != hipSuccess) return -1;
+    return h[1] == 0 ? 1 : 0;
+}
+
 void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile, bool patient)
 {
     // last_tile: not the start-up gate (is the engine resident? 5 ms, code 0x600) but the wait of the reductions for the
@@ -1430,7 +1467,8 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
 }
 
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
-                      unsigned *wait_word, unsigned *abort_word, int band_r1, int ext_r0)
+                      unsigned *wait_word, unsigned *abort_word, int band_r1, int ext_r0, int own_world, int own_rank,
+                      int own_group)
 {
     // rows [r0, r1), or -- band-limited -- [r0, band_r1) and [ext_r0, r1)
     int nb1 = ((band_r1 >= 0 ? band_r1 : r1) - r0) / 64, nb2 = band_r1 >= 0 ? (r1 - ext_r0) / 64 : 0;
@@ -1438,7 +1476,7 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
     if (nb2 < 0) nb2 = 0;
     if (nb1 + nb2 <= 0) return;
     hipLaunchKernelGGL(trsm_tile_kernel, dim3(nb1 + nb2), dim3(256), 0, s, A, lda, c0, r0, dinv, wait_word, abort_word,
-                       nb1, ext_r0);
+                       nb1, ext_r0, own_world, own_rank, own_group < 1 ? 1 : own_group);
 }
 
 // waves per workgroup of the trailing update (COCONS_UPD_WAVES: 4 or 8, see update_kernel's NW)
@@ -1453,7 +1491,7 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
                         int ptiles, int world, int rank, unsigned *sig, int sig_tile,
                         unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
-                        int skew, int kblk, int trim64)
+                        int skew, int kblk, int trim64, const int *pmap, int skip_lo, int skip_hi)
 {
     // tile rows [ti0, ti1), or -- band-limited -- [ti0, band_hi) and [ext0, ti1)
     const bool band = band_hi >= 0;
@@ -1471,7 +1509,7 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     a.Hb = 2 * rows_band; a.ext0 = 2 * ext0;
     a.C = A; a.ldc = lda; a.P = P; a.ldp = ldp; a.K = K;
     a.lower_only = lower_only ? 1 : 0;
-    a.ptiles = ptiles; a.world = world; a.rank = rank;
+    a.ptiles = ptiles < 1 ? 1 : ptiles; a.world = world; a.rank = rank; a.pmap = pmap; a.skip_lo = skip_lo; a.skip_hi = skip_hi;
     a.sig = sig; a.sig_tile = sig_tile;
     a.wait_word = wait_word; a.abort_word = abort_word;
     a.H = 0; a.W = 0;
@@ -1513,6 +1551,27 @@ void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int 
     if (trailing && use_w8 && a.lower_only) hipLaunchKernelGGL((update_kernel<64, 16, 0, 8>), grid, dim3(512), 0, s, a);
     else if (trailing) hipLaunchKernelGGL((update_kernel<64, 8, 0>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((update_kernel<64, 8, 1>), grid, dim3(256), 0, s, a);
+}
+
+// sharded evaluation: gather the solved rows this rank owns into its slot of the owner-packed panel buffer (see kernels.h)
+__global__ void __launch_bounds__(256)
+pack_rows_kernel(const double *A, size_t lda, int col0, int ncols, double *dst, size_t ldp, const int *pmap, int ti_lo,
+                 long long slot_lo, long long slot_hi)
+{
+    const int ti = ti_lo + (int)blockIdx.x;
+    const long long off = pmap[ti];
+    if (off < slot_lo || off >= slot_hi) return;           // another rank's rows
+    const int rho = threadIdx.x & 63, cq = threadIdx.x >> 6;
+    for (int c = 4 * (int)blockIdx.y + cq; c < ncols; c += 4 * (int)gridDim.y)
+        dst[off + rho + (size_t)c * ldp] = A[(size_t)(64 * ti + rho) + (size_t)(col0 + c) * lda];
+}
+
+void launch_pack_rows(const double *A, size_t lda, int col0, int ncols, double *dst, size_t ldp, const int *pmap, int ti_lo,
+                      int ti_hi, long long slot_lo, long long slot_hi, hipStream_t s)
+{
+    if (ti_hi <= ti_lo || ncols <= 0) return;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(ti_hi - ti_lo, 8), dim3(256), 0, s, A, lda, col0, ncols, dst, ldp, pmap, ti_lo,
+                       slot_lo, slot_hi);
 }
 
 // ---- the dependency-driven schedule: table of steps (host) and launch --------------------------------------------

@@ -52,6 +52,9 @@ struct PairArgs {
     double gr;             // global_range
     double nu_fixed;       // closed-form modes
     double pad_diag;       // sym: diagonal of the identity padding beyond n (0 = the default, 1.0)
+    // sym, sharded evaluation: only the tile ROWS of the 256-row blocks this rank owns are assembled -- block b belongs to
+    // rank (b / own_group) % own_world (own_world <= 1: every row)
+    int own_world = 0, own_rank = 0, own_group = 1;
 };
 
 struct RhsArgs {
@@ -127,11 +130,16 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
                          double *wbuf = nullptr, double *pbuf = nullptr, int dag_until = 0,
                          unsigned long long *trace = nullptr);
 void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false, bool patient = false);
+// 1: a kernel on `first` and a kernel launched behind it on `second` overlap (the streams sit on different hardware queues);
+// 0: they run one after the other; -1: HIP error.  words: two device words; both streams idle.
+int streams_run_concurrently(hipStream_t first, hipStream_t second, unsigned *words);
 // rows [r0, r1) x cols [c0, c0+128):  X <- X * L(c0)^{-T}, L read from A(c0,c0).
 // wait_word != NULL: the tile comes from the engine -- every workgroup first waits for *wait_word >= 1
 // band_r1 >= 0 (band-limited factorisation): rows [r0, band_r1) and [ext_r0, r1) instead of [r0, r1).
+// own_world > 1 (sharded evaluation): only the 64-row strips inside 256-row blocks b with (b / own_group) % own_world == own_rank
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
-                      unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, int band_r1 = -1, int ext_r0 = 0);
+                      unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, int band_r1 = -1, int ext_r0 = 0,
+                      int own_world = 0, int own_rank = 0, int own_group = 1);
 // C(i,j) -= sum_{k in [k0,k0+K)} A(i,k) A(j,k) for tiles with tile-row in [ti0,ti1),
 // tile-col in [tj0,tj1); lower_only keeps ti >= tj.  All tile indices in units of TILE.
 // sig / sig_tile: hand-off to the engine (sig = the in[] array, sig_tile = even tile of the diagonal block);
@@ -150,15 +158,22 @@ void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int t
 void set_update_waves(int nw);
 void set_update_w8_max_tiles(int ntiles);
 void set_update_c_wt(int on);           // (experiment) every C tile through L2-bypassing loads and write-through stores
-// like launch_update but the (i,k) and (j,k) operands come from a separate packed
-// panel buffer P (ldp rows, row index = global row), used by the sharded path.
-// (ptiles, world, rank): when world > 1 only tile columns tj with (tj / ptiles) % world == rank
-// are updated (block-cyclic panel ownership).
+// like launch_update but the (i,k) and (j,k) operands come from a separate panel buffer P, used by the sharded path:
+// world > 1: only the tiles whose ROW lies in a 256-row block b with (b / group) % world == rank are updated (row-block
+// ownership); pmap (device, one int per 64-row tile, may be null = global row index): element offset of that tile's rows in
+// P, whose columns are ldp apart -- the gathered panel is packed by owner (api.hip); [skip_lo, skip_hi): the tiles whose 64-row
+// AND 64-column index lie in that range -- a diagonal block its owner has updated ahead of the exchange -- are left out.
 void launch_update_from(double *A, size_t lda, const double *P, size_t ldp, int K,
                         int ti0, int ti1, int tj0, int tj1, bool lower_only, hipStream_t s,
-                        int ptiles, int world, int rank, unsigned *sig = nullptr, int sig_tile = -1,
+                        int group, int world, int rank, unsigned *sig = nullptr, int sig_tile = -1,
                         unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
-                        int band_hi = -1, int ext0 = 0, int skew = 0, int kblk = 0, int trim64 = 0);
+                        int band_hi = -1, int ext0 = 0, int skew = 0, int kblk = 0, int trim64 = 0,
+                        const int *pmap = nullptr, int skip_lo = 0, int skip_hi = 0);
+// sharded evaluation: the solved rows this rank owns of the 256-column panel at column col0 (ncols columns), gathered into
+// its slot of the owner-packed exchange buffer: for every 64-row tile ti in [ti_lo, ti_hi) with pmap[ti] inside the slot
+// [slot_lo, slot_hi): dst[pmap[ti] + rho + c * ldp] = A[(64 ti + rho) + (col0 + c) lda]
+void launch_pack_rows(const double *A, size_t lda, int col0, int ncols, double *dst, size_t ldp, const int *pmap, int ti_lo,
+                      int ti_hi, long long slot_lo, long long slot_hi, hipStream_t s);
 
 // ---- dependency-driven schedule (chol.hip: dag_kernel) -- ONE persistent launch for every trailing update and every
 // panel behind the first one.  DagStepHost mirrors the device record (see DagStep in chol.hip for the meaning).

@@ -1,34 +1,36 @@
-"""Column-panel sharded -2 log-likelihood across the GPUs of one node.
+"""Row-block sharded -2 log-likelihood across the GPUs of one node.
 
-The reference's `chol` (R/neg2loglikelihood.R:200) reads the upper triangle of Sigma row
-block by row block; those row blocks are the column panels of the lower factor kept on
-the device, so "Sigma row-block partitioned" = panels (256 columns) dealt block-cyclically
-over the ranks:
+The reference's `chol` (R/neg2loglikelihood.R:200) walks the upper triangle of Sigma row block by row block.
+Here Sigma is ROW-BLOCK partitioned: block b = rows 256 b .. 256 b + 255, dealt over the ranks in
+groups of G consecutive blocks, owner(b) = (b div G) mod world (COCONS_SHARD_GROUP, default 4).  A rank assembles,
+solves and updates ITS rows of every column:
 
-    for each panel k:
-        owner(k) = (k div G) mod world : factor the panel in place (potrf + panel solve), pack it   (groups of G
-                                          consecutive panels, COCONS_SHARD_GROUP, default 4)
-        broadcast the packed panel (<= 20.7 MB at n = 10^4) from its owner     <- the only collective
-        every rank: update its OWN panels right of k with the received panel    (MFMA fp64)
-    all-reduce of {sum log diag, Gram of the rhs rows} partial sums             (1 + r^2 doubles)
+    for each 256-column block k:
+        owner(k): factor the 256 x 256 diagonal block (every earlier update of its rows is local)
+        broadcast L_kk from owner(k)                                           <- 0.5 MB, on the chain
+        every rank: solve ITS rows of the panel, X = B L_kk^-T
+        owner(k+1): update its diagonal block (k+1,k+1) with its own rows of X, factor it, start its broadcast
+                    (the chain diagonal block -> diagonal block never waits for the bulk exchange)
+        all-gather of the solved rows, packed by owner                         <- B_k / world per rank
+        every rank: update ITS rows of the trailing matrix with the gathered panel   (MFMA fp64)
+    all-reduce of {sum log diag, Gram of the rhs rows} (1 + r^2 doubles) and of the failing minor
 
-The schedule, the RCCL broadcasts (on a communication stream of their own, two panels in
-flight) and the final all-reduce all live INSIDE the HIP library (`sharded_eval` in
-csrc/api.hip): once a fit has collectives, `cocons_neg2loglik_dense` on it is the sharded
-evaluation.  This module only wires a fit to its communicator:
+The schedule, the RCCL collectives (on a communication stream of their own) and the final all-reduce all live
+INSIDE the HIP library (`sharded_eval` in csrc/api.hip): once a fit has collectives, `cocons_neg2loglik_dense`
+on it is the sharded evaluation.  This module only wires a fit to its communicator:
 
   * `ShardedFit.init_rccl(dist)`    one process per GPU: rank 0 draws the RCCL unique id
     (`cocons_comm_unique_id`), the 128 bytes travel over the host's process group
     (torch.distributed here; R would use its own socket/MPI), every rank calls
     `cocons_fit_comm_init`.  torch carries no panel, no reduction, no stream.
   * `ShardedFit.init_host_transport(dist)`   tests: several ranks share ONE GPU, which RCCL refuses;
-    the library's broadcast / all-reduce hooks (`cocons_fit_set_collectives`) are served by
-    gloo through host memory.  Same native schedule, different wire.
+    the library's broadcast / all-gather / all-reduce hooks (`cocons_fit_set_collectives`,
+    `cocons_fit_set_allgather`) are served by gloo through host memory.  Same native schedule, different wire.
   * `MultiFit`   one process, several GPUs (`cocons_multi_*`, ncclCommInitAll).
 
 `sharded_neg2loglik_core(engine, ...)` further down is the same schedule in Python over an abstract
 engine: the CPU tests run it over gloo with a numpy engine (tests/np_shard_engine.py), which pins the
-schedule's logic (ownership, look-ahead order, buffer alternation) where no GPU exists.
+schedule's logic (ownership, look-ahead order, owner-packed exchange) where no GPU exists.
 """
 from __future__ import annotations
 
@@ -126,11 +128,29 @@ class ShardedFit(CoconsFit):
             except Exception:                                   # noqa: BLE001
                 return 9
 
-        cb_b, cb_a = _lib.BCAST_FN(bcast), _lib.ALLREDUCE_FN(allreduce)
-        self._keep += [cb_b, cb_a]
+        def allgather(user, dev_ptr, nbytes, stream):
+            # dev_ptr: `world` slots of nbytes; slot `rank` is this rank's contribution, every other slot is filled here
+            try:
+                if hip.hipStreamSynchronize(stream) != 0:
+                    return 1
+                mine = np.empty(nbytes // 8, dtype=np.float64)
+                if hip.hipMemcpy(mine.ctypes.data, dev_ptr + rank * nbytes, nbytes, D2H) != 0:
+                    return 2
+                parts = [torch.empty(nbytes // 8, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(parts, torch.from_numpy(mine), group=group)
+                for r in range(world):
+                    if r != rank and hip.hipMemcpy(dev_ptr + r * nbytes, parts[r].numpy().ctypes.data, nbytes, H2D) != 0:
+                        return 3
+                return 0
+            except Exception:                                   # noqa: BLE001
+                return 9
+
+        cb_b, cb_a, cb_g = _lib.BCAST_FN(bcast), _lib.ALLREDUCE_FN(allreduce), _lib.ALLGATHER_FN(allgather)
+        self._keep += [cb_b, cb_a, cb_g]
         _lib.check(self._L.cocons_fit_set_collectives(self._h, rank, world, ctypes.cast(cb_b, ctypes.c_void_p),
                                                       ctypes.cast(cb_a, ctypes.c_void_p), None),
                    "cocons_fit_set_collectives")
+        _lib.check(self._L.cocons_fit_set_allgather(self._h, ctypes.cast(cb_g, ctypes.c_void_p)), "cocons_fit_set_allgather")
 
 
 class MultiFit:
@@ -204,46 +224,54 @@ class MultiFit:
 
 
 def sharded_neg2loglik_core(engine, theta_list, dist, rank, world, group=None, lookahead=True):
-    """The sharded schedule over an abstract engine (begin / panel_factor / panel_tensor / panel_apply /
-    finish): the Python twin of `sharded_eval` in csrc/api.hip, run by the CPU tests with a numpy engine.
-    Returns (sum_logliks, parts), identical on every rank; raises CholeskyError on every rank if any
-    panel failed.
+    """The row-block sharded schedule over an abstract engine: the Python twin of `sharded_eval` in csrc/api.hip, run by
+    the CPU tests with a numpy engine.  Engine interface: begin / num_blocks / owner / factor_diag / diag_tensor /
+    set_diag / solve / ahead / exchanges / pack / set_gathered / update / finish / make_tensor.
+    Returns (sum_logliks, parts), identical on every rank; raises CholeskyError on every rank if any pivot failed.
 
-    Look-ahead: the owner of panel k+1 updates and factors that panel FIRST and starts its
-    broadcast asynchronously; every rank then applies panel k to the rest of its panels while
-    the broadcast of k+1 is in flight (the exchange buffers alternate, so the receive of k+1
-    never touches the buffer panel k is being read from)."""
+    Look-ahead (the library's order): the owner of block k+1 updates its diagonal block with its OWN solved rows and
+    factors it before the bulk exchange of step k, and the broadcast of L_(k+1,k+1) is issued right behind the all-gather
+    of step k -- the chain of diagonal blocks never waits for a trailing update.  lookahead=False: every step in plain
+    order (factor | broadcast | solve | all-gather | update), the same arithmetic."""
     engine.begin(theta_list, rank, world)
-    npan = engine.num_panels()
-    owner_of = getattr(engine, "owner", None) or (lambda k: k % world)
-    if world == 1:
-        for k in range(npan):
-            engine.panel_factor(k)
-            engine.panel_apply(k)
-    elif not lookahead:
-        for k in range(npan):
-            owner = owner_of(k)
-            if rank == owner:
-                engine.panel_factor(k)
-            dist.broadcast(engine.panel_tensor(k), src=owner, group=group)
-            engine.panel_apply(k)
-    else:
-        if rank == 0:
-            engine.panel_factor(0)
-        work = dist.broadcast(engine.panel_tensor(0), src=0, group=group, async_op=True)
-        for k in range(npan):
-            work.wait()                                   # panel k is in its exchange buffer
-            nxt = k + 1
-            if nxt < npan:
-                if rank == owner_of(nxt):
-                    engine.panel_apply(k, nxt, nxt + 1)   # only the columns of panel k+1 ...
-                    engine.panel_factor(nxt)              # ... factor it ...
-                # ... and put it on the wire while everybody applies panel k to the rest
-                work = dist.broadcast(engine.panel_tensor(nxt), src=owner_of(nxt), group=group, async_op=True)
-                if rank == owner_of(nxt):
-                    engine.panel_apply(k, nxt + 1, None)
-                else:
-                    engine.panel_apply(k)
+    nb = engine.num_blocks()
+    owner_of = engine.owner
+
+    def bcast_diag(k):
+        if world > 1:
+            dist.broadcast(engine.diag_tensor(k), src=owner_of(k), group=group)
+        if rank != owner_of(k):
+            engine.set_diag(k)
+
+    def gather(k):
+        mine = engine.pack(k)
+        if world > 1:
+            parts = [mine.new_empty(mine.shape) for _ in range(world)]
+            dist.all_gather(parts, mine, group=group)
+        else:
+            parts = [mine]
+        engine.set_gathered(k, parts)
+
+    if rank == owner_of(0):
+        engine.factor_diag(0)
+    if lookahead:
+        bcast_diag(0)
+    for k in range(nb):
+        if not lookahead:
+            if k > 0 and rank == owner_of(k):
+                engine.factor_diag(k)
+            bcast_diag(k)
+        engine.solve(k)                                   # this rank's rows below block k
+        ahead = lookahead and k + 1 < nb and engine.exchanges(k)
+        if ahead and rank == owner_of(k + 1):
+            engine.ahead(k + 1)                           # own rows of X: local
+            engine.factor_diag(k + 1)
+        if engine.exchanges(k):
+            gather(k)
+        if lookahead and k + 1 < nb:
+            bcast_diag(k + 1)
+        if engine.exchanges(k):
+            engine.update(k, skip_diag=(k + 1 if (ahead and rank == owner_of(k + 1)) else None))
     part, info = engine.finish()
     if world > 1:
         t = engine.make_tensor(np.concatenate([part, [-float(info)]]))

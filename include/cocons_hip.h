@@ -239,6 +239,11 @@ typedef int (*cocons_bcast_fn)(void *user, void *dev_ptr, long long bytes, int r
 typedef int (*cocons_allreduce_fn)(void *user, double *host_inout, int count, int op);
 int cocons_fit_set_collectives(cocons_fit *fit, int rank, int world, cocons_bcast_fn bcast,
                                cocons_allreduce_fn allreduce, void *user);
+/* ... and the all-gather of the sharded evaluation: dev_buf holds `world` slots of bytes_per_rank bytes, slot r is
+ * rank r's contribution (already in place on rank r); on return every slot is filled on every rank.  `stream`: the
+ * stream the library has ordered the buffer's producer on (synchronise it, or enqueue behind it).  0 = ok.        */
+typedef int (*cocons_allgather_fn)(void *user, void *dev_buf, long long bytes_per_rank, void *stream);
+int cocons_fit_set_allgather(cocons_fit *fit, cocons_allgather_fn allgather);
 /* number of ranks the fit is sharded over (1 = not sharded) */
 int cocons_fit_world(cocons_fit *fit);
 
@@ -269,35 +274,14 @@ int cocons_multi_comm_ranks(cocons_multi *m, int *ndev, int *rccl_count);
  * them for every rank.                                                                                            */
 int cocons_fit_comm_info(cocons_fit *fit, int *count, int *user_rank, int *device);
 
-/* ---- column-panel sharded evaluation, step by step (the building blocks of the above; kept public for
- * callers that bring their own schedule, and used by the CPU tests of the schedule) --------------------
- * column-panel sharded evaluation across GPUs (one process per GPU) ---------
- * The reference's chol reads the UPPER triangle of Sigma row by row; its row
- * blocks are exactly the column panels of the lower factor kept here.  Panels
- * are dealt block-cyclically over `world` ranks; the caller (torch.distributed
- * over RCCL, see cocons_amd/shard.py) broadcasts each factored panel.
- *   shard_begin : assemble the rank's own panels for this theta
- *   shard_panel_factor(k) : owner only -- factor panel k in place (needs all
- *                  updates from panels < k applied), pack it into the exchange buffer
- *   shard_panel_buffer : device pointer + bytes of the exchange buffer for panel k
- *   shard_panel_apply(k) : every rank, after the broadcast -- update own panels > k
- *   shard_finish : local partial sums (logdet_half, Gram of the rhs rows) -> host  */
-int cocons_shard_begin(cocons_fit *fit, const double *theta, const double *mean,
-                       int rank, int world);
-int cocons_shard_panel_factor(cocons_fit *fit, int k);
-int cocons_shard_panel_buffer(cocons_fit *fit, int k, void **dev_ptr, long long *bytes);
-int cocons_shard_panel_apply(cocons_fit *fit, int k);
-/* same, restricted to the rank's own panels j in [j0, j1) (j1 < 0: to the end) -- lets the
- * owner of panel k+1 update and factor it first (look-ahead) and apply the rest afterwards */
-int cocons_shard_panel_apply_range(cocons_fit *fit, int k, int j0, int j1);
-int cocons_shard_finish(cocons_fit *fit, double *partial /* 1 + (r)(r) */, int *info);
-int cocons_shard_num_panels(cocons_fit *fit);
-/* rank that owns panel k among `world` ranks: (k / G) % world, G = COCONS_SHARD_GROUP (default 4) consecutive panels */
-int cocons_shard_panel_owner(int k, int world);
-/* bytes one exchange buffer must hold; optionally hand in two caller-owned device
- * buffers (e.g. torch tensors, so torch.distributed can broadcast them in place) */
-long long cocons_shard_exchange_bytes(cocons_fit *fit);
-int cocons_shard_set_exchange(cocons_fit *fit, void *buf0, void *buf1, long long bytes);
+/* ---- how the sharded evaluation deals the matrix (no GPU call) ----------------------------------------
+ * Sigma is ROW-BLOCK partitioned: block b = rows 256 b ... 256 b + 255 (the reference's chol walks the upper
+ * triangle row block by row block, R/neg2loglikelihood.R:200); blocks are dealt in groups of G consecutive
+ * blocks, owner(b) = (b / G) mod world (COCONS_SHARD_GROUP, default 4).  Per block: its owner factors the
+ * 256 x 256 diagonal block and broadcasts it (0.5 MB), every rank solves ITS rows of the panel, the solved
+ * rows are all-gathered, every rank updates its rows.                              */
+int cocons_shard_block_owner(int b, int world);
+int cocons_shard_num_blocks(cocons_fit *fit);
 /* HIP stream the fit launches on (hipStream_t as void*), so the caller can order
  * collectives against it. */
 void *cocons_fit_stream(cocons_fit *fit);

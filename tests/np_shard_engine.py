@@ -1,9 +1,8 @@
 """TEST DOUBLE (not product code): a numpy implementation of the engine interface that
-cocons_amd.shard.sharded_neg2loglik_core drives, with the same storage conventions as the
-HIP engine (column-major lower factor, 128-tiles, 256-column panels dealt over the ranks in groups of `group`,
-rhs rows under the matrix, packed exchange buffers).  Lets the N>1 schedule and its
-collectives run over gloo on CPU.  Panels a rank does not own are filled with NaN, so any
-use of data that was never broadcast shows up in the result."""
+cocons_amd.shard.sharded_neg2loglik_core drives, with the same storage conventions as the HIP path (column-major lower
+factor, 128-tiles, 256-row blocks dealt over the ranks in groups of `group`, rhs rows under the matrix, the solved rows
+exchanged in an owner-packed buffer with 64-row tiles).  Lets the N > 1 schedule and its collectives run over gloo on CPU.
+Rows a rank does not own are filled with NaN, so any use of data that was never exchanged shows up in the result."""
 import numpy as np
 import torch
 
@@ -20,85 +19,126 @@ class NumpyShardEngine:
         self.sl = smooth_limits
         self.npad = (self.n + TILE - 1) // TILE * TILE
         self.nt = self.npad // TILE
-        self.lda = self.npad + TILE
-        self.xbuf = [torch.zeros(self.lda * PT * TILE, dtype=torch.float64) for _ in range(2)]
+        self.mt = self.nt + 1                       # one tile row of right-hand sides under the matrix
+        self.lda = self.mt * TILE
         self.info = 0x7F7F7F7F
 
-    def num_panels(self):
+    def num_blocks(self):
         return (self.nt + PT - 1) // PT
 
-    def owner(self, k):
-        """(k div G) mod world: csrc/api.hip shard_owner."""
-        return (k // self.group) % self.world
+    def owner(self, b):
+        """(b div G) mod world: csrc/api.hip shard_owner."""
+        return (b // self.group) % self.world
+
+    def _owner64(self, ti):
+        return self.owner(ti // 4)
 
     def _cols(self, k):
         c0 = k * PT * TILE
         return c0, min(c0 + PT * TILE, self.npad)
 
+    def exchanges(self, k):
+        """Is there a trailing matrix right of block k (otherwise only right-hand-side rows lie below: no exchange)."""
+        return self._cols(k)[1] < self.npad
+
+    def _own_tiles(self, k, rank=None):
+        rank = self.rank if rank is None else rank
+        c1 = self._cols(k)[1]
+        return [ti for ti in range(c1 // 64, 2 * self.mt) if self._owner64(ti) == rank]
+
     def begin(self, theta_list, rank, world):
         self.rank, self.world = rank, world
-        S = self.O.cov_rns(theta_list, self.locs, self.X, self.sl)
+        S = np.tril(self.O.cov_rns(theta_list, self.locs, self.X, self.sl))
         A = np.full((self.lda, self.npad), np.nan)
         resid = self.z - (self.X @ np.asarray(theta_list["mean"], float))[:, None]
-        for k in range(self.num_panels()):
-            if self.owner(k) != rank:
-                continue
-            c0, c1 = self._cols(k)
-            A[:, c0:c1] = 0.0
-            hi = min(c1, self.n)
-            if hi > c0:
-                A[: self.n, c0:hi] = np.tril(S)[:, c0:hi]
-                A[self.npad: self.npad + self.r, c0:hi] = resid[c0:hi].T
-            for c in range(max(c0, self.n), c1):
-                A[c, c] = 1.0
+        full = np.zeros((self.lda, self.npad))
+        full[: self.n, : self.n] = S
+        for c in range(self.n, self.npad):
+            full[c, c] = 1.0
+        full[self.npad: self.npad + self.r, : self.n] = resid.T
+        for ti in range(2 * self.mt):
+            if self._owner64(ti) == rank:
+                A[64 * ti: 64 * ti + 64] = full[64 * ti: 64 * ti + 64]
         self.A = A
+        self.L = {}
 
-    def panel_factor(self, k):
+    def factor_diag(self, k):
         c0, c1 = self._cols(k)
-        A = self.A
-        blk = np.tril(A[c0:c1, c0:c1])
+        blk = np.tril(self.A[c0:c1, c0:c1])
         blk = blk + np.tril(blk, -1).T
         try:
             L = np.linalg.cholesky(blk)
         except np.linalg.LinAlgError:
             self.info = min(self.info, c0 + 1)
             L = np.eye(c1 - c0)
-        A[c0:c1, c0:c1] = L
+        self.A[c0:c1, c0:c1] = L
+        self.L[k] = torch.from_numpy(np.ascontiguousarray(L))
+
+    def diag_tensor(self, k):
+        c0, c1 = self._cols(k)
+        if k not in self.L:
+            self.L[k] = torch.full((c1 - c0, c1 - c0), float("nan"), dtype=torch.float64)
+        return self.L[k]
+
+    def set_diag(self, k):
+        c0, c1 = self._cols(k)
+        self.A[c0:c1, c0:c1] = self.L[k].numpy()
+
+    def solve(self, k):
         from scipy.linalg import solve_triangular
-        A[c1:, c0:c1] = solve_triangular(L, A[c1:, c0:c1].T, lower=True).T
-        rows = self.lda - c0
-        self.xbuf[k & 1][: rows * (c1 - c0)] = torch.from_numpy(
-            np.asfortranarray(A[c0:, c0:c1]).ravel(order="F").copy())
-
-    def panel_tensor(self, k):
         c0, c1 = self._cols(k)
-        return self.xbuf[k & 1][: (self.lda - c0) * (c1 - c0)]
+        L = self.L[k].numpy()
+        for ti in self._own_tiles(k):
+            r0 = 64 * ti
+            self.A[r0:r0 + 64, c0:c1] = solve_triangular(L, self.A[r0:r0 + 64, c0:c1].T, lower=True).T
 
-    def panel_apply(self, k, j0=None, j1=None):
+    def ahead(self, j):
+        """Owner of block j: its diagonal block updated with its OWN solved rows of panel j - 1."""
+        c0, c1 = self._cols(j - 1)
+        d0, d1 = self._cols(j)
+        Xo = self.A[d0:d1, c0:c1]
+        self.A[d0:d1, d0:d1] -= Xo @ Xo.T
+
+    def _slot_rows(self, k):
+        return 64 * max(len(self._own_tiles(k, r)) for r in range(self.world))
+
+    def pack(self, k):
         c0, c1 = self._cols(k)
-        rows = self.lda - c0
-        P = self.panel_tensor(k).numpy().reshape((rows, c1 - c0), order="F")
-        j0 = k + 1 if j0 is None else max(j0, k + 1)
-        j1 = self.num_panels() if (j1 is None or j1 < 0) else min(j1, self.num_panels())
-        for j in range(j0, j1):
-            if self.owner(j) != self.rank:
+        out = np.zeros((self._slot_rows(k), c1 - c0))
+        for pos, ti in enumerate(self._own_tiles(k)):
+            out[64 * pos: 64 * pos + 64] = self.A[64 * ti: 64 * ti + 64, c0:c1]
+        return torch.from_numpy(out)
+
+    def set_gathered(self, k, parts):
+        c0, c1 = self._cols(k)
+        P = np.full((self.lda, c1 - c0), np.nan)
+        for r in range(self.world):
+            slot = parts[r].numpy()
+            for pos, ti in enumerate(self._own_tiles(k, r)):
+                P[64 * ti: 64 * ti + 64] = slot[64 * pos: 64 * pos + 64]
+        self.P = P
+
+    def update(self, k, skip_diag=None):
+        c0, c1 = self._cols(k)
+        for ti in self._own_tiles(k):
+            r0 = 64 * ti
+            ce = min(r0 + 64, self.npad)                  # columns up to the tile's own diagonal
+            if ce <= c1:
                 continue
-            d0, d1 = self._cols(j)
-            # rows >= d0 of own panel j:  C -= P(rows) P(cols d0:d1)^T
-            self.A[d0:, d0:d1] -= P[d0 - c0:, :] @ P[d0 - c0: d1 - c0, :].T
+            cols = np.arange(c1, ce)
+            if skip_diag is not None:
+                d0, d1 = self._cols(skip_diag)
+                if d0 <= r0 < d1:                         # a row of that diagonal block proper (not a right-hand-side row)
+                    cols = cols[(cols < d0) | (cols >= d1)]
+            if cols.size:
+                self.A[r0:r0 + 64, cols] -= self.P[r0:r0 + 64] @ self.P[cols].T
 
     def finish(self):
         part = np.zeros(1 + self.r * self.r)
-        for k in range(self.num_panels()):
-            if self.owner(k) != self.rank:
-                continue
-            c0, c1 = self._cols(k)
-            hi = min(c1, self.n)
-            if hi <= c0:
-                continue
-            part[0] += np.sum(np.log(np.diag(self.A)[c0:hi]))
-            Y = self.A[self.npad: self.npad + self.r, c0:hi]
-            part[1:] += (Y @ Y.T).ravel()
+        if self._owner64(2 * self.nt) == self.rank:       # the rank that owns the right-hand-side rows has every L_kk too
+            part[0] = np.sum(np.log(np.diag(self.A)[: self.n]))
+            Y = self.A[self.npad: self.npad + self.r, : self.n]
+            part[1:] = (Y @ Y.T).ravel()
         return part, self.info
 
     def make_tensor(self, arr):

@@ -119,14 +119,15 @@ def test_glue_compiles_against_declared_apis():
     assert r.returncode == 0, r.stderr[-4000:]
 
 
-def test_panel_ownership_deal_matches_the_python_twin():
-    """cocons_shard_panel_owner (no GPU call): panels are dealt in groups of COCONS_SHARD_GROUP consecutive panels
-    (default 4), owner(k) = (k div G) mod world -- the same deal the gloo twin's numpy engine uses (tests/np_shard_engine.py)."""
+def test_block_ownership_deal_matches_the_python_twin():
+    """cocons_shard_block_owner (no GPU call): the 256-row blocks of Sigma are dealt in groups of COCONS_SHARD_GROUP
+    consecutive blocks (default 4), owner(b) = (b div G) mod world -- the same deal the gloo twin's numpy engine uses
+    (tests/np_shard_engine.py)."""
     from cocons_amd import _lib
     lib = _lib.load()
     g = int(os.environ.get("COCONS_SHARD_GROUP", "4"))
     for world in (1, 2, 3, 8):
-        owners = [lib.cocons_shard_panel_owner(k, world) for k in range(40)]
-        assert owners == [(k // g) % world for k in range(40)]
+        owners = [lib.cocons_shard_block_owner(b, world) for b in range(40)]
+        assert owners == [(b // g) % world for b in range(40)]
         assert all(0 <= o < world for o in owners)
-    assert lib.cocons_shard_panel_owner(-1, 2) == -1 and lib.cocons_shard_panel_owner(0, 0) == -1
+    assert lib.cocons_shard_block_owner(-1, 2) == -1 and lib.cocons_shard_block_owner(0, 0) == -1

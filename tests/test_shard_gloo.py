@@ -47,8 +47,8 @@ def _worker(rank, world, port, n, seed, out_dir, lookahead=True, group=1):
 @pytest.mark.parametrize("world,n,lookahead,group", [(2, 700, True, 1), (3, 900, True, 1), (2, 200, True, 1),
                                                         (2, 700, False, 1), (4, 1300, True, 1), (4, 200, True, 1),
                                                         (3, 100, False, 1),
-                                                        # panels dealt in groups of consecutive panels (the library's
-                                                        # default deal): 6 panels over 4 ranks in pairs leaves a rank idle
+                                                        # blocks dealt in groups of consecutive blocks (the library's
+                                                        # default deal): 6 blocks over 4 ranks in pairs leaves a rank idle
                                                         (2, 1300, True, 2), (4, 1300, True, 2), (3, 900, False, 3)])
 def test_sharded_schedule_over_gloo(oracle, tmp_path, world, n, lookahead, group):
     import torch.multiprocessing as mp
