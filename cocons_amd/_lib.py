@@ -81,6 +81,7 @@ SIGNATURES = {
     "cocons_shard_block_owner": (c_int, [c_int, c_int]),
     "cocons_shard_num_blocks": (c_int, [c_vp]),
     "cocons_fit_set_allgather": (c_int, [c_vp, c_vp]),
+    "cocons_fit_same_data": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "cocons_fit_stream": (c_vp, [c_vp]),
     "cocons_fit_set_stream": (c_int, [c_vp, c_vp]),
     "cocons_fit_sync": (c_int, [c_vp]),

@@ -308,7 +308,7 @@ struct cocons_fit {
     double *dcoll;                // device staging of the final all-reduce (RCCL)
     double upd_flops;             // algorithmic flops of the event-timed trailing updates (profile runs)
     // host copies of the inputs + lazily created clones: the slots of cocons_neg2loglik_batch
-    std::vector<double> *h_locs, *h_X, *h_z;
+    std::vector<double> *h_locs, *h_X, *h_z, *h_xb;
     std::vector<cocons_fit *> *slots;
     bool sorted;                  // observations are stored in Morton order (see fit_create_impl)
     cocons_fit *unsorted;         // lazily created clone in the ORIGINAL order (marginal simulation)
@@ -369,7 +369,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->stream2) hipStreamDestroy(f->stream2);
         if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
     }
-    delete f->h_locs; delete f->h_X; delete f->h_z;
+    delete f->h_locs; delete f->h_X; delete f->h_z; delete f->h_xb;
     delete f->taper_hi; delete f->taper_inv;
     delete f;
 }
@@ -465,6 +465,8 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     f->h_X = new std::vector<double>(X, X + (size_t)n * p);
     f->h_z = new std::vector<double>();
     if (r > 0) f->h_z->assign(z, z + (size_t)n * r);
+    f->h_xb = new std::vector<double>();
+    if (q > 0) f->h_xb->assign(x_betas, x_betas + (size_t)n * q);
     f->sorted = false;
     for (int i = 0; i < n; ++i)
         if (perm[i] != i) { f->sorted = true; break; }
@@ -718,6 +720,22 @@ extern "C" cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double
     // 4.7 ms at n = 10^4): plain schedule
     if (!f->taper_hi->empty()) f->engine_ok = false;
     return f;
+}
+
+// Does the handle hold exactly these data (bitwise)?  The R glue's handle cache asks on a miss of its address check
+// (glue/cocons_hip_glue.c): O(n) host work, no device call.  1 = the same, 0 = different (or a taper handle / bad argument).
+extern "C" int cocons_fit_same_data(cocons_fit *f, int n, int p, int r, int q, const double *locs, const double *X,
+                                    const double *z, const double *x_betas, const double *smooth_limits)
+{
+    if (!f || !locs || !X || !smooth_limits || f->taper_nnz > 0) return 0;
+    if (f->n_user != n || f->p != p || f->r != r || f->q != q) return 0;
+    if (f->smooth_limits[0] != smooth_limits[0] || f->smooth_limits[1] != smooth_limits[1]) return 0;
+    if (memcmp(f->h_locs->data(), locs, (size_t)2 * n * sizeof(double)) != 0) return 0;
+    if (memcmp(f->h_X->data(), X, (size_t)n * p * sizeof(double)) != 0) return 0;
+    if (r > 0 && (!z || memcmp(f->h_z->data(), z, (size_t)n * r * sizeof(double)) != 0)) return 0;
+    if (q > 0 && (!x_betas || f->h_xb->size() != (size_t)n * q ||
+                  memcmp(f->h_xb->data(), x_betas, (size_t)n * q * sizeof(double)) != 0)) return 0;
+    return 1;
 }
 
 extern "C" void *cocons_fit_stream(cocons_fit *f) { return f ? (void *)f->stream : nullptr; }

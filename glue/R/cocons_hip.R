@@ -5,11 +5,12 @@
 # are: only the native symbols behind them change (glue/cocons_hip_glue.c).
 #
 # The device-resident data of a fit live in an explicit handle (external pointer).  Callers that hold
-# one pass it as `fit = `; otherwise one handle per (process, data) is created on first use and kept in
-# an environment keyed on the ADDRESS-INDEPENDENT content hash of everything the handle depends on
-# (all of locs, x_covariates, z, x_betas, smooth.limits) -- two datasets can no longer alias.
-
-.cocons.hip <- new.env(parent = emptyenv())
+# one pass it as `fit = `; otherwise -- cocoOptim calls the closures with the reference's signatures, which have no
+# handle -- the native side keeps up to eight handles per process and finds the right one in O(1): addresses and
+# dimensions of (locs, x_covariates, z, x_betas), smooth.limits and a fingerprint of sampled elements; only when that
+# misses are the data compared with the copies the handles keep, and only then is a handle created
+# (glue/cocons_hip_glue.c, _cocons_hip_fit_cached).  No hash of the data on any path, no package beyond base R.
+# cocons_hip_forget() drops the cached handles (e.g. after modifying a data object IN PLACE from C code).
 
 cocons_hip_fit <- function(locs, x_covariates, z, smooth.limits, x_betas = NULL, device = NULL) {
   if (is.null(device)) {
@@ -23,14 +24,17 @@ cocons_hip_fit <- function(locs, x_covariates, z, smooth.limits, x_betas = NULL,
 }
 
 .cocons.hip.cached <- function(locs, x_covariates, z, smooth.limits, x_betas = NULL) {
-  key <- paste(Sys.getpid(), rlang::hash(list(locs, x_covariates, z, x_betas, smooth.limits)))
-  fit <- .cocons.hip[[key]]
-  if (is.null(fit)) {
-    fit <- cocons_hip_fit(locs, x_covariates, z, smooth.limits, x_betas)
-    assign(key, fit, envir = .cocons.hip)
+  if (!is.matrix(z)) z <- as.matrix(z)                     # (no copy when the caller passes a matrix, as cocoOptim does)
+  if (!is.double(locs) || !is.double(x_covariates) || !is.double(z) || (!is.null(x_betas) && !is.double(x_betas)) ||
+      !is.double(smooth.limits)) {                           # integer inputs: converted once per call -- the rare path
+    storage.mode(locs) <- storage.mode(x_covariates) <- storage.mode(z) <- "double"
+    if (!is.null(x_betas)) storage.mode(x_betas) <- "double"
+    smooth.limits <- as.double(smooth.limits)
   }
-  fit
+  .Call(`_cocons_hip_fit_cached`, locs, x_covariates, z, x_betas, smooth.limits, -1L)   # -1: worker -> GPU map, natively
 }
+
+cocons_hip_forget <- function() invisible(.Call(`_cocons_hip_cache_clear`))
 
 .cocons.hip.result <- function(res, safe) {       # the reference's tryCatch contract, :200-206
   if (res[[1]] > 0L) {

@@ -18,7 +18,9 @@
  * library's message.  No HIP call happens at load time (R_init_cocons): cocoOptim forks its workers
  * (R/optim.R:117-121) and a HIP context does not survive fork; a handle refuses use in another process.
  */
+#include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <R.h>
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
@@ -188,6 +190,105 @@ SEXP _cocons_hip_fit_create(SEXP locs, SEXP X, SEXP z, SEXP x_betas, SEXP smooth
     INTEGER(tag)[0] = n; INTEGER(tag)[1] = p; INTEGER(tag)[2] = r; INTEGER(tag)[3] = q;
     SEXP ptr = PROTECT(R_MakeExternalPtr(f, tag, R_NilValue));
     R_RegisterCFinalizerEx(ptr, fit_finalizer, TRUE);
+    UNPROTECT(2);
+    return ptr;
+}
+
+/* ---- handle cache for callers that pass no handle (the reference's signatures have none) ---------------------------
+ * cocoOptim's closures call GetNeg2loglikelihood(theta, par.pos, locs, x_covariates, smooth.limits, z, n, lambda) with
+ * the SAME R objects at every parameter step (R/optim.R:237-259), so the cache keys on what is O(1) to check: the
+ * process, the addresses and dimensions of the four arrays, smooth.limits, and a fingerprint of a few dozen sampled
+ * elements per array (an object R modified in place keeps its address; the sample includes its first and last element).
+ * Only when that check misses are the data themselves compared, against the host copies each cached handle keeps
+ * (cocons_fit_same_data: O(n), no hashing, no extra package) -- a copy of the same data then re-keys its entry -- and
+ * only when that misses too is a handle created.  Per call on the hit path: ~30 comparisons and ~260 loads.
+ * (Round 3 hashed all inputs with rlang::hash on EVERY call: ~0.5 MB per 10 ms evaluation at n = 10^4.)               */
+#define HIP_CACHE_SLOTS 8
+#define HIP_FP_SAMPLES 64
+typedef struct {
+    int pid, n, p, r, q;
+    const double *a_locs, *a_X, *a_z, *a_xb;
+    double sl[2], fp;
+    SEXP handle;                /* external pointer, R_PreserveObject'ed while cached */
+    unsigned long stamp;        /* least recently used goes first */
+} hip_cache_entry;
+static hip_cache_entry hip_cache[HIP_CACHE_SLOTS];
+static unsigned long hip_cache_clock = 0;
+
+static double sample_sum(const double *a, size_t len)
+{
+    if (!a || len == 0) return 0.0;
+    double s = a[0] + 3.0 * a[len - 1];
+    const size_t step = len / HIP_FP_SAMPLES + 1;
+    for (size_t i = step; i < len; i += step) s += a[i] * (double)(1 + (i & 7));
+    return s;
+}
+
+static void hip_cache_drop(hip_cache_entry *e)
+{
+    if (e->handle) R_ReleaseObject(e->handle);
+    memset(e, 0, sizeof *e);
+}
+
+/* every cached handle is forgotten (their finalizers run when R collects them) */
+SEXP _cocons_hip_cache_clear(void)
+{
+    for (int i = 0; i < HIP_CACHE_SLOTS; ++i) hip_cache_drop(&hip_cache[i]);
+    return R_NilValue;
+}
+
+SEXP _cocons_hip_fit_cached(SEXP locs, SEXP X, SEXP z, SEXP x_betas, SEXP smooth_limits, SEXP device)
+{
+    const int n = Rf_nrows(X), p = Rf_ncols(X);
+    const int r = Rf_isMatrix(z) ? Rf_ncols(z) : 1;
+    const int q = Rf_isNull(x_betas) ? 0 : (Rf_isMatrix(x_betas) ? Rf_ncols(x_betas) : 1);
+    if (!Rf_isReal(locs) || !Rf_isReal(X) || !Rf_isReal(z) || (q && !Rf_isReal(x_betas)) || !Rf_isReal(smooth_limits))
+        Rf_error("locs, x_covariates, z, x_betas and smooth.limits must be double");
+    if (Rf_nrows(locs) != n || Rf_ncols(locs) != 2 || XLENGTH(z) != (R_xlen_t)n * r) Rf_error("locs must be n x 2 and z n x r");
+    const double *a_locs = REAL(locs), *a_X = REAL(X), *a_z = REAL(z), *a_xb = q ? REAL(x_betas) : NULL;
+    const double *sl = REAL(smooth_limits);
+    const int pid = (int)getpid();
+    const double fp = sample_sum(a_locs, (size_t)2 * n) + sample_sum(a_X, (size_t)n * p) + sample_sum(a_z, (size_t)n * r) +
+                      sample_sum(a_xb, (size_t)n * q);
+    /* 1: the O(1) check */
+    for (int i = 0; i < HIP_CACHE_SLOTS; ++i) {
+        hip_cache_entry *e = &hip_cache[i];
+        if (e->handle && e->pid == pid && e->a_locs == a_locs && e->a_X == a_X && e->a_z == a_z && e->a_xb == a_xb &&
+            e->n == n && e->p == p && e->r == r && e->q == q && e->sl[0] == sl[0] && e->sl[1] == sl[1] && e->fp == fp) {
+            e->stamp = ++hip_cache_clock;
+            return e->handle;
+        }
+    }
+    /* 2: the same data at other addresses (R copied them), or a handle of another process (fork): compare / drop */
+    int victim = 0;
+    for (int i = 0; i < HIP_CACHE_SLOTS; ++i) {
+        hip_cache_entry *e = &hip_cache[i];
+        if (e->handle && e->pid != pid) hip_cache_drop(e);            /* inherited through fork: useless here */
+        if (!e->handle) { victim = i; continue; }
+        cocons_fit *f = (cocons_fit *)R_ExternalPtrAddr(e->handle);
+        if (f && cocons_fit_same_data(f, n, p, r, q, a_locs, a_X, a_z, a_xb, sl)) {
+            e->a_locs = a_locs; e->a_X = a_X; e->a_z = a_z; e->a_xb = a_xb; e->fp = fp;
+            e->stamp = ++hip_cache_clock;
+            return e->handle;
+        }
+        if (hip_cache[victim].handle && e->stamp < hip_cache[victim].stamp) victim = i;
+    }
+    /* 3: a new handle, in place of the least recently used entry.  device < 0: the worker -> GPU map of the forked workers
+     * (R/optim.R:117-121): COCONS_HIP_DEVICE, else pid modulo the number of devices */
+    if (Rf_asInteger(device) < 0) {
+        const char *ev = getenv("COCONS_HIP_DEVICE");
+        int ndev = cocons_device_count();
+        if (ndev < 1) ndev = 1;
+        device = Rf_ScalarInteger(ev ? atoi(ev) : pid % ndev);
+    }
+    PROTECT(device);
+    SEXP ptr = PROTECT(_cocons_hip_fit_create(locs, X, z, x_betas, smooth_limits, device));
+    hip_cache_entry *e = &hip_cache[victim];
+    hip_cache_drop(e);
+    R_PreserveObject(ptr);
+    e->handle = ptr; e->pid = pid; e->n = n; e->p = p; e->r = r; e->q = q;
+    e->a_locs = a_locs; e->a_X = a_X; e->a_z = a_z; e->a_xb = a_xb; e->sl[0] = sl[0]; e->sl[1] = sl[1]; e->fp = fp;
+    e->stamp = ++hip_cache_clock;
     UNPROTECT(2);
     return ptr;
 }
@@ -488,6 +589,8 @@ static const R_CallMethodDef CallEntries[] = {
     {"_cocons_cov_rns_taper", (DL_FUNC)&_cocons_cov_rns_taper, 6},
     {"_cocons_hip_device_count", (DL_FUNC)&_cocons_hip_device_count, 0},
     {"_cocons_hip_fit_create", (DL_FUNC)&_cocons_hip_fit_create, 6},
+    {"_cocons_hip_fit_cached", (DL_FUNC)&_cocons_hip_fit_cached, 6},
+    {"_cocons_hip_cache_clear", (DL_FUNC)&_cocons_hip_cache_clear, 0},
     {"_cocons_hip_fit_create_taper", (DL_FUNC)&_cocons_hip_fit_create_taper, 8},
     {"_cocons_hip_fit_close", (DL_FUNC)&_cocons_hip_fit_close, 1},
     {"_cocons_hip_neg2loglik_parts", (DL_FUNC)&_cocons_hip_neg2loglik_parts, 3},

@@ -282,6 +282,12 @@ int cocons_fit_comm_info(cocons_fit *fit, int *count, int *user_rank, int *devic
  * rows are all-gathered, every rank updates its rows.                              */
 int cocons_shard_block_owner(int b, int world);
 int cocons_shard_num_blocks(cocons_fit *fit);
+/* 1 if the handle holds exactly these data (bitwise comparison with the host copies it keeps), else 0.  Host work only.
+ * The R glue's handle cache (glue/cocons_hip_glue.c, _cocons_hip_fit_cached) calls it when its O(1) address check
+ * misses, so that GetNeg2loglikelihood(theta, par.pos, locs, x_covariates, smooth.limits, z, n, lambda) -- the
+ * reference's signature, R/neg2loglikelihood.R:183-191, no handle argument -- finds its handle without hashing the data. */
+int cocons_fit_same_data(cocons_fit *fit, int n, int p, int r, int q, const double *locs, const double *X,
+                         const double *z, const double *x_betas, const double *smooth_limits);
 /* HIP stream the fit launches on (hipStream_t as void*), so the caller can order
  * collectives against it. */
 void *cocons_fit_stream(cocons_fit *fit);

@@ -50,4 +50,6 @@ void R_ClearExternalPtr(SEXP);
 SEXP R_MakeExternalPtr(void *, SEXP, SEXP);
 typedef void (*R_CFinalizer_t)(SEXP);
 void R_RegisterCFinalizerEx(SEXP, R_CFinalizer_t, Rboolean);
+void R_PreserveObject(SEXP);
+void R_ReleaseObject(SEXP);
 #endif

@@ -102,6 +102,32 @@ def test_glue_covers_the_reference_call_surface():
         assert sym in table, sym
 
 
+def test_glue_handle_lookup_hashes_nothing_on_the_hit_path():
+    """The closures keep the reference's signatures (no handle argument: R/neg2loglikelihood.R:183-191), so every call looks
+    its handle up.  That look-up must be O(1) on a hit: no hashing / digest / serialisation of the data anywhere in the R
+    glue, no package beyond base R, and in the native look-up nothing that walks the data (memcmp, cocons_fit_same_data,
+    a loop over all elements) before the address check has returned."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rfile = open(os.path.join(root, "glue", "R", "cocons_hip.R")).read()
+    code = "\n".join(ln.split("#")[0] for ln in rfile.splitlines())
+    for banned in ("hash(", "digest", "rlang::", "serialize(", "md5"):
+        assert banned not in code, banned
+    body = code[code.index(".cocons.hip.cached <- function"):]
+    body = body[:body.index("\n}\n") + 3]
+    assert "_cocons_hip_fit_cached" in body
+    glue = open(os.path.join(root, "glue", "cocons_hip_glue.c")).read()
+    fn = glue[glue.index("SEXP _cocons_hip_fit_cached("):]
+    hit = fn[fn.index("/* 1: the O(1) check */"):fn.index("/* 2:")]
+    assert "return e->handle;" in hit
+    for walker in ("memcmp", "cocons_fit_same_data", "sample_sum"):
+        assert walker not in hit, walker
+    # the fingerprint that is computed before the check reads a bounded number of elements per array
+    fp = glue[glue.index("static double sample_sum("):]
+    fp = fp[:fp.index("\n}\n")]
+    assert "HIP_FP_SAMPLES" in fp and re.search(r"i \+= step", fp)
+
+
 def test_glue_compiles_against_declared_apis():
     """R is not installed here, so the glue is never linked -- but the compiler's front end can still check it: every call
     of a cocons_* entry point against include/cocons_hip.h (argument count and types) and every use of R's C API against

@@ -912,3 +912,33 @@ def test_first_engine_operation_of_a_fresh_process(record_property):
     assert res["state"]["retries"] == 0 and res["state"]["active"], res["state"]
     assert res["value"] == want                               # bit-identical: same kernels, same schedule
     fit.close()
+
+
+def test_fit_same_data_is_a_bitwise_comparison():
+    """cocons_fit_same_data (what the R glue's handle cache asks when its address check misses): 1 for the data the handle
+    was created with -- at any address --, 0 as soon as one element, a dimension or smooth.limits differs."""
+    import ctypes
+    import cocons_amd as ca
+    from cocons_amd import _lib, workloads as wl
+    rng = np.random.default_rng(2)
+    n = 300
+    locs = np.asfortranarray(rng.uniform(0, 1, size=(n, 2)))
+    X = np.asfortranarray(wl.design_from_locs(locs)["std.covs"])
+    z = np.asfortranarray(rng.standard_normal((n, 2)))
+    sl = np.asarray(wl.SMOOTH_LIMITS, dtype=np.float64)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    L = _lib.load()
+    p = lambda a: a.ctypes.data_as(_lib.c_dp)
+
+    def same(l, x, zz, s, nn=n, r=2):
+        return L.cocons_fit_same_data(fit._h, nn, 3, r, 0, p(l), p(x), p(zz), None, p(s))
+    assert same(locs, X, z, sl) == 1
+    assert same(locs.copy(order="F"), X.copy(order="F"), z.copy(order="F"), sl.copy()) == 1
+    z2 = z.copy(order="F"); z2[n - 1, 1] = np.nextafter(z2[n - 1, 1], 1e9)
+    assert same(locs, X, z2, sl) == 0
+    l2 = locs.copy(order="F"); l2[0, 0] += 1e-16 + abs(l2[0, 0]) * 1e-15
+    assert same(l2, X, z, sl) == 0
+    assert same(locs, X, z, np.array([0.5, 2.4])) == 0
+    assert same(locs, X, z, sl, nn=n - 1) == 0
+    assert same(locs, X, z, sl, r=1) == 0
+    fit.close()
