@@ -13,10 +13,13 @@ beside it (n^3/3 flop per evaluation).
 N = 1 : one GPU evaluates the whole thing.
 N > 1 : one rank per GPU.  Started by torch.distributed.run (the ranks read RANK / LOCAL_RANK /
         WORLD_SIZE) or bare (`python bench.py --gpus N`): then this process starts the N ranks itself
-        and never touches a GPU.  Default mode "shard": Sigma's row blocks (= column panels of the
-        factor) are dealt block-cyclically over the ranks and the evaluation is the library's native
-        sharded one (RCCL broadcasts on its own stream, csrc/api.hip `sharded_eval`); torch.distributed
-        only carries the 128-byte RCCL unique id, the barriers and the timing reduction (gloo).
+        and never touches a GPU.  Default mode "shard": Sigma's 256-row blocks are dealt over the ranks
+        in groups and the evaluation is the library's native sharded one (per block: broadcast of the
+        factored diagonal block, every rank solves its rows, all-gather of the solved rows, every rank
+        updates its rows -- RCCL on its own stream, csrc/api.hip `sharded_eval`); torch.distributed
+        only carries the 128-byte RCCL unique id, the barriers and the timing reduction (gloo).  The
+        line carries the critical-path model's PREDICTION for this N beside the measurement
+        (`shard_prediction`, cocons_amd/shard_model.py).
         Total work is fixed -> "scaling": "strong".  If the sharded path fails the run FAILS (non-zero
         exit, no JSON value): a replica number is never reported in its place.
         Mode "replica" (explicit): every rank evaluates its own theta (what optimParallel's 1+2P
@@ -228,7 +231,8 @@ def main():
     es = fit.engine_state()
     engine = {"engine_active": es["active"], "engine_retries": es["retries"], "engine_last_abort": es["last_abort"],
               "switches": {k: os.environ.get(k) for k in ("COCONS_ENGINE", "COCONS_UPD_DYNAMIC", "COCONS_UPD_WAVES",
-                                                         "COCONS_UPD_W8_MAX_TILES") if os.environ.get(k) is not None}}
+                                                         "COCONS_UPD_W8_MAX_TILES", "COCONS_DAG", "COCONS_DAG_MIN_TILES")
+                           if os.environ.get(k) is not None}}
 
     # Stage timings and the dominant kernel's roofline (HIP events on the launch stream around every stage and every
     # trailing-update launch, cocons_fit_profile) are taken HERE, straight behind the timed steps and on the same warm
@@ -367,15 +371,30 @@ def main():
         roofline = None
         flops, launches = st["update_flops"], st["update_launches"]
         if launches > 0 and st["update_sum_ms"] > 0:
-            achieved = flops / (st["update_sum_ms"] * 1e-3) / 1e12
+            dag = st.get("dag_ms", 0.0) > 0 and st.get("dag_flops", 0.0) > 0
+            if dag:
+                # the dominant kernel is the ONE persistent launch that runs the head of the factorisation (its trailing updates
+                # AND the panels between them, dag_kernel); only the update flops are counted for it
+                achieved = st["dag_flops"] / (st["dag_ms"] * 1e-3) / 1e12
+                kernel = ("cocons::dag_kernel (persistent, dependency-driven: the trailing updates of the head of the factorisation "
+                          "-- steps of >= %s update tiles, %.0f %% of the update flops -- and the panel tasks between them, "
+                          "v_mfma_f64_16x16x4_f64); the remaining %d steps: cocons::update_kernel launches"
+                          % (os.environ.get("COCONS_DAG_MIN_TILES", "4000"), 100.0 * st["dag_flops"] / flops, launches - 1))
+                kflops, kms, klaunches = st["dag_flops"], st["dag_ms"], 1
+            else:
+                achieved = flops / (st["update_sum_ms"] * 1e-3) / 1e12
+                kernel = ("cocons::update_kernel<64, 8, 0, 4> / <64, 16, 0, 8> (trailing SYRK/GEMM, v_mfma_f64_16x16x4_f64; the "
+                          "8-wave form for launches of <= 3500 tiles)")
+                kflops, kms, klaunches = flops, st["update_avg_ms"], launches
             roofline = {"bound": "mfma",
-                        "kernel": "cocons::update_kernel<64, 8, 0, false, 4> / <64, 16, 0, false, 8> (trailing SYRK/GEMM, "
-                                  "v_mfma_f64_16x16x4_f64; the 8-wave form for launches of <= 3500 tiles)",
+                        "kernel": kernel,
                         "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
                         "measured_in": "this run (HIP events around each launch on the launch stream)",
-                        "flops_per_launch": flops / max(launches, 1),
-                        "launch_ms": round(st["update_avg_ms"], 4), "launches_per_eval": launches,
+                        "flops_per_launch": kflops / max(klaunches, 1),
+                        "launch_ms": round(kms, 4), "launches_per_eval": klaunches,
+                        "all_update_launches": {"launches": launches, "sum_ms": round(st["update_sum_ms"], 4), "flops": flops,
+                                                "tflops": round(flops / (st["update_sum_ms"] * 1e-3) / 1e12, 3)},
                         "pipe_busy_frac_pmc": None,
                         "pipe_busy_source": "NOT measured in this run: profiles/r03_update_kernel_mfma_util.json "
                                             "(SQ_VALU_MFMA_BUSY_CYCLES over SIMD cycles, all 39 launches; rocprofv3 --pmc "
@@ -406,6 +425,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu, cpu_val = cpu_baseline(n, locs, X, th, z)
             parity = abs(val - cpu_val) / abs(cpu_val)
+        # N > 1, sharded: what the critical-path model of the row-block exchange predicts for this N, beside the measurement
+        # (single-GPU rate in it: this handle's own eval_ms); the first run on a multi-GPU node confirms or refutes it
+        shard_pred = None
+        if shard_mode:
+            from cocons_amd import shard_model
+            one = 1e3 / st["eval_ms"] if st and st.get("eval_ms", 0) > 0 else None
+            shard_pred = shard_model.predict(n, world, one)
+            shard_pred["measured_evals_per_s"] = round(evals_per_s, 4)
+            shard_pred["one_gpu_evals_per_s_this_run"] = round(one, 2) if one else None
+            shard_pred["note"] = ("model of DESIGN.md section 5 (cocons_amd/shard_model.py): per block max(chain, rank work); "
+                                  "kernel times measured on one GPU, link figures assumed; rehearsal runs (ranks sharing one "
+                                  "GPU over gloo) are not what it predicts")
         label = {10000: "C3", 4096: "C2"}.get(n, "grid")
         out = {
             "metric": "-2loglik evals/sec (dense cov_rns + Cholesky/solve/log-det, fp64) at n=%d" % n,
@@ -415,7 +446,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %dx%d grid n=%d, p=3, full nonstationary cov_rns (Bessel-K branch), r=1, "
                                    "dense -2loglik" % (label, g, g, n),
-                       "parallelism": ("Sigma row blocks (column panels) sharded x%d, native RCCL broadcast%s"
+                       "parallelism": ("Sigma row blocks sharded x%d, native RCCL broadcast + all-gather%s"
                                        % (world, " [rehearsal: gloo wire, one GPU]" if rehearsal else "")) if shard_mode
                                       else ("replica x%d" % world if world > 1 else "single GPU"),
                        "target_8gpu_evals_per_s": 100},
@@ -425,6 +456,7 @@ def main():
             "stages_ms": stages,
             "engine": engine,
             "comm": comm,
+            "shard_prediction": shard_pred,
             "neg2loglik": val,
             "throughput_inflight": inflight,
             "throughput_batch_api": batch,

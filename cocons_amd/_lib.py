@@ -10,7 +10,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcocons_hip.so")
+LIB_PATH = os.environ.get("COCONS_HIP_LIB") or os.path.join(_HERE, "csrc", "libcocons_hip.so")   # (override: A/B of two builds)
 P_MAX = 32
 
 _lib = None

@@ -1,0 +1,66 @@
+"""Critical-path model of the row-block sharded evaluation (csrc/api.hip `sharded_eval`): what
+`bench.py --gpus N` prints beside its measurement.  Nothing here has been measured on a multi-GPU node -- the kernel
+times are single-GPU measurements of this repository (kernel traces of rounds 3-4), the link figures are assumptions
+stated below; the point of printing the prediction is that the first run on real hardware confirms or refutes it.
+
+Per 256-column block k every rank runs, in stream order,
+    unpack L_kk | solve its rows | pack them | wait for the all-gather | update its rows
+while the owner of block k + 1 -- between its solve and its pack -- updates its own diagonal block, factors it and starts
+the broadcast of L_(k+1,k+1).  So a step lasts
+    max( chain, rank ),   chain = bcast(L) + unpack + solve + diagonal update + diagonal factor      (independent of N)
+                          rank  = unpack + solve + pack + allgather(B_k) + U_k / N
+"""
+from __future__ import annotations
+
+TILE = 128
+
+# single-GPU kernel times, microseconds (launch gaps included where a sequence is meant)
+T_UNPACK = 5.0            # two device-to-device copies of 0.5 MB + 32 KB
+T_SOLVE = 45.0            # solve | in-panel update | solve over a rank's rows (three launches; strips run side by side)
+T_DIAG_UPDATE = 10.0      # 256 x 256 x 256 update of the next diagonal block (10 tiles)
+T_DIAG_FACTOR = 100.0     # potrf 30 | solve 13 | update 10 | potrf 30 + launch gaps (plain sequence)
+T_PACK = 10.0
+T_ASSEMBLY_MS = 1.1       # covariance assembly of the whole lower triangle on one GPU (shards: / N)
+T_UPDATES_MS = 6.4        # all trailing updates of one evaluation on one GPU at n = 10^4 (scaled by (n / 10^4)^3)
+COLL_LATENCY = 20.0       # per collective, microseconds (assumption)
+LINK_GBPS = 70.0          # one xGMI link, one direction, effective (assumption; 7 links per GPU, point to point)
+L_BYTES = (2 * TILE) ** 2 * 8 + 2 * 2048 * 8
+
+
+def allgather_gbps(world: int) -> float:
+    """Aggregate rate at which one rank RECEIVES in an all-gather: it has world - 1 peers, each on its own link."""
+    return LINK_GBPS * max(1, min(world - 1, 7))
+
+
+def predict(n: int, world: int, single_gpu_evals_per_s: float | None = None) -> dict:
+    """Predicted -2 loglik evaluations per second of the sharded evaluation at order n on `world` GPUs."""
+    npad = (n + TILE - 1) // TILE * TILE
+    nt = npad // TILE
+    nb = (nt + 1) // 2
+    rows_total = npad + TILE
+    upd_total_us = T_UPDATES_MS * 1e3 * (n / 1e4) ** 3
+    # trailing update of step k ~ (rows below)^2
+    below = [max(0, rows_total - 256 * (k + 1)) for k in range(nb)]
+    wsum = sum(b * b for b in below) or 1.0
+    chain = COLL_LATENCY + L_BYTES / (LINK_GBPS * 1e3) + T_UNPACK + T_SOLVE + T_DIAG_UPDATE + T_DIAG_FACTOR
+    total = T_DIAG_FACTOR + T_ASSEMBLY_MS * 1e3 * (n / 1e4) ** 2 / world
+    chain_bound = 0
+    for k in range(nb):
+        bk = below[k] * 256 * 8.0                                   # bytes of the solved panel
+        ag = 0.0 if world == 1 else COLL_LATENCY + bk * (world - 1) / world / (allgather_gbps(world) * 1e3)
+        rank = T_UNPACK + T_SOLVE + T_PACK + ag + upd_total_us * below[k] ** 2 / wsum / world
+        step = max(chain if world > 1 else 0.0, rank)
+        chain_bound += step == chain
+        total += step
+    out = {"evals_per_s": round(1e6 / total, 1), "ms_per_eval": round(total * 1e-3, 3), "chain_us_per_block": round(chain, 1),
+           "blocks": nb, "blocks_bound_by_the_chain": int(chain_bound),
+           "assumptions": {"link_GBps_per_direction": LINK_GBPS, "collective_latency_us": COLL_LATENCY,
+                           "diag_factor_us": T_DIAG_FACTOR, "solve_us": T_SOLVE, "updates_ms_one_gpu": round(upd_total_us * 1e-3, 2)}}
+    if single_gpu_evals_per_s:
+        out["vs_one_gpu"] = round(out["evals_per_s"] / single_gpu_evals_per_s, 2)
+    return out
+
+
+if __name__ == "__main__":
+    for w in (1, 2, 4, 8):
+        print(w, predict(10000, w, 104.0))
