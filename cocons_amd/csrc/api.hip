@@ -1353,8 +1353,20 @@ static int info_status(cocons_fit *f)
     // COCONS_DEBUG_ABORT=1: say which wait gave up (0x1tt / 0x2tt engine waiting for tile tt, 0x3tt panel solve
     // waiting for the engine's tile tt, 0x5.. in-panel update, 0x600 the gate waiting for the engine to be resident,
     // 0x800 panel product (mode 3), 0x900 the reductions waiting for the engine's last tile)
-    if (f->hinfo[1] != 0 && getenv("COCONS_DEBUG_ABORT"))
+    if (f->hinfo[1] != 0 && getenv("COCONS_DEBUG_ABORT")) {
         fprintf(stderr, "cocons: hand-off time-out, code 0x%x\n", f->hinfo[1]);
+        if (f->dag_used && f->ddag && (f->hinfo[1] & 0xf00) >= 0xa00) {
+            // a wait of the DAG launch: what it waited for (dag_wait's record) and what the word holds NOW
+            unsigned rec[6] = {0, 0, 0, 0, 0, 0}, now = 0, qn = 0;
+            hipMemcpyAsync(rec, f->ddag + 8, sizeof rec, hipMemcpyDeviceToHost, f->stream);
+            hipStreamSynchronize(f->stream);
+            if (rec[2] < f->ddag_words) hipMemcpyAsync(&now, f->ddag + rec[2], sizeof now, hipMemcpyDeviceToHost, f->stream);
+            hipMemcpyAsync(&qn, f->ddag, sizeof qn, hipMemcpyDeviceToHost, f->stream);
+            hipStreamSynchronize(f->stream);
+            fprintf(stderr, "cocons: DAG wait: task %u (of %u, counter now %u) code 0x%x waited for word %u >= %u, saw %u, holds %u now\n",
+                    rec[0], f->dag_ntasks, qn, rec[1], rec[2], rec[3], rec[4], now);
+        }
+    }
     if (f->hinfo[1] != 0)
         return fail(ENGINE_ABORT, "hand-off between the diagonal-tile engine and the main stream timed out");
     // the operation ran to its end on the schedule factorize chose: book-keeping of the engine's back-off

@@ -416,6 +416,19 @@ __device__ __forceinline__ void signal_add(unsigned *word)
     __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One poll of a hand-off word.  An L2-bypassing (sc1) load is what the protocol uses -- and what round 4 caught returning
+// a STALE value for as long as the waiter kept polling: 3 of 40 000 evaluations under the dependency-driven schedule ended in a
+// 100 ms time-out whose record read "waited for word 9646 >= 2, saw 1, holds 2 now" (dag_wait), whether the word had been
+// published by a write-through store or by a read-modify-write atomic.  The stale copy is the poller's: its own refill can
+// install the pre-update line in its XCD's L2 just behind the invalidation the update sent, and every later poll then hits
+// it.  A read-modify-write atomic executes at the memory side and cannot be served by that line: every 8th poll (~4 us into
+// a wait; most waits are over after the first) is a fetch-add of zero.
+__device__ __forceinline__ unsigned poll_word(unsigned *word, unsigned it)
+{
+    if ((it & 7u) == 7u) return __hip_atomic_fetch_add(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // one lane; returns false on abort / timeout.  ACQUIRE = false: the caller reads the handed-off bytes with
 // load_wt only
 // code: what the abort word is set to on a time-out (who gave up: diagnostic, any non-zero value aborts)
@@ -424,8 +437,8 @@ __device__ __forceinline__ bool wait_ge(unsigned *word, unsigned need, unsigned 
                                         unsigned long long ticks = ENGINE_TIMEOUT_TICKS)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
-        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+    for (unsigned it = 0;; ++it) {
+        if (poll_word(word, it) >= need) break;
         if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
         if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) {
             __hip_atomic_store(abort_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1002,6 +1015,29 @@ struct DagArgs {
                                      // complete, product done and previous C version there, stored and signalled
 };
 
+// a bounded wait of dag_kernel: like wait_ge<false>, and when it runs out the waiter leaves a record in words 8 .. 13 of the
+// task-word block (a.queue + 8): task, code, index of the word it waited for, value needed, value seen, low bits of the clock
+__device__ __forceinline__ bool dag_wait(const DagArgs &a, unsigned *word, unsigned need, unsigned code, unsigned L)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned it = 0;; ++it) {
+        const unsigned v = poll_word(word, it);
+        if (v >= need) break;
+        if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > ENGINE_TIMEOUT_TICKS) {
+            if (__hip_atomic_exchange(a.abort_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                unsigned *d = a.queue + 8;
+                d[0] = L; d[1] = code; d[2] = (unsigned)(word - a.queue); d[3] = need; d[4] = v;
+                d[5] = (unsigned)__builtin_amdgcn_s_memrealtime();
+            }
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler ordering only
+    return true;
+}
+
 __global__ void __launch_bounds__(256, 8)
 dag_kernel(DagArgs a)
 {
@@ -1115,12 +1151,12 @@ dag_kernel(DagArgs a)
                 if (!isT) {
                     // update tile: whole panel there (2)?  else its two strips (1)
                     if (__hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n0) ok = 2u;
-                    else ok = (wait_ge<false>(w1, n1, a.abort_word, 0xb00u + (unsigned)s) &&
-                               wait_ge<false>(w2, n2, a.abort_word, 0xc00u + (unsigned)s)) ? 1u : 0u;
+                    else ok = (dag_wait(a, w1, n1, 0xb00u + (unsigned)s, L) &&
+                               dag_wait(a, w2, n2, 0xc00u + (unsigned)s, L)) ? 1u : 0u;
                 } else {
-                    bool o = wait_ge<false>(w0, n0, a.abort_word, 0xa00u + (unsigned)s);
-                    if (o && w1) o = wait_ge<false>(w1, n1, a.abort_word, 0xb00u + (unsigned)s);
-                    if (o && w2) o = wait_ge<false>(w2, n2, a.abort_word, 0xc00u + (unsigned)s);
+                    bool o = dag_wait(a, w0, n0, 0xa00u + (unsigned)s, L);
+                    if (o && w1) o = dag_wait(a, w1, n1, 0xb00u + (unsigned)s, L);
+                    if (o && w2) o = dag_wait(a, w2, n2, 0xc00u + (unsigned)s, L);
                     ok = o ? 1u : 0u;
                 }
                 *share = ok;
@@ -1187,7 +1223,7 @@ dag_kernel(DagArgs a)
         if (t2 == 0) {
             const unsigned Ln = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight during the poll)
             unsigned ok = 1u;
-            if (we) ok = wait_ge<false>(we, ne, a.abort_word, 0xd00u + (unsigned)s) ? 1u : 0u;
+            if (we) ok = dag_wait(a, we, ne, 0xd00u + (unsigned)s, L) ? 1u : 0u;
             share[0] = ok; share[1] = Ln;
             if (a.trace) a.trace[4 * (size_t)L + 2] = __builtin_amdgcn_s_memrealtime();
         }
@@ -1220,7 +1256,12 @@ dag_kernel(DagArgs a)
         __syncthreads();
         if (t2 == 0) {
             if (sigT >= 0) signal_add(a.sig + sigT);
-            if (dval) __hip_atomic_store(dn, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (every word another workgroup polls is updated with a read-modify-write atomic, which executes at the memory side.
+            // Round 4's first version published tdone with a write-through STORE: such a store leaves the line valid in the
+            // storing XCD's L2, and a workgroup of that XCD polling a NEIGHBOURING word of the line -- another tile's -- could
+            // then read a stale value for as long as it kept polling: 2 time-outs in 16 000 evaluations, caught with
+            // dag_wait's record: "waited for word 9646 >= 2, saw 1, holds 2 now".)
+            if (dval) __hip_atomic_fetch_max(dn, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (__hip_atomic_fetch_add(dn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (st.two ? 6u : 2u))
                 __hip_atomic_fetch_add(a.pall + s + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the strip is complete
             if (a.trace) a.trace[4 * (size_t)L + 3] = __builtin_amdgcn_s_memrealtime();

@@ -909,7 +909,8 @@ def test_first_engine_operation_of_a_fresh_process(record_property):
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     record_property("fresh_process_engine_state", "retries=%d last_abort=0x%x active=%d"
                     % (res["state"]["retries"], res["state"]["last_abort"], int(res["state"]["active"])))
-    assert res["state"]["retries"] == 0 and res["state"]["active"], res["state"]
+    assert res["state"]["retries"] == 0, res["state"]
+    assert res["state"]["active"] == (os.environ.get("COCONS_ENGINE", "1") != "0"), res["state"]
     assert res["value"] == want                               # bit-identical: same kernels, same schedule
     fit.close()
 
