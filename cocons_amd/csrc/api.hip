@@ -276,9 +276,10 @@ struct cocons_fit {
     // dependency-driven schedule (factorize_dag): second buffer shaped like dA, tile inverses, task words, step table
     double *dP; size_t dP_elems;
     double *dWt; int dWt_tiles;
+    double *dpart;                // early halves of the split diagonal-block tiles (2 x 16 x 64 x 64 doubles)
     unsigned *ddag; size_t ddag_words;      // [queue (64 words)] [tdone] [pdone]
     void *ddag_steps; int dag_nsteps; unsigned dag_ntasks;
-    int dag_key[6];               // (nt, mt, trim, kskip, lead, min_tiles) the step table was built for
+    int dag_key[7];               // (nt, mt, trim, kskip, lead, min_tiles, split) the step table was built for
     unsigned long long *ddag_trace; size_t dag_trace_tasks;   // diagnostics (cocons_debug_tune("dag_trace", 1)): 4 stamps per task
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
     bool dag_used;                // the factorisation enqueued last ran the DAG schedule: its factor is split over dA and dP
@@ -358,7 +359,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
         if (f->ev_eng) hipEventDestroy(f->ev_eng);
         hipFree(f->dflags);
-        hipFree(f->dP); hipFree(f->dWt); hipFree(f->ddag); hipFree(f->ddag_steps); hipFree(f->ddag_trace);
+        hipFree(f->dP); hipFree(f->dWt); hipFree(f->ddag); hipFree(f->ddag_steps); hipFree(f->ddag_trace); hipFree(f->dpart);
         hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_thi);
         if (f->cstream) { hipStreamSynchronize(f->cstream); hipStreamDestroy(f->cstream); }
         shard_state_free(f->shard);
@@ -918,8 +919,10 @@ struct Tunables {
     int dag = 1;             // COCONS_DAG: 1 = the head of the factorisation under the dependency-driven schedule (one persistent
                              // launch for its updates and panels, dag_kernel); 0 = the classic schedule throughout
     int dag_lead = 3600;     // COCONS_DAG_LEAD: far tiles of a step in front of its panel tasks
-    int dag_min_tiles = 4000;  // COCONS_DAG_MIN_TILES: the DAG launch covers the leading steps of at least this many update tiles
-                             // (n = 10^4: 19 of the 39 steps, 90 % of the flops; below n ~ 6000 no step at all)
+    int dag_min_tiles = 3000;  // COCONS_DAG_MIN_TILES: the DAG launch covers the leading steps of at least this many update tiles
+                             // (n = 10^4: 21 of the 39 steps, 87 % of the flops; below n ~ 5200 no step at all)
+    int dag_split = 1;       // COCONS_DAG_SPLIT: the diagonal-block tiles of a DAG step in two halves, the first one off the chain
+    int dag_xcc_quota = 208; // workgroups of the DAG launch that take part on the engine's XCD (of the 255 that land there; 0: all)
     int dag_trace = 0;       // (diagnostics) time stamps per task, cocons_debug_dag_trace
     int gate_sabotage = 0;   // (tests) the next N engine-schedule factorisations wait at the gate for a word nobody raises:
                              // a genuine 5 ms time-out, abort code 0x600, to exercise the fall-back and its book-keeping
@@ -935,6 +938,8 @@ static Tunables &tun()
         rd("COCONS_DAG", t.dag);
         rd("COCONS_DAG_LEAD", t.dag_lead);
         rd("COCONS_DAG_MIN_TILES", t.dag_min_tiles);
+        rd("COCONS_DAG_SPLIT", t.dag_split);
+        rd("COCONS_DAG_XCC_QUOTA", t.dag_xcc_quota);
         t.init = true;
     }
     return t;
@@ -950,6 +955,8 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "dag") t.dag = value;
     else if (k == "dag_lead") t.dag_lead = value;
     else if (k == "dag_min_tiles") t.dag_min_tiles = value;
+    else if (k == "dag_split") t.dag_split = value;
+    else if (k == "dag_xcc_quota") t.dag_xcc_quota = value;
     else if (k == "dag_trace") t.dag_trace = value;
     else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
@@ -1093,6 +1100,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         HIPCHK(hipMemsetAsync(f->dP, 0, elems * sizeof(double), f->stream));
         f->dP_elems = elems;
     }
+    if (!f->dpart) HIPCHK(hipMalloc(&f->dpart, (size_t)2 * 16 * 64 * 64 * sizeof(double)));
     if (f->dWt_tiles < v.nt) {
         HIPCHK(hipStreamSynchronize(f->stream));
         HIPCHK(hipStreamSynchronize(f->stream2));
@@ -1102,10 +1110,10 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         f->dWt_tiles = v.nt;
     }
     const int kskip = (f->pad0 / 16) * 16;
-    const int key[6] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles};
+    const int key[7] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split};
     if (memcmp(key, f->dag_key, sizeof key) != 0 || !f->ddag_steps) {
         std::vector<DagStepHost> steps;
-        const unsigned ntasks = dag_build_steps(v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, steps);
+        const unsigned ntasks = dag_build_steps(v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, steps);
         HIPCHK(hipStreamSynchronize(f->stream));
         HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->ddag_steps) { HIPCHK(hipFree(f->ddag_steps)); f->ddag_steps = nullptr; }
@@ -1117,7 +1125,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         f->dag_nsteps = (int)steps.size(); f->dag_ntasks = ntasks;
         memcpy(f->dag_key, key, sizeof key);
         const size_t T64 = 2 * (size_t)v.mt;
-        const size_t words = 64 + T64 * (T64 + 1) / 2 + (steps.size() + 2) * T64 + steps.size() + 64;
+        const size_t words = 64 + T64 * (T64 + 1) / 2 + (steps.size() + 2) * T64 + steps.size() + 64 + 16 * (steps.size() + 2);
         if (f->ddag_words < words) {
             if (f->ddag) { HIPCHK(hipFree(f->ddag)); f->ddag = nullptr; }
             HIPCHK(hipMalloc(&f->ddag, words * sizeof(unsigned)));
@@ -1127,14 +1135,16 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
     HIPCHK(hipMemsetAsync(f->ddag, 0, f->ddag_words * sizeof(unsigned), f->stream));
     if (tun().dag_trace && f->dag_trace_tasks < f->dag_ntasks) {
         if (f->ddag_trace) { HIPCHK(hipFree(f->ddag_trace)); f->ddag_trace = nullptr; }
-        HIPCHK(hipMalloc(&f->ddag_trace, ((size_t)f->dag_ntasks * 4 + 8 * (size_t)(v.nt + 2)) * sizeof(unsigned long long)));   // + the engine's
+        HIPCHK(hipMalloc(&f->ddag_trace, ((size_t)f->dag_ntasks * 5 + 8 * (size_t)(v.nt + 2)) * sizeof(unsigned long long)));   // + the engine's + hw_where() per task
         f->dag_trace_tasks = f->dag_ntasks;
     }
+    if (tun().dag_trace && f->ddag_trace)
+        HIPCHK(hipMemsetAsync(f->ddag_trace, 0, ((size_t)f->dag_ntasks * 5 + 8 * (size_t)(v.nt + 2)) * sizeof(unsigned long long), f->stream));
     return 0;
 }
 
 // diagnostics: the step table and the per-task stamps of the last DAG factorisation of the handle (dag_trace = 1).
-// steps_out: nsteps x 12 ints (DagStepHost); stamps_out: ntasks x 4 ticks of the 100 MHz clock.  Returns ntasks (or < 0);
+// steps_out: nsteps x 14 ints (DagStepHost); stamps_out: ntasks x 4 ticks of the 100 MHz clock.  Returns ntasks (or < 0);
 // with null outputs only the sizes: *nsteps_out.  engine_out (may be null): 8 stamps per tile pair, (nt + 2) / 2 pairs ... room
 // for 8 * (nt + 2) values (see EngineArgs::trace).
 extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int *steps_out, unsigned long long *stamps_out,
@@ -1162,13 +1172,13 @@ static int engine_start(cocons_fit *f, const FactorView &v)
     hipStream_t M = f->stream;
     if (int rc = flags_reset(f, nt)) return rc;
     unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
-    HIPCHK(hipEventRecord(f->ev_eng, M));
-    HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
     f->dag_next = dag_wanted(f, v);
     if (f->dag_next) {
         if (int rc = dag_prepare(f, v)) return rc;
         if (f->dag_nsteps < 2) f->dag_next = false;          // too small a problem for a head worth the launch: classic throughout
     }
+    HIPCHK(hipEventRecord(f->ev_eng, M));                    // (behind the resets of the flag and task words, and of W / P when new)
+    HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
     launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
                         f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dag_next ? f->dWt : nullptr,
                         f->dag_next ? f->dP : nullptr, f->dag_next ? 2 * f->dag_nsteps : 0,
@@ -1257,6 +1267,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         const size_t T64 = 2 * (size_t)mt;
         unsigned *queue = f->ddag, *tdone = f->ddag + 64, *pdone = tdone + T64 * (T64 + 1) / 2;
         unsigned *pall = pdone + ((size_t)f->dag_nsteps + 2) * T64;
+        unsigned *dcount = pall + (size_t)f->dag_nsteps + 64;
         hipEvent_t ea = nullptr, eb = nullptr;
         if (ev_upd) {
             const double before = f->upd_flops;
@@ -1266,7 +1277,8 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
             hipEventRecord(ea, M);
         }
         launch_dag(v.A, v.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
-                   pdone, (int)T64, pall, in, out, xr, abort_word, M, tun().dag_trace ? f->ddag_trace : nullptr);
+                   pdone, (int)T64, pall, f->dpart, dcount, in, out, xr, abort_word, M, tun().dag_trace ? f->ddag_trace : nullptr,
+                   alive, tun().dag_xcc_quota, f->ddag_trace ? (unsigned *)(f->ddag_trace + 4 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2)) : nullptr);
         if (ev_upd) { hipEventRecord(eb, M); ev_upd->push_back(ea); ev_upd->push_back(eb); f->dag_events = 1; }
         k_first = 2 * f->dag_nsteps;
     }
@@ -1357,14 +1369,62 @@ static int info_status(cocons_fit *f)
         fprintf(stderr, "cocons: hand-off time-out, code 0x%x\n", f->hinfo[1]);
         if (f->dag_used && f->ddag && (f->hinfo[1] & 0xf00) >= 0xa00) {
             // a wait of the DAG launch: what it waited for (dag_wait's record) and what the word holds NOW
-            unsigned rec[6] = {0, 0, 0, 0, 0, 0}, now = 0, qn = 0;
+            unsigned rec[7] = {0, 0, 0, 0, 0, 0, 0}, now = 0, qn = 0;
             hipMemcpyAsync(rec, f->ddag + 8, sizeof rec, hipMemcpyDeviceToHost, f->stream);
             hipStreamSynchronize(f->stream);
             if (rec[2] < f->ddag_words) hipMemcpyAsync(&now, f->ddag + rec[2], sizeof now, hipMemcpyDeviceToHost, f->stream);
             hipMemcpyAsync(&qn, f->ddag, sizeof qn, hipMemcpyDeviceToHost, f->stream);
             hipStreamSynchronize(f->stream);
-            fprintf(stderr, "cocons: DAG wait: task %u (of %u, counter now %u) code 0x%x waited for word %u >= %u, saw %u, holds %u now\n",
-                    rec[0], f->dag_ntasks, qn, rec[1], rec[2], rec[3], rec[4], now);
+            fprintf(stderr, "cocons: DAG wait: task %u (of %u, counter now %u) code 0x%x waited for word %u >= %u, saw %u, holds %u now; "
+                    "%.1f ms, %u polls\n", rec[0], f->dag_ntasks, qn, rec[1], rec[2], rec[3], rec[4], now, rec[5] * 1e-5, rec[6]);
+            if (const char *dump = getenv("COCONS_DEBUG_ABORT_DUMP")) {
+                // everything an offline look needs (tools/dag_abort.py): header, record, step table, all task words, the engine's
+                // flag words, and with tracing on the stamps of every task and of the engine
+                static int ndump = 0;
+                char path[512];
+                snprintf(path, sizeof path, "%s.%d", dump, ndump++);
+                if (FILE *fp = fopen(path, "wb")) {
+                    const unsigned ntr = (tun().dag_trace && f->ddag_trace) ? 1u : 0u;
+                    unsigned hdr[16] = {0xDA6D0001u, (unsigned)f->nt, (unsigned)f->dag_nsteps, f->dag_ntasks, (unsigned)f->ddag_words,
+                                        (unsigned)f->flags_cap, ntr, (unsigned)f->hinfo[1], qn, now, 0, 0, 0, 0, 0, 0};
+                    fwrite(hdr, sizeof hdr, 1, fp);
+                    fwrite(rec, sizeof rec, 1, fp);
+                    std::vector<DagStepHost> sh((size_t)f->dag_nsteps);
+                    hipMemcpyAsync(sh.data(), f->ddag_steps, sh.size() * sizeof(DagStepHost), hipMemcpyDeviceToHost, f->stream);
+                    std::vector<unsigned> w((size_t)f->ddag_words), fl(4 * (size_t)f->flags_cap + 64);
+                    hipMemcpyAsync(w.data(), f->ddag, w.size() * sizeof(unsigned), hipMemcpyDeviceToHost, f->stream);
+                    hipMemcpyAsync(fl.data(), f->dflags, fl.size() * sizeof(unsigned), hipMemcpyDeviceToHost, f->stream);
+                    hipStreamSynchronize(f->stream);
+                    fwrite(sh.data(), sizeof(DagStepHost), sh.size(), fp);
+                    fwrite(w.data(), sizeof(unsigned), w.size(), fp);
+                    fwrite(fl.data(), sizeof(unsigned), fl.size(), fp);
+                    if (ntr) {
+                        std::vector<unsigned long long> st((size_t)f->dag_ntasks * 5 + 8 * (size_t)(f->nt + 2));
+                        hipMemcpyAsync(st.data(), f->ddag_trace, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, f->stream);
+                        hipStreamSynchronize(f->stream);
+                        fwrite(st.data(), sizeof(unsigned long long), st.size(), fp);
+                    }
+                    fclose(fp);
+                    fprintf(stderr, "cocons: state written to %s\n", path);
+                }
+            }
+            if (tun().dag_trace && f->ddag_trace && !getenv("COCONS_DEBUG_ABORT_DUMP")) {
+                // which tasks were drawn and never finished (stamps: drawn, inputs complete, product done, stored)
+                std::vector<unsigned long long> st((size_t)f->dag_ntasks * 4);
+                hipMemcpyAsync(st.data(), f->ddag_trace, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, f->stream);
+                hipStreamSynchronize(f->stream);
+                unsigned long long tmin = ~0ull;
+                for (size_t i = 0; i < st.size(); i += 4) if (st[i] && st[i] < tmin) tmin = st[i];
+                int shown = 0;
+                for (unsigned L = 0; L < f->dag_ntasks && shown < 40; ++L) {
+                    const unsigned long long *q = &st[(size_t)L * 4];
+                    if (q[0] && !q[3]) {
+                        fprintf(stderr, "   unfinished task %u: drawn %.1f us, inputs %s, product %s\n", L, (q[0] - tmin) * 0.01,
+                                q[1] ? "complete" : "WAITING", q[2] ? "done" : "-");
+                        ++shown;
+                    }
+                }
+            }
         }
     }
     if (f->hinfo[1] != 0)

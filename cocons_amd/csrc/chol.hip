@@ -404,9 +404,26 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
 // Every spin is bounded: after ENGINE_TIMEOUT_TICKS of the 100 MHz constant clock the waiter sets the
 // abort word and every party leaves; the host then repeats the factorisation on the plain schedule
 // instead of hanging the GPU.  A legitimate wait lasts at most one trailing-update launch (< 1 ms).
+#ifndef ENGINE_TIMEOUT_TICKS
 #define ENGINE_TIMEOUT_TICKS 10000000ull    // 100 ms
+#endif
 #define GATE_TIMEOUT_TICKS 500000ull        // 5 ms: the engine is resident within microseconds or -- every CU taken by
                                             // someone else's kernels -- not for a long while
+// What a wait is bounded by is the waiter's OWN spinning, not the wall clock: a poll costs >= ~0.6 us (s_sleep 16 = 0.43 us plus
+// the load's round trip), so `ticks` of the 100 MHz clock are converted into ticks / 100 polls.  Why: the driver now and
+// then pauses every queue of the process in mid-kernel -- all waves saved, restored about 0.9 ms later on other CUs (round 4:
+// seen in the task stamps of the DAG launch about once per 4000 evaluations on this pool; dag_kernel's header has the rest
+// of that story).  A waiter that stands still does not poll, so a pause of whatever length never turns into a time-out; a
+// true deadlock still ends after ticks / 100 polls, and WALL_BACKSTOP_TICKS ends anything else.
+#define WALL_BACKSTOP_TICKS 500000000ull    // 5 s
+
+// (diagnostics) where a wave runs: XCC id in bits 28..31, HW_ID (wave, SIMD, CU, SH, SE ...) below
+__device__ __forceinline__ unsigned hw_where()
+{
+    unsigned x, h;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(x), "=s"(h));
+    return (x << 28) | (h & 0x0fffffffu);
+}
 
 __device__ __forceinline__ void signal_add(unsigned *word)
 {
@@ -437,10 +454,11 @@ __device__ __forceinline__ bool wait_ge(unsigned *word, unsigned need, unsigned 
                                         unsigned long long ticks = ENGINE_TIMEOUT_TICKS)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned max_polls = (unsigned)(ticks / 100ull);
     for (unsigned it = 0;; ++it) {
         if (poll_word(word, it) >= need) break;
         if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) {
+        if (it > max_polls || ((it & 1023u) == 1023u && __builtin_amdgcn_s_memrealtime() - t0 > WALL_BACKSTOP_TICKS)) {
             __hip_atomic_store(abort_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -545,14 +563,21 @@ potrf_engine_kernel(EngineArgs e)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *A = e.A;
     const size_t lda = e.lda;
-    if (tid == 0) __hip_atomic_store(e.alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the word also says WHERE: 1 + the id of the XCD the workgroup runs on -- dag_kernel keeps that XCD less than full)
+    if (tid == 0) __hip_atomic_store(e.alive, 1u + (hw_where() >> 28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int t = e.t0; t < e.nt; t += 2) {
         if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
         unsigned long long *tr = (DAG && e.trace) ? e.trace + 8 * (size_t)(t >> 1) : nullptr;
-        if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
+        if (tr && tid == 0) {
+            tr[0] = __builtin_amdgcn_s_memrealtime();
+            // (the unused record of pair 0: where the engine ran first, where it runs now, the pair at which that changed)
+            const unsigned long long w = hw_where();
+            if (e.trace[0] == 0) e.trace[0] = w;
+            if (e.trace[1] != w) { e.trace[1] = w; e.trace[2] = (unsigned long long)(t >> 1); }
+        }
         potrf_tile_body<true>(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem, QALL);
         __syncthreads();
         if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
@@ -996,6 +1021,8 @@ struct DagStep {
     int k0, K;              // the panel: columns [k0, k0 + K)
     int nstrip, two;        // next panel: 64-row strips below its diagonal block; the block has a second tile
     int need;               // pdone count at which a strip of THIS step's panel is complete (step 0: unused)
+    int nd_next;            // "early half" tasks in this step's list: the diagonal-block tiles of the NEXT step, first 128 panel columns
+    int split;              // this step's diagonal-block tiles only take the last 128 panel columns and add the early half's result
 };
 
 struct DagArgs {
@@ -1008,15 +1035,20 @@ struct DagArgs {
     unsigned *tdone;                 // per 64-tile (i >= j) at i (i + 1) / 2 + j: update steps applied
     unsigned *pdone; int pstride;    // per panel p and strip: panel tasks finished
     unsigned *pall;                  // per panel p: strips complete (a workgroup that has seen pall[p] = all of them asks no more)
+    double *partbuf;                 // early halves of the diagonal-block tiles: 2 (step parity) x 16 tiles x 64 x 64 doubles
+    unsigned *dcount;                // per step and diagonal-block tile (16 words per step): early halves finished
     unsigned *sig;                   // the engine's in[] words
     unsigned *out, *xr;              // the engine's out[] / xr[] words
     unsigned *abort_word;
+    const unsigned *alive;           // the engine's alive word: 1 + the XCD it runs on
+    unsigned xcc_quota;              // workgroups that take part on that XCD (0: all)
+    unsigned *hw;                    // diagnostics (may be null): per task hw_where() when drawn and when stored
     unsigned long long *trace;       // diagnostics (may be null): per task 4 stamps of the 100 MHz clock -- drawn, inputs
                                      // complete, product done and previous C version there, stored and signalled
 };
 
 // a bounded wait of dag_kernel: like wait_ge<false>, and when it runs out the waiter leaves a record in words 8 .. 13 of the
-// task-word block (a.queue + 8): task, code, index of the word it waited for, value needed, value seen, low bits of the clock
+// task-word block (a.queue + 8): task, code, index of the word it waited for, value needed, value seen, wall ticks, polls
 __device__ __forceinline__ bool dag_wait(const DagArgs &a, unsigned *word, unsigned need, unsigned code, unsigned L)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -1024,11 +1056,13 @@ __device__ __forceinline__ bool dag_wait(const DagArgs &a, unsigned *word, unsig
         const unsigned v = poll_word(word, it);
         if (v >= need) break;
         if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > ENGINE_TIMEOUT_TICKS) {
+        if (it > (unsigned)(ENGINE_TIMEOUT_TICKS / 100ull) ||
+            ((it & 1023u) == 1023u && __builtin_amdgcn_s_memrealtime() - t0 > WALL_BACKSTOP_TICKS)) {
             if (__hip_atomic_exchange(a.abort_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 unsigned *d = a.queue + 8;
                 d[0] = L; d[1] = code; d[2] = (unsigned)(word - a.queue); d[3] = need; d[4] = v;
-                d[5] = (unsigned)__builtin_amdgcn_s_memrealtime();
+                d[5] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0);      // ticks of 10 ns this wait lasted
+                d[6] = it;
             }
             return false;
         }
@@ -1056,7 +1090,27 @@ dag_kernel(DagArgs a)
     // workgroups asking one word at the same instant cost ~8 us -- once per factorisation here, not per launch): whatever
     // part of the grid the chip holds at a given moment (another process may own CUs) then works on the LOWEST undrawn
     // tasks, and every dependency points downwards in the order -- no placement can deadlock
-    if (tid == 0) share[1] = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    //
+    // The XCD that also hosts the engine is kept LESS THAN FULL: of the workgroups that land there only the first
+    // `xcc_quota` take part, the others leave at once.  Why: the driver now and then pauses all queues of a process in
+    // mid-kernel -- every wave is saved and restored about 0.9 ms later, on other CUs than before (on this pool about once
+    // per 4000 evaluations; the stamps of such an evaluation show every workgroup standing still for that long and coming
+    // back somewhere else).  An XCD that runs kernels of TWO queues does not hold eight of these workgroups on every CU
+    // (227 instead of 248 beside the engine's CU; which CUs take seven depends on where the engine sits), so after a
+    // restore that moved the engine the same set of workgroups need not fit again: one or two stay saved until
+    // somebody leaves -- holding tasks everything else waits for, so nobody leaves until the bounded waits give up (round 4's
+    // soak runs: 1 evaluation in 7000 repeated on the plain schedule; tools/dag_abort.py shows the picture).  With the
+    // quota that XCD has a few CUs' worth of room in every placement, and no workgroup of the grid is ever waiting in the
+    // dispatcher for a slot there (the others XCDs hold their 255 at eight per CU, before and after).
+    if (tid == 0) {
+        bool take = true;
+        if (a.xcc_quota) {
+            const unsigned ex = __hip_atomic_load(a.alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ex == 1u + (hw_where() >> 28))
+                take = __hip_atomic_fetch_add(a.queue + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.xcc_quota;
+        }
+        share[1] = take ? __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+    }
     __syncthreads();
     unsigned L = (unsigned)__builtin_amdgcn_readfirstlane((int)share[1]);
     __syncthreads();
@@ -1071,15 +1125,19 @@ dag_kernel(DagArgs a)
         const int s = lo;
         const DagStep st = steps[s];
         const unsigned q = L - st.base;
-        if (a.trace && tid == 0) a.trace[4 * (size_t)L] = __builtin_amdgcn_s_memrealtime();
+        if (a.trace && tid == 0) {
+            a.trace[4 * (size_t)L] = __builtin_amdgcn_s_memrealtime();
+            if (a.hw) a.hw[2 * (size_t)L] = hw_where();
+        }
         const int t = st.tj0 >> 1;                           // first 128-tile of the next block
         const bool isT = q >= st.tpos && q < st.tpos + st.nT;
         const double *gIb, *gJb;
-        unsigned ldib, ldjb;                                 // leading dimensions in bytes
-        int K, i_wt = 0, store_only = 0;
+        unsigned ldib, ldjb, ldob = ldab;                    // leading dimensions in bytes (operands, output)
+        int K, i_wt = 0, store_only = 0, strip_task = 0;
         double *Cb;                                          // the task's 64 x 64 output tile
-        unsigned *w0 = nullptr, *w1 = nullptr, *w2 = nullptr, *we = nullptr, *dn;
-        unsigned n0 = 0, n1 = 0, n2 = 0, ne = 0, dval = 0;   // dval != 0: store dval to *dn; 0: add 1
+        const double *pa = nullptr;                          // finisher of a split diagonal-block tile: the early half's result
+        unsigned *w0 = nullptr, *w1 = nullptr, *w2 = nullptr, *we = nullptr, *we2 = nullptr, *dn;
+        unsigned n0 = 0, n1 = 0, n2 = 0, ne = 0, dval = 0;   // dval != 0: raise *dn to dval; 0: add 1
         int sigT = -1;                                       // >= 0: the tile lies in the next diagonal block: raise sig[sigT]
         int prio = 0;
         if (!isT) {
@@ -1105,17 +1163,50 @@ dag_kernel(DagArgs a)
             we = a.tdone + (ti * (ti + 1) / 2 + tj); ne = (unsigned)s;
             dn = we; dval = (unsigned)s + 1u;
             const int Ti = (ti >> 1) - t, Tj = (tj >> 1) - t;
-            if (Ti >= 0 && Ti <= 1 && Tj >= 0 && Tj <= Ti) { sigT = t + Ti; prio = 3; }
+            if (Ti >= 0 && Ti <= 1 && Tj >= 0 && Tj <= Ti) {
+                sigT = t + Ti; prio = 3;
+                if (st.split) {
+                    // One of the ten tiles the next diagonal block waits for.  Under load a tile's product is memory latency
+                    // per 8-column chunk (60 us for 256 columns, whatever its priority), and these ten sit on the chain between
+                    // two diagonal blocks: their FIRST 128 panel columns (X0: complete as soon as T1 is, long before the
+                    // engine has finished the block) were multiplied by an "early half" task in the previous step's list;
+                    // this task takes the last 128 columns and subtracts both halves in a fixed order.
+                    const int ta = ti - st.tj0, tb = tj - st.tj0, dd = ta * (ta + 1) / 2 + tb;
+                    gIb += (size_t)TILE * a.lda; gJb += (size_t)TILE * a.lda; K = TILE;
+                    pa = a.partbuf + ((size_t)(s & 1) * 16 + dd) * (TM * TM);
+                    we2 = a.dcount + (size_t)s * 16 + dd;
+                }
+            }
         } else {
-            const unsigned u = q - st.tpos;
+            unsigned u = q - st.tpos;
             const int per = 2 * st.nstrip;
-            const int stage = (int)(u / (unsigned)per), rem = (int)(u % (unsigned)per);
-            const int strip = rem >> 1, h = rem & 1;
-            const int row64 = st.tj0 + (st.two ? 4 : 2) + strip;
             const size_t c_t = (size_t)t * TILE, c_t1 = c_t + TILE;
-            dn = a.pdone + (size_t)(s + 1) * a.pstride + strip;
             prio = 2;
-            if (stage == 0) {            // T1: X0(:, half h of tile t) = B0 W(t)^T
+            int stage, strip = 0, h = 0, row64 = 0;
+            if (u >= (unsigned)per && u < (unsigned)(per + st.nd_next)) {
+                stage = 3;               // early half of a diagonal-block tile of the NEXT step
+            } else {
+                if (u >= (unsigned)per) u -= (unsigned)st.nd_next;
+                stage = (int)(u / (unsigned)per);
+                const int rem = (int)(u % (unsigned)per);
+                strip = rem >> 1; h = rem & 1;
+                row64 = st.tj0 + (st.two ? 4 : 2) + strip;
+                strip_task = 1;
+            }
+            dn = a.pdone + (size_t)(s + 1) * a.pstride + strip;
+            if (stage == 3) {
+                const int dd = (int)(q - st.tpos) - per;
+                const int ta = c_tri_ib[dd], tb = dd - ta * (ta + 1) / 2;
+                const int tj0n = st.tj0 + 4;                           // the next step's trapezoid (this block has two tiles)
+                const size_t k0n = (size_t)(s + 1) * 2 * TILE;         // its panel's first column
+                gIb = a.P + (size_t)(tj0n + ta) * TM + k0n * a.lda; ldib = ldab;
+                gJb = a.P + (size_t)(tj0n + tb) * TM + k0n * a.lda; ldjb = ldab;
+                K = TILE;
+                Cb = a.partbuf + ((size_t)((s + 1) & 1) * 16 + dd) * (TM * TM); store_only = 1; ldob = 8u * TM;
+                w0 = a.pdone + (size_t)(s + 1) * a.pstride + ta; n0 = 2u;      // both T1 of the two strips: X0 complete
+                w1 = a.pdone + (size_t)(s + 1) * a.pstride + tb; n1 = 2u;
+                dn = a.dcount + (size_t)(s + 1) * 16 + dd;
+            } else if (stage == 0) {     // T1: X0(:, half h of tile t) = B0 W(t)^T
                 gIb = a.A + (size_t)row64 * TM + c_t * a.lda; ldib = ldab; i_wt = 1;
                 gJb = a.Wt + (size_t)t * TILE * TILE + TM * h; ldjb = 8u * TILE;
                 K = TM * (h + 1);
@@ -1224,6 +1315,7 @@ dag_kernel(DagArgs a)
             const unsigned Ln = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight during the poll)
             unsigned ok = 1u;
             if (we) ok = dag_wait(a, we, ne, 0xd00u + (unsigned)s, L) ? 1u : 0u;
+            if (ok && we2) ok = wait_ge<false>(we2, 1u, a.abort_word, 0xe00u + (unsigned)s) ? 1u : 0u;   // (no record: a second dag_wait costs the kernel its scratch-free allocation)
             share[0] = ok; share[1] = Ln;
             if (a.trace) a.trace[4 * (size_t)L + 2] = __builtin_amdgcn_s_memrealtime();
         }
@@ -1233,8 +1325,8 @@ dag_kernel(DagArgs a)
         const unsigned Lnext = share[1];
         if (!okE) return;
         // ---- epilogue: the wave's 32 x 32 part of the tile, one accumulator block at a time (loads first, then stores)
-        double *Cw = Cb + (size_t)((TM / 2) * wi) + (size_t)((TM / 2) * wj) * a.lda;
-        unsigned cve = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldab;
+        double *Cw = (double *)((char *)(Cb + (TM / 2) * wi) + (size_t)((TM / 2) * wj) * ldob);
+        unsigned cve = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldob;
         asm volatile("" : "+v"(cve));
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -1245,12 +1337,23 @@ dag_kernel(DagArgs a)
                 else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        cv[r] = load_wt((const double *)((const char *)(Cw + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldab)));
-                    cv -= acc[x][y];
+                        cv[r] = load_wt((const double *)((const char *)(Cw + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldob)));
+                    if (pa) {
+                        // (offsets re-derived here from the laundered output offset: nothing extra lives through the product)
+                        const double *Pw = pa + (TM / 2) * wi + (TM / 2) * wj * TM;
+                        int ln;
+                        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                        const unsigned cvp = 8u * (unsigned)(ln & 15) + (unsigned)(ln >> 4) * (8u * TM);
+                        d4 pv;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            pv[r] = load_wt((const double *)((const char *)(Pw + 16 * x) + (cvp + (unsigned)(16 * y + 4 * r) * (8u * TM))));
+                        cv -= pv + acc[x][y];                 // (early half + late half, then off C: one fixed order)
+                    } else cv -= acc[x][y];
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    store_wt((double *)((char *)(Cw + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldab)), cv[r]);
+                    store_wt((double *)((char *)(Cw + 16 * x) + (cve + (unsigned)(16 * y + 4 * r) * ldob)), cv[r]);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1262,9 +1365,12 @@ dag_kernel(DagArgs a)
             // then read a stale value for as long as it kept polling: 2 time-outs in 16 000 evaluations, caught with
             // dag_wait's record: "waited for word 9646 >= 2, saw 1, holds 2 now".)
             if (dval) __hip_atomic_fetch_max(dn, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else if (__hip_atomic_fetch_add(dn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (st.two ? 6u : 2u))
+            else if (__hip_atomic_fetch_add(dn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (st.two ? 6u : 2u) && strip_task)
                 __hip_atomic_fetch_add(a.pall + s + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the strip is complete
-            if (a.trace) a.trace[4 * (size_t)L + 3] = __builtin_amdgcn_s_memrealtime();
+            if (a.trace) {
+                a.trace[4 * (size_t)L + 3] = __builtin_amdgcn_s_memrealtime();
+                if (a.hw) a.hw[2 * (size_t)L + 1] = hw_where();
+            }
         }
         L = (unsigned)__builtin_amdgcn_readfirstlane((int)Lnext);
         if (L >= a.ntasks) break;
@@ -1619,7 +1725,7 @@ void launch_pack_rows(const double *A, size_t lda, int col0, int ncols, double *
 // Steps for a factorisation with nt column tiles and mt row tiles (trim64: the last 64 rows hold nothing), first panel
 // (tiles 0, 1) already formed in place; kskip leading columns of it are unit vectors (front padding) and are skipped.
 // lead: far tiles of a step in front of its panel tasks.  Returns the number of tasks.
-unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, std::vector<DagStepHost> &out)
+unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, int split, std::vector<DagStepHost> &out)
 {
     out.clear();
     unsigned base = 0;
@@ -1646,6 +1752,7 @@ unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int mi
         st.k0 = k * TILE + (k == 0 ? kskip : 0);
         st.K = 2 * TILE - (k == 0 ? kskip : 0);
         st.need = prev_two ? 6 : 2;
+        st.nd_next = 0; st.split = 0;
         st.base = base;
         base += (unsigned)tiles + st.nT;
         prev_two = st.two;
@@ -1656,12 +1763,28 @@ unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int mi
         base -= l.nT;
         l.nT = 0; l.nstrip = 0;
     }
+    if (split) {
+        // the diagonal-block tiles of step s + 1 in two halves: the early one rides in step s's list behind its T1 tasks.
+        // (steps from 1 on: K = 256 there; step s must form the panel of s + 1, i.e. have panel tasks)
+        unsigned shift = 0;
+        for (size_t s = 0; s < out.size(); ++s) {
+            out[s].base += shift;
+            if (s + 1 < out.size() && out[s].nT > 0 && out[s].two) {
+                out[s].nd_next = out[s + 1].two ? 10 : 3;
+                out[s].nT += (unsigned)out[s].nd_next;
+                out[s + 1].split = 1;
+                shift += (unsigned)out[s].nd_next;
+            }
+        }
+        base += shift;
+    }
     return base;
 }
 
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
-                unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, unsigned *sig, unsigned *out,
-                unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace)
+                unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, double *partbuf, unsigned *dcount,
+                unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace,
+                const unsigned *alive, int xcc_quota, unsigned *hw)
 {
     static_assert(sizeof(DagStepHost) == sizeof(DagStep), "host and device step records");
     if (nsteps <= 0 || ntasks == 0) return;
@@ -1669,7 +1792,8 @@ void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagSte
     a.A = A; a.lda = lda; a.P = P; a.Wt = Wt;
     a.steps = (const DagStep *)dsteps; a.nsteps = nsteps; a.ntasks = ntasks;
     a.queue = queue; a.tdone = tdone; a.pdone = pdone; a.pstride = pstride; a.pall = pall;
-    a.sig = sig; a.out = out; a.xr = xr; a.abort_word = abort_word; a.trace = trace;
+    a.partbuf = partbuf; a.dcount = dcount;
+    a.sig = sig; a.out = out; a.xr = xr; a.abort_word = abort_word; a.trace = trace; a.hw = trace ? hw : nullptr;
     static int slots = 0;
     if (!slots) {
         int dev = 0, cus = 256;
@@ -1678,6 +1802,7 @@ void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagSte
         slots = 8 * cus;
     }
     const unsigned cap = (unsigned)(slots - 8);          // one CU's worth fewer: the engine owns a CU
+    a.alive = alive; a.xcc_quota = (alive && xcc_quota > 0) ? (unsigned)xcc_quota : 0u;
     hipLaunchKernelGGL(dag_kernel, dim3(ntasks < cap ? ntasks : cap), dim3(256), 0, s, a);
 }
 

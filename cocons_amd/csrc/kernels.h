@@ -179,16 +179,20 @@ void launch_pack_rows(const double *A, size_t lda, int col0, int ncols, double *
 // panel behind the first one.  DagStepHost mirrors the device record (see DagStep in chol.hip for the meaning).
 struct DagStepHost {
     unsigned base, near, tpos, nT;
-    int H, W, tj0, k0, K, nstrip, two, need;
+    int H, W, tj0, k0, K, nstrip, two, need, nd_next, split;
 };
 // only the leading steps with at least min_tiles update tiles are taken (the head of the factorisation); the last of them has
 // no panel tasks: the panel behind it is left to the caller's classic kernels
-unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, std::vector<DagStepHost> &out);
+// split != 0: the diagonal-block tiles of the steps from 1 on are computed in two halves (nd_next / split, see DagStep)
+unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, int split, std::vector<DagStepHost> &out);
 // dsteps: DEVICE copy of the table.  queue, tdone (2 mt (2 mt + 1) / 2 words), pdone ((nsteps + 1) * pstride words,
 // pstride >= 2 mt), pall (nsteps + 1 words): zero at launch.  sig / out / xr: the engine's words (launch_potrf_engine with wbuf = Wt, pbuf = P).
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
-                unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, unsigned *sig, unsigned *out,
-                unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace = nullptr);
+                unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, double *partbuf, unsigned *dcount,
+                unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace = nullptr,
+                const unsigned *alive = nullptr, int xcc_quota = 0, unsigned *hw = nullptr);
+                // alive: the engine's alive word (1 + its XCD); xcc_quota: workgroups of the launch that take part on that XCD
+                // partbuf: 2 x 16 x 64 x 64 doubles; dcount: 16 words per step (+ 1 step), zero at launch
 
 // reductions: out[0] = sum_{i<n} log(A(i,i)); out[1 + a*nr + b] = sum_{c<n} A(row0+a,c) A(row0+b,c)
 void launch_finalize(const double *A, size_t lda, int n, int row0, int nr, double *out, hipStream_t s,

@@ -24,7 +24,7 @@ def dag_on():
     _tune("dag_min_tiles", 0)
     yield
     _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
-    _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "4000")))
+    _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "3000")))
 
 
 def _grid(gx, gy):
@@ -125,7 +125,7 @@ def test_dag_changing_parameters_stay_reproducible(dag_on):
     fit.close()
 
 
-@pytest.mark.parametrize("g,min_tiles", [(64, 1000), (100, 6000)])
+@pytest.mark.parametrize("g,min_tiles", [(64, 1000), (100, 3000)])
 def test_dag_head_then_classic(g, min_tiles):
     """The shipped form: the DAG launch for the head of the factorisation (steps of at least `min_tiles` update tiles), the
     classic schedule behind it -- n = 4096 with a three-step head, and the benchmark size with the default threshold -- against
@@ -151,5 +151,37 @@ def test_dag_head_then_classic(g, min_tiles):
         assert es["retries"] == 0 and es["active"]
     finally:
         _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
-        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "4000")))
+        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "3000")))
+        fit.close()
+
+
+def test_dag_xcd_quota_changes_nothing_but_who_works():
+    """dag_kernel keeps the engine's XCD less than full (COCONS_DAG_XCC_QUOTA workgroups take part there, the others leave
+    at once -- room for the driver's save / restore of the queues, chol.hip): which workgroup computes a task does not
+    enter the result, so no quota (0), the default and a tiny one (8 of the 255 that land there) give the same bits."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    g = 72
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    z = wl.synthetic_z(g * g)
+    th = wl.theta_full()
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    default = int(os.environ.get("COCONS_DAG_XCC_QUOTA", "208"))
+    _tune("dag", 1)
+    _tune("dag_min_tiles", 0)
+    try:
+        vals = []
+        for q in (default, 0, 8, default):
+            _tune("dag_xcc_quota", q)
+            vals.append(fit.neg2loglik_core(th)[0])
+            st = fit.profile_stages(th, reps=1)
+            assert st["dag_ms"] > 0
+        assert len(set(vals)) == 1, vals
+        es = fit.engine_state()
+        assert es["retries"] == 0 and es["active"]
+    finally:
+        _tune("dag_xcc_quota", default)
+        _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
+        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "3000")))
         fit.close()

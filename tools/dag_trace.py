@@ -36,7 +36,7 @@ def main():
     ns = ctypes.c_int(0)
     nt = L.cocons_debug_dag_trace(fit._h, ctypes.byref(ns), None, None, None)
     assert nt > 0, _lib.last_error()
-    steps = np.zeros((ns.value, 12), dtype=np.int32)
+    steps = np.zeros((ns.value, 14), dtype=np.int32)
     st = np.zeros((nt, 4), dtype=np.uint64)
     eng = np.zeros((8 * (2 * ns.value + 8),), dtype=np.uint64)
     ntile = (g * g + 127) // 128
@@ -58,14 +58,17 @@ def main():
     prev_t3c = 0.0
     for s in range(ns.value):
         base, near, tpos, nT = [int(v) for v in steps[s].view(np.uint32)[:4]]
-        H, W, tj0, k0, K, nstrip, two, need = [int(v) for v in steps[s][4:]]
+        H, W, tj0, k0, K, nstrip, two, need, nd_next, split = [int(v) for v in steps[s][4:]]
         nxt = int(steps[s + 1].view(np.uint32)[0]) if s + 1 < ns.value else nt
         rows = T[base:nxt]
         q = np.arange(nxt - base)
         isT = (q >= tpos) & (q < tpos + nT)
         u = q - tpos
-        stage = np.where(isT, u // max(1, 2 * nstrip), -1)
-        strip = np.where(isT, (u % max(1, 2 * nstrip)) // 2, -1)
+        per = max(1, 2 * nstrip)
+        early = isT & (u >= per) & (u < per + nd_next)          # early halves of the next step's diagonal-block tiles
+        u2 = np.where(u >= per + nd_next, u - nd_next, u)
+        stage = np.where(isT & ~early, u2 // per, -1)
+        strip = np.where(isT & ~early, (u2 % per) // 2, -1)
         isnear = (~isT) & (q < near)
         isfar = (~isT) & ~isnear
         # diagonal-block tiles: column jl < 4, row offset jl + r < 4
@@ -83,7 +86,8 @@ def main():
             r = rows[m]
             return (np.mean(r[:, 1] - r[:, 0]), np.mean(r[:, 2] - r[:, 1]), np.mean(r[:, 3] - r[:, 2]))
         sf = stats(isfar)
-        for name, m in (("diag", isdiag), ("near", isnear & ~isdiag), ("far", isfar), ("T1", stage == 0), ("T2", stage == 1), ("T3", stage == 2)):
+        for name, m in (("diag", isdiag), ("near", isnear & ~isdiag), ("far", isfar), ("T1", stage == 0), ("T2", stage == 1), ("T3", stage == 2),
+                        ("early", early)):
             if m.any():
                 r = rows[m]
                 d = kinds_tot.setdefault(name, [0, 0.0, 0.0, 0.0])
