@@ -231,7 +231,7 @@ def main():
     es = fit.engine_state()
     engine = {"engine_active": es["active"], "engine_retries": es["retries"], "engine_last_abort": es["last_abort"],
               "switches": {k: os.environ.get(k) for k in ("COCONS_ENGINE", "COCONS_UPD_DYNAMIC", "COCONS_UPD_WAVES",
-                                                         "COCONS_UPD_W8_MAX_TILES", "COCONS_DAG", "COCONS_DAG_MIN_TILES")
+                                                         "COCONS_UPD_W8_MAX_TILES", "COCONS_DAG", "COCONS_DAG_MIN_TILES", "COCONS_DAG_SPLIT", "COCONS_DAG_XCC_QUOTA")
                            if os.environ.get(k) is not None}}
 
     # Stage timings and the dominant kernel's roofline (HIP events on the launch stream around every stage and every
