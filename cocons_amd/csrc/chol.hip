@@ -151,8 +151,11 @@ __device__ __forceinline__ void rsqrt_pivot(double a, double &l, double &r)
     const double y = fma(y0 * t, fma(t, 0.375, 0.5), y0);
     double s = a * y;
     s = fma(fma(-s, s, a), 0.5 * y, s);      // s + (a - s^2) / (2 s)
-    l = (a > 0.0) ? s : __builtin_nan("");   // non-positive pivot: propagate NaN like sqrt would
-    r = (a > 0.0) ? y : __builtin_nan("");
+    // A pivot that is not a positive finite number comes out as NaN in both results WITHOUT being asked (like sqrt would):
+    // v_rsq_f64 gives NaN for a < 0, +-inf for +-0 (then a y0 = 0 inf = NaN) and 0 for +inf (inf 0 = NaN).  Rounds 1-3
+    // selected NaN explicitly: eight v_cndmask per pivot on the one wave every diagonal tile waits for.
+    l = s;
+    r = y;
 }
 
 // select among the lower-triangular 4x4 values by (c = row in group, k = column)
@@ -181,24 +184,24 @@ __device__ __forceinline__ void potrf16_step(d4 &D, double (&Q)[4], int lane, in
     // 4x4 Cholesky (dpotf2 order) -- identical on every lane.  Pivots through
     // rsqrt_pivot(): l = sqrt(a) and r = 1/l from one v_rsq_f64 seed (short dependent chain;
     // this loop is pure latency).
-    if (!(a00 > 0.0) && fail == 0) fail = 4 * S + 1;
     double l00, r0;
     rsqrt_pivot(a00, l00, r0);
     double l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
     double t11 = fma(-l10, l10, a11);
-    if (!(t11 > 0.0) && fail == 0) fail = 4 * S + 2;
     double l11, r1;
     rsqrt_pivot(t11, l11, r1);
     double l21 = fma(-l20, l10, a21) * r1, l31 = fma(-l30, l10, a31) * r1;
     double t22 = fma(-l21, l21, fma(-l20, l20, a22));
-    if (!(t22 > 0.0) && fail == 0) fail = 4 * S + 3;
     double l22, r2;
     rsqrt_pivot(t22, l22, r2);
     double l32 = fma(-l31, l21, fma(-l30, l20, a32)) * r2;
     double t33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a33)));
-    if (!(t33 > 0.0) && fail == 0) fail = 4 * S + 4;
     double l33, r3;
     rsqrt_pivot(t33, l33, r3);
+    // which pivot failed first is asked ONCE per group, behind the chain, and only looked into when the last pivot is not
+    // a positive number -- a bad pivot makes every later one NaN (the values are the same on every lane: a scalar branch)
+    if (__builtin_amdgcn_ballot_w64(!(t33 > 0.0)) != 0ull && fail == 0)
+        fail = 4 * S + (!(a00 > 0.0) ? 1 : (!(t11 > 0.0) ? 2 : (!(t22 > 0.0) ? 3 : 4)));
     // (An outer-product form with reciprocals on the dependent chain and the square roots refined beside it -- 3 x 6 + 12
     // dependent operations instead of 4 x 14 -- was measured in round 3: SLOWER, 4.54 -> 4.72 ms on the taper path, whose
     // time is half tile factorisations: one wave issues in order, and the variant has a quarter more instructions.)
