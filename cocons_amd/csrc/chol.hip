@@ -218,11 +218,14 @@ __device__ __forceinline__ void potrf16_step(d4 &D, double (&Q)[4], int lane, in
     double q = sel_lower4(c, k, m00, m10, m11, m20, m21, m22, m30, m31, m32, m33);
     q = ingrp ? q : 0.0;
     Q[S] = q;
-    // columns of group S:  X = D(:, group S) * inv(L4)^T ; exact values inside the diagonal sub-block
+    // columns of group S:  X = D(:, group S) * inv(L4)^T -- the rows of the diagonal sub-block too (D4 inv(L4)^T = L4: the
+    // block arrives SYMMETRIC, potrf_tile_body mirrors the diagonal blocks when it loads the tile and every update keeps
+    // them so), with exact zeros above the diagonal.  (Until round 4 those sixteen entries were selected from the scalar
+    // factor: a second ten-way select, twenty v_cndmask per group on the wave every diagonal tile waits for.)
     d4 z = {0.0, 0.0, 0.0, 0.0};
     d4 X = MFMA64(q, ds, z);
-    double lex = sel_lower4(c, k, l00, l10, l11, l20, l21, l22, l30, l31, l32, l33);
-    double xs = ingrp ? lex : ((m < 4 * S) ? 0.0 : X[S]);
+    (void)l11; (void)l22; (void)l33; (void)l00;
+    double xs = (m < 4 * S + k) ? 0.0 : X[S];
     // rank-4 update of the remaining columns (registers r > S)
     if (S < 3) {
         d4 U = MFMA64(xs, -xs, D);
@@ -289,13 +292,16 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
         const int i = tid & 15, k = (tid >> 4) & 15;
         const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
         const double *src = A + (size_t)(c0 + i) + (size_t)(c0 + k) * lda;
+        // (the eight DIAGONAL blocks are loaded symmetric -- their upper half mirrored from the lower, the only half of the
+        // matrix that holds data: potrf16_step takes the factor's diagonal sub-blocks out of a product that reads both)
+        const double *srcd = (i < k) ? A + (size_t)(c0 + k) + (size_t)(c0 + i) * lda : src;
         double v[18];
 #pragma unroll
         for (int t = 0; t < 18; ++t) {
             const int bb = 2 * t + half;
             const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
-            v[t] = WT ? load_wt(src + (size_t)(16 * ib) + (size_t)(16 * kb) * lda)
-                      : src[(size_t)(16 * ib) + (size_t)(16 * kb) * lda];
+            const double *sp = (ib == kb ? srcd : src) + (size_t)(16 * ib) + (size_t)(16 * kb) * lda;
+            v[t] = WT ? load_wt(sp) : *sp;
         }
 #pragma unroll
         for (int t = 0; t < 18; ++t) {
