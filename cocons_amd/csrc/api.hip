@@ -1560,7 +1560,7 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
     static int nslots_env = -1;
     if (nslots_env < 0) {
         const char *e = getenv("COCONS_BATCH_SLOTS");
-        nslots_env = e ? atoi(e) : 3;
+        nslots_env = e ? atoi(e) : 2;
         if (nslots_env < 1) nslots_env = 1;
         if (nslots_env > 8) nslots_env = 8;
     }
@@ -1574,11 +1574,13 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
         if (!c) { (void)hipGetLastError(); break; }
         f->slots->push_back(c);
     }
-    // several evaluations in flight already hide each other's panel chains; the resident engine is
-    // for an evaluation that has the GPU to itself
+    // Two evaluations in flight, each on the engine + DAG schedule (round 4; n = 10^4, 40 points: 123 evaluations/s against
+    // 105 one after the other -- the chain-bound tail of one runs beside the chip-filling head of the other).  Until round 3
+    // the slots ran the plain schedule, three deep: 106 (COCONS_BATCH_ENGINE=0 COCONS_BATCH_SLOTS=3); engine + 3 slots: 116,
+    // engine + 4: 122, plain + 2: 116.
     const bool engine_saved = f->engine_ok;
     static int batch_engine = -1;
-    if (batch_engine < 0) { const char *e = getenv("COCONS_BATCH_ENGINE"); batch_engine = e ? atoi(e) : 0; }
+    if (batch_engine < 0) { const char *e = getenv("COCONS_BATCH_ENGINE"); batch_engine = e ? atoi(e) : 1; }
     if (!batch_engine) {
         if (S > 1) f->engine_ok = false;
         for (auto c : *f->slots) c->engine_ok = false;

@@ -127,7 +127,7 @@ int cocons_neg2loglik_dense(cocons_fit *fit, const double *theta, const double *
  * finite-difference gradient, R/optim.R:237-259 with R/profile.R:11-12; getHessian's
  * 3 P (P+1)/2 points, R/getFunctions.R:979-1016).  thetas: nb x (6 p) row-major tables,
  * means: nb x p, values[nb] = sum_logliks of each, status[nb] = 0 or the failing minor k > 0.
- * Evaluations are pipelined over a few internal slots (COCONS_BATCH_SLOTS, default 3) so the
+ * Evaluations are pipelined over a few internal slots (COCONS_BATCH_SLOTS, default 2, each on the engine schedule) so the
  * latency-bound panel chain of one overlaps the updates and the assembly of the others.    */
 int cocons_neg2loglik_batch(cocons_fit *fit, int nb, const double *thetas, const double *means,
                             double *values, int *status);
