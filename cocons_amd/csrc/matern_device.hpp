@@ -149,6 +149,93 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         // 2^(1-nu) u^nu sqrt(pi / 2u) e^-u = sqrt(pi/2) 2^((nu - 1/2) log2 u + 1 - nu) e^-u: one exponential
         return 1.2533141373155002512 * pow2a_expmu(fma(nu - 0.5, log2(u), 1.0 - nu), u) * rg * S;
     }
+#ifndef COCONS_TRAP_ULO
+#define COCONS_TRAP_ULO 2.0
+#endif
+#ifndef COCONS_TRAP_UHI
+#define COCONS_TRAP_UHI 20.0
+#endif
+    if (u >= COCONS_TRAP_ULO && u < COCONS_TRAP_UHI && nu <= 3.5) {
+        // The middle band (round 4): the integral  e^u K_nu(u) = int_0^inf exp(-u (cosh t - 1)) cosh(nu t) dt  by the trapezoid
+        // rule, which converges geometrically for an analytic even integrand: with  1/h^2 = 1/0.22^2 + u/0.72^2  the
+        // discretisation error is below 4e-15 for nu <= 3.5 and 0.5 <= u <= 30 (mpmath, tests/test_gpu_parity.py), and the
+        // terms fall below one ulp of the sum after 13 (u = 8 .. 20) to 22 (u = 0.75) nodes.  Per node one exponential and
+        // two three-term recurrences -- cosh(j h) - 1 and cosh(nu j h) -- directly at order nu: no series set-up (Temme: a
+        // logarithm, an exponential, two reciprocals before the first term), no order recurrence, and a cost that hardly
+        // depends on u, where Steed's CF2 takes 6 steps at u = 19 and 50 at u = 2.1 (the band that made the assembly 2.5 ms
+        // at correlation range 1.0 against 1.2 ms at 0.05, n = 10^4).  Every term is positive: no cancellation anywhere.
+        const double L2E = 1.4426950408889634074;
+        const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+        double hh = fma(u, 1.0 / (0.72 * 0.72), 1.0 / (0.22 * 0.22));      // 1 / h^2
+        double h = __builtin_amdgcn_rsq(hh);
+        h = h * fma(fma(-hh * h, h, 1.0), 0.5, 1.0);                       // one Newton step: 48 bits, h is a free parameter
+        const double h2 = h * h;
+        // kappa = cosh(h) - 1 = h^2/2 (1 + h^2/12 (1 + h^2/30 (1 + h^2/56 (1 + h^2/90 (1 + h^2/132 (1 + h^2/182))))))
+        double kap = fma(h2, 1.0 / 182.0, 1.0);
+        kap = fma(kap * h2, 1.0 / 132.0, 1.0);
+        kap = fma(kap * h2, 1.0 / 90.0, 1.0);
+        kap = fma(kap * h2, 1.0 / 56.0, 1.0);
+        kap = fma(kap * h2, 1.0 / 30.0, 1.0);
+        kap = fma(kap * h2, 1.0 / 12.0, 1.0);
+        kap = kap * (0.5 * h2);
+        // cosh(nu h): |nu h| <= 0.77, Taylor polynomial in (nu h)^2 to degree 11 (0.77^24 / 24! = 3e-27)
+        const double xx = nu * h, x2 = xx * xx;
+        double chn = 1.0 / 51090942171709440000.0 * (1.0 / 22.0);         // 1/22!
+        chn = fma(chn, x2, 1.0 / 2432902008176640000.0);                   // 1/20!
+        chn = fma(chn, x2, 1.0 / 6402373705728000.0);                      // 1/18!
+        chn = fma(chn, x2, 1.0 / 20922789888000.0);                        // 1/16!
+        chn = fma(chn, x2, 1.0 / 87178291200.0);                           // 1/14!
+        chn = fma(chn, x2, 1.0 / 479001600.0);                             // 1/12!
+        chn = fma(chn, x2, 1.0 / 3628800.0);                               // 1/10!
+        chn = fma(chn, x2, 1.0 / 40320.0);                                 // 1/8!
+        chn = fma(chn, x2, 1.0 / 720.0);                                   // 1/6!
+        chn = fma(chn, x2, 1.0 / 24.0);                                    // 1/4!
+        chn = fma(chn, x2, 0.5);
+        chn = fma(chn, x2, 1.0);
+        const double tk = 2.0 * kap, tc = 2.0 * chn;
+        double c_prev = 0.0, c = kap;        // cosh(j h) - 1 for j - 1, j
+        double w_prev = 1.0, w = chn;        // cosh(nu j h)
+        double S = 0.5;
+        // exp(-u c): -u c = k ln 2 + r, e^r by its Taylor polynomial to degree 13 (|r| <= 0.347: 4e-18)
+        auto node_exp = [&](double cc) {
+            const double x = -u * cc;
+            const double k = rint(x * L2E);
+            double r = fma(-k, LN2_HI, x);
+            r = fma(-k, LN2_LO, r);
+            double pe = 1.0 / 6227020800.0;
+            pe = fma(pe, r, 1.0 / 479001600.0);
+            pe = fma(pe, r, 1.0 / 39916800.0);
+            pe = fma(pe, r, 1.0 / 3628800.0);
+            pe = fma(pe, r, 1.0 / 362880.0);
+            pe = fma(pe, r, 1.0 / 40320.0);
+            pe = fma(pe, r, 1.0 / 5040.0);
+            pe = fma(pe, r, 1.0 / 720.0);
+            pe = fma(pe, r, 1.0 / 120.0);
+            pe = fma(pe, r, 1.0 / 24.0);
+            pe = fma(pe, r, 1.0 / 6.0);
+            pe = fma(pe, r, 0.5);
+            pe = fma(pe, r, 1.0);
+            pe = fma(pe, r, 1.0);
+            return ldexp(pe, (int)k);
+        };
+        // two nodes per round, one test (a node too many costs less than asking after every one)
+        for (int j = 1; j < 64; j += 2) {
+            const double t1 = node_exp(c) * w;
+            const double c1 = fma(tk, c + 1.0, fma(2.0, c, -c_prev));
+            const double w1 = fma(tc, w, -w_prev);
+            const double t2 = node_exp(c1) * w1;
+            S += t1;
+            S += t2;
+            if (t2 < S * tol) break;
+            c_prev = c1; c = fma(tk, c1 + 1.0, fma(2.0, c1, -c));
+            w_prev = w1; w = fma(tc, w1, -w);
+        }
+        double rg = (n == 0) ? mu * gampl : gampl;
+        double prod = 1.0;
+        for (int k = 1; k < n; ++k) prod *= (mu + k);
+        rg = rg * fast_rcp(prod);
+        return pow2a_expmu(fma(nu, log2(u), 1.0 - nu), u) * rg * (S * h);
+    }
     double kmu, kmu1;                  // K_mu, K_{mu+1}, both WITHOUT the factor exp(-u) when u > 2
     double escale;                     // the factor still to be applied: exp(-u) (CF2) or 1 (Temme)
     double l2u;                        // log2(u) for the final power of two

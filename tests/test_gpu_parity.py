@@ -821,6 +821,28 @@ def test_device_matern_large_argument_branch_vs_mpmath():
     assert rel.max() < 1e-13, (rel.max(), nu[ok][rel.argmax()], u[ok][rel.argmax()])
 
 
+def test_device_matern_middle_band_vs_mpmath():
+    """The device routine's middle band, 2 <= u < 20 (round 4: the trapezoid rule on the integral representation, one
+    exponential per node, replaces Steed's continued fraction for nu <= 3.5) against 40-digit mpmath on a DENSE grid:
+    200 arguments across the band (both switch points and their neighbours included) x 15 orders -- tiny, half-integer,
+    integer, just beside them, the largest order the branch takes and the first one it leaves to the continued fraction."""
+    import mpmath as mp
+    from cocons_amd import _lib
+    mp.mp.dps = 40
+    us = np.concatenate([np.linspace(2.0, 20.0, 194), [1.9999999, 2.0000001, 19.9999999, 3.14159, 7.75, 12.5]])
+    nus = np.array([0.01, 0.1, 0.25, 0.5, 0.5000001, 0.9999999, 1.0, 1.3, 1.5, 2.0, 2.4999, 2.5, 3.0, 3.5, 3.5000001])
+    nu = np.repeat(nus, us.size)
+    u = np.tile(us, nus.size)
+    want = np.array([float(mp.power(2, 1 - mp.mpf(a)) / mp.gamma(mp.mpf(a)) * mp.power(mp.mpf(b), mp.mpf(a)) *
+                           mp.besselk(mp.mpf(a), mp.mpf(b))) for a, b in zip(nu, u)])
+    out = np.empty_like(u)
+    L = _lib.load()
+    _lib.check(L.cocons_debug_matern(u.size, nu.ctypes.data_as(_lib.c_dp), u.ctypes.data_as(_lib.c_dp),
+                                     out.ctypes.data_as(_lib.c_dp)), "cocons_debug_matern")
+    rel = np.abs(out - want) / want
+    assert rel.max() < 1e-13, (rel.max(), nu[rel.argmax()], u[rel.argmax()])
+
+
 def test_device_matern_asymptotic_stand_in_vs_mpmath():
     """u >= 706: the reference replaces K_nu by its leading asymptotic term, 2^(1-nu)/Gamma(nu) u^nu sqrt(pi/2u) e^-u
     (src/cocons_full.cpp:301-305).  The device routine forms it with its own exponential and reciprocal-gamma table, not
