@@ -135,11 +135,21 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         const double w = fast_rcp(u), p4 = 4.0 * nu * nu * w;
         double t = 1.0, S = 1.0;
 #pragma unroll
-        for (int k = 1; k <= HANKEL_TERMS; ++k) {
+        for (int k = 1; k <= HANKEL_TERMS / 2; ++k) {
             // t_k = t_{k-1} (4 nu^2 - (2k-1)^2) / (8 k u); the two constants fold at compile time
             const double Ak = 1.0 / (8.0 * k), Bk = (double)((2 * k - 1) * (2 * k - 1)) / (8.0 * k);
             t *= fma(p4, Ak, -Bk * w);
             S += t;
+        }
+        // (far out -- u >= 45 or so, most pairs of a short correlation range -- the tenth term is already below half an ulp of
+        // the sum and every later one is smaller still in this range of k: the second half is skipped by the waves that can)
+        if (fabs(t) > 1.0e-17 * S) {
+#pragma unroll
+            for (int k = HANKEL_TERMS / 2 + 1; k <= HANKEL_TERMS; ++k) {
+                const double Ak = 1.0 / (8.0 * k), Bk = (double)((2 * k - 1) * (2 * k - 1)) / (8.0 * k);
+                t *= fma(p4, Ak, -Bk * w);
+                S += t;
+            }
         }
         if (u >= 706.0) S = 1.0;
         double rg = (n == 0) ? mu * gampl : gampl;
@@ -157,7 +167,7 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
 #endif
     if (u >= COCONS_TRAP_ULO && u < COCONS_TRAP_UHI && nu <= 3.5) {
         // The middle band (round 4): the integral  e^u K_nu(u) = int_0^inf exp(-u (cosh t - 1)) cosh(nu t) dt  by the trapezoid
-        // rule, which converges geometrically for an analytic even integrand: with  1/h^2 = 1/0.22^2 + u/0.72^2  the
+        // rule, which converges geometrically for an analytic even integrand: with  1/h^2 = 1/0.24^2 + u/0.78^2  the
         // discretisation error is below 4e-15 for nu <= 3.5 and 0.5 <= u <= 30 (mpmath, tests/test_gpu_parity.py), and the
         // terms fall below one ulp of the sum after 13 (u = 8 .. 20) to 22 (u = 0.75) nodes.  Per node one exponential and
         // two three-term recurrences -- cosh(j h) - 1 and cosh(nu j h) -- directly at order nu: no series set-up (Temme: a
@@ -166,7 +176,7 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         // at correlation range 1.0 against 1.2 ms at 0.05, n = 10^4).  Every term is positive: no cancellation anywhere.
         const double L2E = 1.4426950408889634074;
         const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-        double hh = fma(u, 1.0 / (0.72 * 0.72), 1.0 / (0.22 * 0.22));      // 1 / h^2
+        double hh = fma(u, 1.0 / (0.78 * 0.78), 1.0 / (0.24 * 0.24));      // 1 / h^2
         double h = __builtin_amdgcn_rsq(hh);
         h = h * fma(fma(-hh * h, h, 1.0), 0.5, 1.0);                       // one Newton step: 48 bits, h is a free parameter
         const double h2 = h * h;
@@ -226,7 +236,7 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
             const double t2 = node_exp(c1) * w1;
             S += t1;
             S += t2;
-            if (t2 < S * tol) break;
+            if (t2 < S * (4.0 * tol)) break;       // (what is left behind the last node is a fraction of it)
             c_prev = c1; c = fma(tk, c1 + 1.0, fma(2.0, c1, -c));
             w_prev = w1; w = fma(tc, w1, -w);
         }
