@@ -918,7 +918,7 @@ struct Tunables {
     int upd_dynamic = 1;     // COCONS_UPD_DYNAMIC
     int dag = 1;             // COCONS_DAG: 1 = the head of the factorisation under the dependency-driven schedule (one persistent
                              // launch for its updates and panels, dag_kernel); 0 = the classic schedule throughout
-    int dag_lead = 3600;     // COCONS_DAG_LEAD: far tiles of a step in front of its panel tasks
+    int dag_lead = 2400;     // COCONS_DAG_LEAD: far tiles of a step in front of its panel tasks
     int dag_min_tiles = 3000;  // COCONS_DAG_MIN_TILES: the DAG launch covers the leading steps of at least this many update tiles
                              // (n = 10^4: 21 of the 39 steps, 87 % of the flops; below n ~ 5200 no step at all)
     int dag_split = 1;       // COCONS_DAG_SPLIT: the diagonal-block tiles of a DAG step in two halves, the first one off the chain

@@ -2,7 +2,7 @@
 """Where the time of the dependency-driven factorisation (dag_kernel) goes: per-task stamps of one evaluation
 (cocons_debug_dag_trace) summarised per step and per task kind.
 
-    python tools/dag_trace.py [--n 10000] [--lead 3600]
+    python tools/dag_trace.py [--n 10000] [--lead 2400]
 """
 import argparse
 import ctypes
@@ -17,8 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=10000)
-    ap.add_argument("--lead", type=int, default=3600)
+    ap.add_argument("--lead", type=int, default=2400)
     ap.add_argument("--every", type=int, default=4, help="print every k-th step")
+    ap.add_argument("--chain", type=int, default=-1, help="also print the stamps of the chain's panel tasks of this step")
     a = ap.parse_args()
     import cocons_amd as ca
     from cocons_amd import _lib, workloads as wl
@@ -106,6 +107,26 @@ def main():
             last_stage = 2 if two else 0
             m3 = (stage == last_stage) & (strip < 4)
             prev_t3c = rows[m3, 3].max() if m3.any() else prev_t3c
+    if a.chain >= 0:
+        # the panel tasks of the first four strips of one step (the rows of the next diagonal block): drawn / inputs / product / stored
+        s_ = a.chain
+        base, near, tpos, nT = [int(v) for v in steps[s_].view(np.uint32)[:4]]
+        H, W, tj0, k0, K, nstrip, two, need, nd_next, split = [int(v) for v in steps[s_][4:]]
+        e = E[(tj0 // 2) // 2]
+        print("chain of step %d: engine out[t] %.1f xr %.1f out[t+1] %.1f" % (s_, e[2], e[4], e[7]))
+        per = 2 * nstrip
+        for stage in range(3 if two else 1):
+            for strip in range(min(4, nstrip)):
+                for h in range(2):
+                    u = stage * per + 2 * strip + h
+                    if u >= per:
+                        u += nd_next
+                    L = base + tpos + u
+                    print("   T%d strip %d h %d (task %d): drawn %8.1f inputs %8.1f product %8.1f stored %8.1f" %
+                          (stage + 1, strip, h, L, T[L, 0], T[L, 1], T[L, 2], T[L, 3]))
+        for dd in range(nd_next):
+            L = base + tpos + per + dd
+            print("   early half %2d (task %d): drawn %8.1f inputs %8.1f product %8.1f stored %8.1f" % (dd, L, T[L, 0], T[L, 1], T[L, 2], T[L, 3]))
     print("totals per kind: count, slot-ms waiting for inputs, in the product (+ wait for the previous C version), in the epilogue")
     for k, d in kinds_tot.items():
         print("  %-5s %7d  %9.2f %9.2f %9.2f   mean product %.1f us" % (k, d[0], d[1] * 1e-3, d[2] * 1e-3, d[3] * 1e-3, d[2] / max(1, d[0])))
