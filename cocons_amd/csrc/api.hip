@@ -279,7 +279,7 @@ struct cocons_fit {
     double *dpart;                // early halves of the split diagonal-block tiles (2 x 16 x 64 x 64 doubles)
     unsigned *ddag; size_t ddag_words;      // [queue (64 words)] [tdone] [pdone]
     void *ddag_steps; int dag_nsteps; unsigned dag_ntasks;
-    int dag_key[7];               // (nt, mt, trim, kskip, lead, min_tiles, split) the step table was built for
+    int dag_key[9];               // (nt, mt, trim, kskip, lead, min_tiles, split, lead2, lead3) the step table was built for
     unsigned long long *ddag_trace; size_t dag_trace_tasks;   // diagnostics (cocons_debug_tune("dag_trace", 1)): 4 stamps per task
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
     bool dag_used;                // the factorisation enqueued last ran the DAG schedule: its factor is split over dA and dP
@@ -918,7 +918,12 @@ struct Tunables {
     int upd_dynamic = 1;     // COCONS_UPD_DYNAMIC
     int dag = 1;             // COCONS_DAG: 1 = the head of the factorisation under the dependency-driven schedule (one persistent
                              // launch for its updates and panels, dag_kernel); 0 = the classic schedule throughout
-    int dag_lead = 2400;     // COCONS_DAG_LEAD: far tiles of a step in front of its panel tasks
+    // where a step's panel tasks sit in its list: `lead` far tiles, T1 (+ early halves), `lead2` far tiles, T2, `lead3` far
+    // tiles, T3 -- each group about where the chip gets to it when the engine publishes what it waits for (the chip draws ~32
+    // tasks per us; first tile out ~85 us into a step, strip (t+1, t) ~18 us later, second tile ~60 us after that), so that
+    // the workgroups that draw them neither wait with a slot in hand nor come late.  One block at 3600 (round 4's first
+    // form): -1.4 %; at 2400: -0.9 %; everything between (800 .. 2000, 400 .. 900, 1800 .. 2400) measures alike.
+    int dag_lead = 1600, dag_lead2 = 600, dag_lead3 = 1800;
     int dag_min_tiles = 3000;  // COCONS_DAG_MIN_TILES: the DAG launch covers the leading steps of at least this many update tiles
                              // (n = 10^4: 21 of the 39 steps, 87 % of the flops; below n ~ 5200 no step at all)
     int dag_split = 1;       // COCONS_DAG_SPLIT: the diagonal-block tiles of a DAG step in two halves, the first one off the chain
@@ -937,6 +942,8 @@ static Tunables &tun()
         rd("COCONS_UPD_DYNAMIC", t.upd_dynamic);
         rd("COCONS_DAG", t.dag);
         rd("COCONS_DAG_LEAD", t.dag_lead);
+        rd("COCONS_DAG_LEAD2", t.dag_lead2);
+        rd("COCONS_DAG_LEAD3", t.dag_lead3);
         rd("COCONS_DAG_MIN_TILES", t.dag_min_tiles);
         rd("COCONS_DAG_SPLIT", t.dag_split);
         rd("COCONS_DAG_XCC_QUOTA", t.dag_xcc_quota);
@@ -954,6 +961,8 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "upd_dynamic") t.upd_dynamic = value;
     else if (k == "dag") t.dag = value;
     else if (k == "dag_lead") t.dag_lead = value;
+    else if (k == "dag_lead2") t.dag_lead2 = value;
+    else if (k == "dag_lead3") t.dag_lead3 = value;
     else if (k == "dag_min_tiles") t.dag_min_tiles = value;
     else if (k == "dag_split") t.dag_split = value;
     else if (k == "dag_xcc_quota") t.dag_xcc_quota = value;
@@ -1110,10 +1119,11 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         f->dWt_tiles = v.nt;
     }
     const int kskip = (f->pad0 / 16) * 16;
-    const int key[7] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split};
+    const int key[9] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, tun().dag_lead2, tun().dag_lead3};
     if (memcmp(key, f->dag_key, sizeof key) != 0 || !f->ddag_steps) {
         std::vector<DagStepHost> steps;
-        const unsigned ntasks = dag_build_steps(v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, steps);
+        const unsigned ntasks = dag_build_steps(v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, steps,
+                                                tun().dag_lead2, tun().dag_lead3);
         HIPCHK(hipStreamSynchronize(f->stream));
         HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->ddag_steps) { HIPCHK(hipFree(f->ddag_steps)); f->ddag_steps = nullptr; }
@@ -1144,7 +1154,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
 }
 
 // diagnostics: the step table and the per-task stamps of the last DAG factorisation of the handle (dag_trace = 1).
-// steps_out: nsteps x 14 ints (DagStepHost); stamps_out: ntasks x 4 ticks of the 100 MHz clock.  Returns ntasks (or < 0);
+// steps_out: nsteps x 16 ints (DagStepHost); stamps_out: ntasks x 4 ticks of the 100 MHz clock.  Returns ntasks (or < 0);
 // with null outputs only the sizes: *nsteps_out.  engine_out (may be null): 8 stamps per tile pair, (nt + 2) / 2 pairs ... room
 // for 8 * (nt + 2) values (see EngineArgs::trace).
 extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int *steps_out, unsigned long long *stamps_out,

@@ -1032,6 +1032,8 @@ struct DagStep {
     int need;               // pdone count at which a strip of THIS step's panel is complete (step 0: unused)
     int nd_next;            // "early half" tasks in this step's list: the diagonal-block tiles of the NEXT step, first 128 panel columns
     int split;              // this step's diagonal-block tiles only take the last 128 panel columns and add the early half's result
+    unsigned p2, p3;        // positions inside the step of the T2 block and of the T3 block (T1 and the early halves sit at tpos):
+                            // each group is placed where the chip gets to it about when the engine publishes what it waits for
 };
 
 struct DagArgs {
@@ -1139,7 +1141,19 @@ dag_kernel(DagArgs a)
             if (a.hw) a.hw[2 * (size_t)L] = hw_where();
         }
         const int t = st.tj0 >> 1;                           // first 128-tile of the next block
-        const bool isT = q >= st.tpos && q < st.tpos + st.nT;
+        // where in the step's list: tiles | T1, early halves | tiles | T2 | tiles | T3 | tiles
+        const unsigned per_u = 2u * (unsigned)st.nstrip, nA = per_u + (unsigned)st.nd_next, perBC = st.two ? per_u : 0u;
+        int tkind = -1;                                      // -1: update tile; 0, 1, 2: T1, T2, T3; 3: early half
+        unsigned tu = 0, qt_u = q;                           // index inside its group; index among the step's update tiles
+        if (q >= st.tpos) {
+            if (q < st.tpos + nA) { tu = q - st.tpos; tkind = tu < per_u ? 0 : 3; }
+            else if (q < st.p2) qt_u = q - nA;
+            else if (q < st.p2 + perBC) { tu = q - st.p2; tkind = 1; }
+            else if (q < st.p3) qt_u = q - nA - perBC;
+            else if (q < st.p3 + perBC) { tu = q - st.p3; tkind = 2; }
+            else qt_u = q - nA - 2u * perBC;
+        }
+        const bool isT = tkind >= 0;
         const double *gIb, *gJb;
         unsigned ldib, ldjb, ldob = ldab;                    // leading dimensions in bytes (operands, output)
         int K, i_wt = 0, store_only = 0, strip_task = 0;
@@ -1150,7 +1164,7 @@ dag_kernel(DagArgs a)
         int sigT = -1;                                       // >= 0: the tile lies in the next diagonal block: raise sig[sigT]
         int prio = 0;
         if (!isT) {
-            const int qt = (int)(q < st.tpos ? q : q - st.nT);
+            const int qt = (int)qt_u;
             int jl = 0, jh = st.W - 1;
             while (jl < jh) {
                 const int mid = (jl + jh + 1) >> 1;
@@ -1187,24 +1201,19 @@ dag_kernel(DagArgs a)
                 }
             }
         } else {
-            unsigned u = q - st.tpos;
             const int per = 2 * st.nstrip;
             const size_t c_t = (size_t)t * TILE, c_t1 = c_t + TILE;
             prio = 2;
-            int stage, strip = 0, h = 0, row64 = 0;
-            if (u >= (unsigned)per && u < (unsigned)(per + st.nd_next)) {
-                stage = 3;               // early half of a diagonal-block tile of the NEXT step
-            } else {
-                if (u >= (unsigned)per) u -= (unsigned)st.nd_next;
-                stage = (int)(u / (unsigned)per);
-                const int rem = (int)(u % (unsigned)per);
-                strip = rem >> 1; h = rem & 1;
+            const int stage = tkind;     // (3: early half of a diagonal-block tile of the NEXT step)
+            int strip = 0, h = 0, row64 = 0;
+            if (stage != 3) {
+                strip = (int)(tu >> 1); h = (int)(tu & 1u);
                 row64 = st.tj0 + (st.two ? 4 : 2) + strip;
                 strip_task = 1;
             }
             dn = a.pdone + (size_t)(s + 1) * a.pstride + strip;
             if (stage == 3) {
-                const int dd = (int)(q - st.tpos) - per;
+                const int dd = (int)tu - per;
                 const int ta = c_tri_ib[dd], tb = dd - ta * (ta + 1) / 2;
                 const int tj0n = st.tj0 + 4;                           // the next step's trapezoid (this block has two tiles)
                 const size_t k0n = (size_t)(s + 1) * 2 * TILE;         // its panel's first column
@@ -1734,7 +1743,8 @@ void launch_pack_rows(const double *A, size_t lda, int col0, int ncols, double *
 // Steps for a factorisation with nt column tiles and mt row tiles (trim64: the last 64 rows hold nothing), first panel
 // (tiles 0, 1) already formed in place; kskip leading columns of it are unit vectors (front padding) and are skipped.
 // lead: far tiles of a step in front of its panel tasks.  Returns the number of tasks.
-unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, int split, std::vector<DagStepHost> &out)
+unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, int split, std::vector<DagStepHost> &out,
+                         int lead2, int lead3)
 {
     out.clear();
     unsigned base = 0;
@@ -1786,6 +1796,18 @@ unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int mi
             }
         }
         base += shift;
+    }
+    // T2 `lead2` far tiles behind the T1 group, T3 `lead3` behind the T2 group (as far as the step has far tiles left)
+    for (auto &st : out) {
+        const long long tiles = (long long)st.W * st.H - (long long)st.W * (st.W - 1) / 2;
+        const long long nA = 2LL * st.nstrip + st.nd_next, perBC = st.two ? 2LL * st.nstrip : 0;
+        long long rem = tiles - ((long long)st.tpos);            // update tiles behind the T1 group (tpos counts tiles only so far)
+        if (st.nT == 0) { st.p2 = st.p3 = st.tpos; continue; }
+        const long long d2 = std::min<long long>(rem, perBC ? lead2 : 0);
+        rem -= d2;
+        const long long d3 = std::min<long long>(rem, perBC ? lead3 : 0);
+        st.p2 = (unsigned)(st.tpos + nA + d2);
+        st.p3 = (unsigned)(st.p2 + perBC + d3);
     }
     return base;
 }

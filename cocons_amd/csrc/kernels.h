@@ -180,11 +180,15 @@ void launch_pack_rows(const double *A, size_t lda, int col0, int ncols, double *
 struct DagStepHost {
     unsigned base, near, tpos, nT;
     int H, W, tj0, k0, K, nstrip, two, need, nd_next, split;
+    unsigned p2, p3;
 };
 // only the leading steps with at least min_tiles update tiles are taken (the head of the factorisation); the last of them has
 // no panel tasks: the panel behind it is left to the caller's classic kernels
 // split != 0: the diagonal-block tiles of the steps from 1 on are computed in two halves (nd_next / split, see DagStep)
-unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, int split, std::vector<DagStepHost> &out);
+// lead: far tiles of a step in front of its T1 tasks (and the early halves); lead2 / lead3: far tiles between them and the T2
+// tasks, between those and the T3 tasks
+unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, int split, std::vector<DagStepHost> &out,
+                         int lead2 = 0, int lead3 = 0);
 // dsteps: DEVICE copy of the table.  queue, tdone (2 mt (2 mt + 1) / 2 words), pdone ((nsteps + 1) * pstride words,
 // pstride >= 2 mt), pall (nsteps + 1 words): zero at launch.  sig / out / xr: the engine's words (launch_potrf_engine with wbuf = Wt, pbuf = P).
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,

@@ -45,7 +45,7 @@ int cocons_corun_probe(int bpc_mfma, int bpc_vfma, int iters_mfma, int iters_vfm
 int cocons_debug_tune(const char *name, int value);
 
 /* Per-task time stamps of the last dependency-driven factorisation (cocons_debug_tune("dag", 1) and ("dag_trace", 1)) of a
- * fit handle: steps_out = nsteps x 14 ints (base, near, tpos, nT, H, W, tj0, k0, K, nstrip, two, need, nd_next, split), stamps_out =
+ * fit handle: steps_out = nsteps x 16 ints (base, near, tpos, nT, H, W, tj0, k0, K, nstrip, two, need, nd_next, split, p2, p3), stamps_out =
  * ntasks x 4 ticks of the 100 MHz clock (drawn, inputs complete, product done, stored).  Returns ntasks; null outputs: sizes only. */
 struct cocons_fit;
 long long cocons_debug_dag_trace(struct cocons_fit *fit, int *nsteps_out, int *steps_out, unsigned long long *stamps_out,

@@ -13,17 +13,30 @@ def decode(steps, L):
     """task index -> (step, kind, detail)"""
     s = int(np.searchsorted(steps[:, 0].view(np.uint32) if steps.dtype != np.uint32 else steps[:, 0], L, side="right")) - 1
     base, near, tpos, nT = [int(v) for v in steps[s].view(np.uint32)[:4]]
-    H, W, tj0, k0, K, nstrip, two, need, nd_next, split = [int(v) for v in steps[s][4:]]
+    H, W, tj0, k0, K, nstrip, two, need, nd_next, split = [int(v) for v in steps[s][4:14]]
+    p2, p3 = [int(v) for v in steps[s].view(np.uint32)[14:16]]
     q = L - base
-    if tpos <= q < tpos + nT:
-        u = q - tpos
-        per = max(1, 2 * nstrip)
-        if per <= u < per + nd_next:
-            return s, "early", "dd %d" % (u - per)
-        if u >= per:
-            u -= nd_next
-        return s, "T%d" % (u // per + 1), "strip %d h %d (row64 %d)" % ((u % per) // 2, u % 2, tj0 + (4 if two else 2) + (u % per) // 2)
-    qt = q if q < tpos else q - nT
+    per = 2 * nstrip
+    nA, perBC = per + nd_next, (per if two else 0)
+    kind, u, qt = None, 0, q                      # the list of a step: tiles | T1, early halves | tiles | T2 | tiles | T3 | tiles
+    if q >= tpos:
+        if q < tpos + nA:
+            u = q - tpos
+            kind = "T1" if u < per else "early"
+        elif q < p2:
+            qt = q - nA
+        elif q < p2 + perBC:
+            kind, u = "T2", q - p2
+        elif q < p3:
+            qt = q - nA - perBC
+        elif q < p3 + perBC:
+            kind, u = "T3", q - p3
+        else:
+            qt = q - nA - 2 * perBC
+    if kind == "early":
+        return s, "early", "dd %d" % (u - per)
+    if kind:
+        return s, kind, "strip %d h %d (row64 %d)" % (u // 2, u % 2, tj0 + (4 if two else 2) + u // 2)
     jl = 0
     while (jl + 1) * H - (jl + 1) * jl // 2 <= qt and jl + 1 < W:
         jl += 1
@@ -42,7 +55,7 @@ def main():
     nt, nsteps, ntasks, nwords, fcap, ntr, code, qn, now = [int(v) for v in hdr[1:10]]
     off = 64
     rec = np.frombuffer(raw, np.uint32, 7, off); off += 28
-    steps = np.frombuffer(raw, np.int32, nsteps * 14, off).reshape(nsteps, 14); off += nsteps * 56
+    steps = np.frombuffer(raw, np.int32, nsteps * 16, off).reshape(nsteps, 16); off += nsteps * 64
     words = np.frombuffer(raw, np.uint32, nwords, off); off += 4 * nwords
     flags = np.frombuffer(raw, np.uint32, 4 * fcap + 64, off); off += 4 * (4 * fcap + 64)
     print("abort code 0x%x; nt %d, %d steps, %d tasks, counter %d" % (code, nt, nsteps, ntasks, qn))
@@ -138,7 +151,7 @@ def tile_history(path, ti, tj):
     hdr = np.frombuffer(raw, np.uint32, 16, 0)
     nt, nsteps, ntasks, nwords, fcap, ntr = [int(v) for v in hdr[1:7]]
     off = 64 + 28
-    steps = np.frombuffer(raw, np.int32, nsteps * 14, off).reshape(nsteps, 14); off += nsteps * 56
+    steps = np.frombuffer(raw, np.int32, nsteps * 16, off).reshape(nsteps, 16); off += nsteps * 64
     words = np.frombuffer(raw, np.uint32, nwords, off); off += 4 * nwords + 4 * (4 * fcap + 64)
     st = np.frombuffer(raw, np.uint64, ntasks * 4, off).reshape(ntasks, 4)
     t0 = st[:, 0][st[:, 0] > 0].min()
@@ -146,11 +159,20 @@ def tile_history(path, ti, tj):
     for s in range(nsteps):
         base, near, tpos, nT = [int(v) for v in steps[s].view(np.uint32)[:4]]
         H, W, tj0 = [int(v) for v in steps[s][4:7]]
+        nstrip, two, nd_next = int(steps[s][9]), int(steps[s][10]), int(steps[s][12])
+        p2, p3 = [int(v) for v in steps[s].view(np.uint32)[14:16]]
         jl = tj - tj0
         if jl < 0 or jl >= W or ti < tj:
             continue
         qt = jl * H - jl * (jl - 1) // 2 + (ti - tj)
-        q = qt if qt < tpos else qt + nT
+        nA, perBC = 2 * nstrip + nd_next, (2 * nstrip if two else 0)
+        q = qt                                   # position of update tile qt in the step's list (see decode)
+        if q >= tpos:
+            q += nA
+            if q >= p2:
+                q += perBC
+                if q >= p3:
+                    q += perBC
         L = base + q
         print("  step %2d task %6d (%s): %s" % (s, L, decode(steps, L)[1:], " ".join("%9.1f" % ((float(v) - float(t0)) * 0.01) if v else "        -" for v in st[L])))
 

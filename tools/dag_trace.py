@@ -2,7 +2,7 @@
 """Where the time of the dependency-driven factorisation (dag_kernel) goes: per-task stamps of one evaluation
 (cocons_debug_dag_trace) summarised per step and per task kind.
 
-    python tools/dag_trace.py [--n 10000] [--lead 2400]
+    python tools/dag_trace.py [--n 10000] [--lead 1600]
 """
 import argparse
 import ctypes
@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=10000)
-    ap.add_argument("--lead", type=int, default=2400)
+    ap.add_argument("--lead", type=int, default=1600)
     ap.add_argument("--every", type=int, default=4, help="print every k-th step")
     ap.add_argument("--chain", type=int, default=-1, help="also print the stamps of the chain's panel tasks of this step")
     a = ap.parse_args()
@@ -37,7 +37,7 @@ def main():
     ns = ctypes.c_int(0)
     nt = L.cocons_debug_dag_trace(fit._h, ctypes.byref(ns), None, None, None)
     assert nt > 0, _lib.last_error()
-    steps = np.zeros((ns.value, 14), dtype=np.int32)
+    steps = np.zeros((ns.value, 16), dtype=np.int32)
     st = np.zeros((nt, 4), dtype=np.uint64)
     eng = np.zeros((8 * (2 * ns.value + 8),), dtype=np.uint64)
     ntile = (g * g + 127) // 128
@@ -59,17 +59,22 @@ def main():
     prev_t3c = 0.0
     for s in range(ns.value):
         base, near, tpos, nT = [int(v) for v in steps[s].view(np.uint32)[:4]]
-        H, W, tj0, k0, K, nstrip, two, need, nd_next, split = [int(v) for v in steps[s][4:]]
+        H, W, tj0, k0, K, nstrip, two, need, nd_next, split = [int(v) for v in steps[s][4:14]]
+        p2, p3 = [int(v) for v in steps[s].view(np.uint32)[14:16]]
         nxt = int(steps[s + 1].view(np.uint32)[0]) if s + 1 < ns.value else nt
         rows = T[base:nxt]
         q = np.arange(nxt - base)
-        isT = (q >= tpos) & (q < tpos + nT)
-        u = q - tpos
-        per = max(1, 2 * nstrip)
-        early = isT & (u >= per) & (u < per + nd_next)          # early halves of the next step's diagonal-block tiles
-        u2 = np.where(u >= per + nd_next, u - nd_next, u)
-        stage = np.where(isT & ~early, u2 // per, -1)
-        strip = np.where(isT & ~early, (u2 % per) // 2, -1)
+        # the list of a step: tiles | T1, early halves | tiles | T2 | tiles | T3 | tiles
+        per = 2 * nstrip
+        nA, perBC = per + nd_next, (per if two else 0)
+        inA = (q >= tpos) & (q < tpos + nA)
+        inB = (q >= p2) & (q < p2 + perBC)
+        inC = (q >= p3) & (q < p3 + perBC)
+        isT = inA | inB | inC
+        early = inA & (q - tpos >= per)                          # early halves of the next step's diagonal-block tiles
+        stage = np.where(inA & ~early, 0, np.where(inB, 1, np.where(inC, 2, -1)))
+        u2 = np.where(inA, q - tpos, np.where(inB, q - p2, q - p3))
+        strip = np.where(isT & ~early, u2 // 2, -1)
         isnear = (~isT) & (q < near)
         isfar = (~isT) & ~isnear
         # diagonal-block tiles: column jl < 4, row offset jl + r < 4
@@ -111,17 +116,15 @@ def main():
         # the panel tasks of the first four strips of one step (the rows of the next diagonal block): drawn / inputs / product / stored
         s_ = a.chain
         base, near, tpos, nT = [int(v) for v in steps[s_].view(np.uint32)[:4]]
-        H, W, tj0, k0, K, nstrip, two, need, nd_next, split = [int(v) for v in steps[s_][4:]]
+        H, W, tj0, k0, K, nstrip, two, need, nd_next, split = [int(v) for v in steps[s_][4:14]]
+        p2, p3 = [int(v) for v in steps[s_].view(np.uint32)[14:16]]
         e = E[(tj0 // 2) // 2]
         print("chain of step %d: engine out[t] %.1f xr %.1f out[t+1] %.1f" % (s_, e[2], e[4], e[7]))
         per = 2 * nstrip
         for stage in range(3 if two else 1):
             for strip in range(min(4, nstrip)):
                 for h in range(2):
-                    u = stage * per + 2 * strip + h
-                    if u >= per:
-                        u += nd_next
-                    L = base + tpos + u
+                    L = base + (tpos, p2, p3)[stage] + 2 * strip + h
                     print("   T%d strip %d h %d (task %d): drawn %8.1f inputs %8.1f product %8.1f stored %8.1f" %
                           (stage + 1, strip, h, L, T[L, 0], T[L, 1], T[L, 2], T[L, 3]))
         for dd in range(nd_next):
