@@ -61,6 +61,59 @@ __device__ __forceinline__ double fast_rcp(double x)
     return fma(fma(e, e, e), r, r);
 }
 
+// sqrt(x) for x >= 0 of ordinary magnitude (squared distances over squared ranges, ratios of determinants): v_rsq_f64 (24
+// bits) + one third-order step + one Heron correction, ~1 ulp in ten instructions; zero stays zero.  The library square root
+// spends as many again on scaling for operands near the ends of the exponent range, which do not occur here.
+__device__ __forceinline__ double sqrt_pos(double x)
+{
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double s0 = x * y0;
+    const double t = fma(-s0, y0, 1.0);
+    const double y = fma(y0 * t, fma(t, 0.375, 0.5), y0);
+    double s_ = x * y;
+    s_ = fma(fma(-s_, s_, x), 0.5 * y, s_);
+    return x > 0.0 ? s_ : 0.0;
+}
+
+// One Horner step p t + C with the coefficient in a SCALAR register pair.  Written out because the compiler's own choice for
+// fma(p, t, literal) in straight-line code is v_fmac_f64 with the constant moved into a fresh vector register pair first:
+// two v_mov_b32 and the fused multiply-add, three vector instructions per coefficient in a kernel that is bound by vector
+// issue (the scalar moves this form needs instead issue beside them).  Same operation, same bits.
+__device__ __forceinline__ double hfma(double p, double t, double C)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(t), "s"(C));
+    return r;
+}
+
+// log2(u) for a normal positive u (the branches below call it with 2 <= u < 1100): u = 2^e m with m in [sqrt(1/2), sqrt 2),
+// log m = 2 s (1 + s^2/3 + s^4/5 + ...) in s = (m - 1)/(m + 1), |s| <= 0.172 (the term behind s^22/23 is 2e-20).  Absolute error
+// ~2e-16, which the exponent nu log2(u) + 1 - nu it goes into turns into a relative 5e-16 of the result; the library routine
+// pays seventy instructions of double-double arithmetic for its last half ulp.
+__device__ __forceinline__ double log2_pos(double u)
+{
+    double m = __builtin_amdgcn_frexp_mant(u);            // [1/2, 1)
+    int e = __builtin_amdgcn_frexp_exp(u);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double s_ = (m - 1.0) * fast_rcp(m + 1.0);
+    const double s2 = s_ * s_;
+    double p = 1.0 / 23.0;
+    p = hfma(p, s2, 1.0 / 21.0);
+    p = hfma(p, s2, 1.0 / 19.0);
+    p = hfma(p, s2, 1.0 / 17.0);
+    p = hfma(p, s2, 1.0 / 15.0);
+    p = hfma(p, s2, 1.0 / 13.0);
+    p = hfma(p, s2, 1.0 / 11.0);
+    p = hfma(p, s2, 1.0 / 9.0);
+    p = hfma(p, s2, 1.0 / 7.0);
+    p = hfma(p, s2, 1.0 / 5.0);
+    p = hfma(p, s2, 1.0 / 3.0);
+    p = hfma(p, s2, 1.0);
+    return fma(p * s_, 2.0 * 1.4426950408889634074, (double)e);
+}
+
 // 2^a e^-u for |a| < 1000, 0 <= u < 1100, in ONE exponential: u = n_u ln 2 + r (Cody-Waite, r exact to ~1e-17), a = n_a + f_a
 // (exact), so 2^a e^-u = 2^(n_a - n_u + k) 2^g with g = f_a - r log2(e) - k in [-1/2, 1/2]; 2^g = e^(g ln 2) by its Taylor series
 // to degree 14 (|g ln 2| <= 0.347: truncation 1e-19).  Relative error ~4e-16; replaces exp2(a) * exp(-u) (two library
@@ -77,20 +130,20 @@ __device__ __forceinline__ double pow2a_expmu(double a, double u)
     const double k = rint(f);
     const double t = (f - k) * LN2;
     double p = 1.0 / 87178291200.0;                   // 1/14!
-    p = fma(p, t, 1.0 / 6227020800.0);
-    p = fma(p, t, 1.0 / 479001600.0);
-    p = fma(p, t, 1.0 / 39916800.0);
-    p = fma(p, t, 1.0 / 3628800.0);
-    p = fma(p, t, 1.0 / 362880.0);
-    p = fma(p, t, 1.0 / 40320.0);
-    p = fma(p, t, 1.0 / 5040.0);
-    p = fma(p, t, 1.0 / 720.0);
-    p = fma(p, t, 1.0 / 120.0);
-    p = fma(p, t, 1.0 / 24.0);
-    p = fma(p, t, 1.0 / 6.0);
-    p = fma(p, t, 0.5);
-    p = fma(p, t, 1.0);
-    p = fma(p, t, 1.0);
+    p = hfma(p, t, 1.0 / 6227020800.0);
+    p = hfma(p, t, 1.0 / 479001600.0);
+    p = hfma(p, t, 1.0 / 39916800.0);
+    p = hfma(p, t, 1.0 / 3628800.0);
+    p = hfma(p, t, 1.0 / 362880.0);
+    p = hfma(p, t, 1.0 / 40320.0);
+    p = hfma(p, t, 1.0 / 5040.0);
+    p = hfma(p, t, 1.0 / 720.0);
+    p = hfma(p, t, 1.0 / 120.0);
+    p = hfma(p, t, 1.0 / 24.0);
+    p = hfma(p, t, 1.0 / 6.0);
+    p = hfma(p, t, 0.5);
+    p = hfma(p, t, 1.0);
+    p = hfma(p, t, 1.0);
     return ldexp(p, (int)(na - nu_ + k));
 }
 
@@ -116,8 +169,8 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
     double gam1 = 0.0, gam2 = 0.0;
 #pragma unroll
     for (int j = RG_NTERMS - 1; j >= 0; --j) {
-        gam1 = fma(gam1, mu2, c_rg_odd[j]);
-        gam2 = fma(gam2, mu2, c_rg_even[j]);
+        gam1 = hfma(gam1, mu2, c_rg_odd[j]);
+        gam2 = hfma(gam2, mu2, c_rg_even[j]);
     }
     double gampl = gam2 - mu * gam1;   // 1/Gamma(1+mu)
     double gammi = gam2 + mu * gam1;   // 1/Gamma(1-mu)
@@ -157,7 +210,7 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         for (int k = 1; k < n; ++k) prod *= (mu + k);
         rg = rg * fast_rcp(prod);
         // 2^(1-nu) u^nu sqrt(pi / 2u) e^-u = sqrt(pi/2) 2^((nu - 1/2) log2 u + 1 - nu) e^-u: one exponential
-        return 1.2533141373155002512 * pow2a_expmu(fma(nu - 0.5, log2(u), 1.0 - nu), u) * rg * S;
+        return 1.2533141373155002512 * pow2a_expmu(fma(nu - 0.5, log2_pos(u), 1.0 - nu), u) * rg * S;
     }
 #ifndef COCONS_TRAP_ULO
 #define COCONS_TRAP_ULO 2.0
@@ -191,17 +244,17 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         // cosh(nu h): |nu h| <= 0.77, Taylor polynomial in (nu h)^2 to degree 11 (0.77^24 / 24! = 3e-27)
         const double xx = nu * h, x2 = xx * xx;
         double chn = 1.0 / 51090942171709440000.0 * (1.0 / 22.0);         // 1/22!
-        chn = fma(chn, x2, 1.0 / 2432902008176640000.0);                   // 1/20!
-        chn = fma(chn, x2, 1.0 / 6402373705728000.0);                      // 1/18!
-        chn = fma(chn, x2, 1.0 / 20922789888000.0);                        // 1/16!
-        chn = fma(chn, x2, 1.0 / 87178291200.0);                           // 1/14!
-        chn = fma(chn, x2, 1.0 / 479001600.0);                             // 1/12!
-        chn = fma(chn, x2, 1.0 / 3628800.0);                               // 1/10!
-        chn = fma(chn, x2, 1.0 / 40320.0);                                 // 1/8!
-        chn = fma(chn, x2, 1.0 / 720.0);                                   // 1/6!
-        chn = fma(chn, x2, 1.0 / 24.0);                                    // 1/4!
-        chn = fma(chn, x2, 0.5);
-        chn = fma(chn, x2, 1.0);
+        chn = hfma(chn, x2, 1.0 / 2432902008176640000.0);                   // 1/20!
+        chn = hfma(chn, x2, 1.0 / 6402373705728000.0);                      // 1/18!
+        chn = hfma(chn, x2, 1.0 / 20922789888000.0);                        // 1/16!
+        chn = hfma(chn, x2, 1.0 / 87178291200.0);                           // 1/14!
+        chn = hfma(chn, x2, 1.0 / 479001600.0);                             // 1/12!
+        chn = hfma(chn, x2, 1.0 / 3628800.0);                               // 1/10!
+        chn = hfma(chn, x2, 1.0 / 40320.0);                                 // 1/8!
+        chn = hfma(chn, x2, 1.0 / 720.0);                                   // 1/6!
+        chn = hfma(chn, x2, 1.0 / 24.0);                                    // 1/4!
+        chn = hfma(chn, x2, 0.5);
+        chn = hfma(chn, x2, 1.0);
         const double tk = 2.0 * kap, tc = 2.0 * chn;
         double c_prev = 0.0, c = kap;        // cosh(j h) - 1 for j - 1, j
         double w_prev = 1.0, w = chn;        // cosh(nu j h)
@@ -244,7 +297,7 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         double prod = 1.0;
         for (int k = 1; k < n; ++k) prod *= (mu + k);
         rg = rg * fast_rcp(prod);
-        return pow2a_expmu(fma(nu, log2(u), 1.0 - nu), u) * rg * (S * h);
+        return pow2a_expmu(fma(nu, log2_pos(u), 1.0 - nu), u) * rg * (S * h);
     }
     double kmu, kmu1;                  // K_mu, K_{mu+1}, both WITHOUT the factor exp(-u) when u > 2
     double escale;                     // the factor still to be applied: exp(-u) (CF2) or 1 (Temme)
@@ -257,15 +310,15 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         double x2 = 0.5 * u, pimu = pi * mu;
         const double y = pimu * pimu;
         double sp = -1.0 / 51090942171709440000.0;          // -1/21!
-        sp = fma(sp, y, 1.0 / 121645100408832000.0);         //  1/19!
-        sp = fma(sp, y, -1.0 / 355687428096000.0);           // -1/17!
-        sp = fma(sp, y, 1.0 / 1307674368000.0);              //  1/15!
-        sp = fma(sp, y, -1.0 / 6227020800.0);                // -1/13!
-        sp = fma(sp, y, 1.0 / 39916800.0);                   //  1/11!
-        sp = fma(sp, y, -1.0 / 362880.0);                    // -1/9!
-        sp = fma(sp, y, 1.0 / 5040.0);                       //  1/7!
-        sp = fma(sp, y, -1.0 / 120.0);                       // -1/5!
-        sp = fma(sp, y, 1.0 / 6.0);                          //  1/3!
+        sp = hfma(sp, y, 1.0 / 121645100408832000.0);         //  1/19!
+        sp = hfma(sp, y, -1.0 / 355687428096000.0);           // -1/17!
+        sp = hfma(sp, y, 1.0 / 1307674368000.0);              //  1/15!
+        sp = hfma(sp, y, -1.0 / 6227020800.0);                // -1/13!
+        sp = hfma(sp, y, 1.0 / 39916800.0);                   //  1/11!
+        sp = hfma(sp, y, -1.0 / 362880.0);                    // -1/9!
+        sp = hfma(sp, y, 1.0 / 5040.0);                       //  1/7!
+        sp = hfma(sp, y, -1.0 / 120.0);                       // -1/5!
+        sp = hfma(sp, y, 1.0 / 6.0);                          //  1/3!
         sp = fma(-sp, y, 1.0);                               // sin(x)/x = 1 - x^2 (1/3! - x^2 (1/5! - ...))
         double fact = fast_rcp(sp);                          // pi mu / sin(pi mu)
         double d = -log(x2), e = mu * d;
@@ -273,12 +326,12 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         const double E = exp(e), Ei = fast_rcp(E);
         const double e2 = e * e;
         double sh = 1.0 / 6227020800.0;                       // sinh(e)/e = sum e^(2k) / (2k+1)!, |e| < 1/4: 1e-19 after e^12
-        sh = fma(sh, e2, 1.0 / 39916800.0);
-        sh = fma(sh, e2, 1.0 / 362880.0);
-        sh = fma(sh, e2, 1.0 / 5040.0);
-        sh = fma(sh, e2, 1.0 / 120.0);
-        sh = fma(sh, e2, 1.0 / 6.0);
-        sh = fma(sh, e2, 1.0);
+        sh = hfma(sh, e2, 1.0 / 39916800.0);
+        sh = hfma(sh, e2, 1.0 / 362880.0);
+        sh = hfma(sh, e2, 1.0 / 5040.0);
+        sh = hfma(sh, e2, 1.0 / 120.0);
+        sh = hfma(sh, e2, 1.0 / 6.0);
+        sh = hfma(sh, e2, 1.0);
         double fact2 = fabs(e) < 0.25 ? sh : 0.5 * (E - Ei) * fast_rcp(e);
         double ff = fact * (gam1 * (0.5 * (E + Ei)) + gam2 * fact2 * d);
         double sum = ff;
@@ -306,7 +359,7 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         //   q_k = (q_{k-2} - (b_k - 2) q_{k-1}) / a_k ,  C_k = -C_{k-1} a_k / k
         // become  A_k = -(B_{k-1} - (b_k - 2) A_{k-1}) / k ,  B_k = -(a_k / k) A_{k-1}
         // (a_k cancels), leaving one reciprocal per step.
-        l2u = log2(u);
+        l2u = log2_pos(u);
         double a = mu2 - 0.25;
         double b = 2.0 * (u + 1.0), D = fast_rcp(b), f = D, delta = D;
         double Ak = -a;          // C_1 q_1 = -a * 1
@@ -384,8 +437,8 @@ __device__ __forceinline__ double pair_value_idx(const double *base_a, size_t sa
     // division, :140-141; the same reciprocal serves the normalisation below): u moves by a few ulp, M(u) by u times that --
     // below 3e-13 at u = 700, inside the entrywise tolerance of 2e-12
     const double rdet = fast_rcp(det);
-    double u = sqrt((8 * smtns) * (rgr * rdet) *
-                    fma(kahan(s22, dx * dx, -s11, dy * dy), 1.0, -2 * s12 * dx * dy));
+    double u = sqrt_pos((8 * smtns) * (rgr * rdet) *
+                        fma(kahan(s22, dx * dx, -s11, dy * dy), 1.0, -2 * s12 * dx * dy));
     if (u <= epsilon) return FA(11);
     double m;
     if (MODE == MODE_HALF) m = exp(-u);
@@ -395,7 +448,7 @@ __device__ __forceinline__ double pair_value_idx(const double *base_a, size_t sa
     // stage 2: amplitude (fields reloaded, see above)
     asm volatile("" : "+v"(oa), "+v"(ob));
     // (1 / det is formed again rather than kept across the Bessel call: one more live value there spills)
-    double amp = sqrt(FA(8) * FB(8) * fast_rcp(det));      // sqrt(dets_i sin t_i dets_j sin t_j / det), field 8 = dets sin t
+    double amp = sqrt_pos(FA(8) * FB(8) * fast_rcp(det));      // sqrt(dets_i sin t_i dets_j sin t_j / det), field 8 = dets sin t
     return m * FA(9) * FB(9) * amp;
 #undef FA
 #undef FB
