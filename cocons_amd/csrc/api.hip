@@ -2545,6 +2545,8 @@ static int shard_begin(cocons_fit *f, const double *theta, const double *mean, i
     if (f->r < 1) return fail(-1, "sharded evaluation: fit has no z");
     if (int rc = shard_prepare(f, rank, world)) return rc;
     if (int rc = reset_info(f)) return rc;
+    if (engine_enabled())
+        if (int rc = flags_reset(f, f->nt)) return rc;     // (the words shard_factor_diag's engine launches read and raise)
     ThetaVecs tv;
     make_theta_vecs(theta, f->p, tv);
     ModeSel ms = select_mode(theta, f->p, f->smooth_limits, 0);
@@ -2578,12 +2580,23 @@ static int shard_factor_diag(cocons_fit *f, int k)
     const int t = k * PT, w = S->plan.ncols[k] / TILE;
     hipStream_t s = f->stream;
     double *A = f->dA, *q0 = f->dinv, *q1 = f->dinv + 2048;
-    launch_potrf_tile(A, f->lda, t * TILE, q0, f->dinfo, s);
-    if (w == 2) {
-        launch_trsm_tile(A, f->lda, t * TILE, (t + 1) * TILE, (t + 2) * TILE, q0, s);
-        launch_update(A, f->lda, t * TILE, TILE, t + 1, t + 2, t + 1, t + 2, true, s);
-        launch_potrf_tile(A, f->lda, (t + 1) * TILE, q1, f->dinfo, s);
+    if (engine_enabled() && f->flags_cap >= t + w) {
+        // the whole block in ONE launch of the diagonal-block engine (tile, strip solve, tile update, tile: what the four
+        // launches below do, without their three boundaries -- this block is the chain every rank waits for, section 5): its
+        // input words are raised beforehand, so it never waits, and it leaves behind the block of its second tile
+        unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(in + t), 7, (size_t)w, s));
+        launch_potrf_engine(A, f->lda, t, t + w, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
+                            f->dflags + 3 * (size_t)f->flags_cap, s);
+    } else {
+        launch_potrf_tile(A, f->lda, t * TILE, q0, f->dinfo, s);
+        if (w == 2) {
+            launch_trsm_tile(A, f->lda, t * TILE, (t + 1) * TILE, (t + 2) * TILE, q0, s);
+            launch_update(A, f->lda, t * TILE, TILE, t + 1, t + 2, t + 1, t + 2, true, s);
+            launch_potrf_tile(A, f->lda, (t + 1) * TILE, q1, f->dinfo, s);
+        }
     }
+    (void)q1;
     double *L = S->lkk[k & 1];
     HIPCHK(hipMemcpy2DAsync(L, (size_t)PT * TILE * sizeof(double), A + (size_t)t * TILE + (size_t)t * TILE * f->lda,
                             f->lda * sizeof(double), (size_t)w * TILE * sizeof(double), (size_t)w * TILE,

@@ -18,9 +18,11 @@ TILE = 128
 T_UNPACK = 5.0            # two device-to-device copies of 0.5 MB + 32 KB
 T_SOLVE = 45.0            # solve | in-panel update | solve over a rank's rows (three launches; strips run side by side)
 T_DIAG_UPDATE = 10.0      # 256 x 256 x 256 update of the next diagonal block (10 tiles)
-T_DIAG_FACTOR = 100.0     # potrf 30 | solve 13 | update 10 | potrf 30 + launch gaps (plain sequence)
+T_DIAG_FACTOR = 85.0      # ONE launch of the diagonal-block engine (tile | strip solve | tile update | tile: 78 us measured at
+                          # n = 10^4, profiles/r04_shard_one_rank_kernel_stats.csv) + the fill that raises its input words + one gap
+                          # (until the end of round 4: four launches, potrf 30 | solve 13 | update 10 | potrf 30 + gaps = 100)
 T_PACK = 10.0
-T_ASSEMBLY_MS = 1.1       # covariance assembly of the whole lower triangle on one GPU (shards: / N)
+T_ASSEMBLY_MS = 0.9       # covariance assembly of the whole lower triangle on one GPU (shards: / N)
 T_UPDATES_MS = 6.4        # all trailing updates of one evaluation on one GPU at n = 10^4 (scaled by (n / 10^4)^3)
 COLL_LATENCY = 20.0       # per collective, microseconds (assumption)
 LINK_GBPS = 70.0          # one xGMI link, one direction, effective (assumption; 7 links per GPU, point to point)

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 from cocons_amd import _lib, workloads as wl
 from cocons_amd.shard import ShardedFit, MultiFit
-g = 20
+g = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 locs = wl.grid_locs(g); X = wl.design_from_locs(locs)["std.covs"]; th = wl.theta_full()
 z = wl.synthetic_z(g * g)
 fit = ShardedFit(locs, X, z, wl.SMOOTH_LIMITS, device=0)
