@@ -321,9 +321,12 @@ __device__ __noinline__ double matern_bessel(double nu, double u)
         sp = hfma(sp, y, 1.0 / 6.0);                          //  1/3!
         sp = fma(-sp, y, 1.0);                               // sin(x)/x = 1 - x^2 (1/3! - x^2 (1/5! - ...))
         double fact = fast_rcp(sp);                          // pi mu / sin(pi mu)
-        double d = -log(x2), e = mu * d;
-        l2u = fma(-d, 1.4426950408889634074, 1.0);
-        const double E = exp(e), Ei = fast_rcp(E);
+        // (d = -ln(u/2) = ln 2 (1 - log2 u) from the kernel's own log2; E = e^(mu d) = 2^(mu (1 - log2 u)) through the one
+        // exponential routine: the library's log and exp cost 110 instructions between them)
+        l2u = log2_pos(u);
+        const double oml = 1.0 - l2u;
+        double d = oml * 0.6931471805599453094, e = mu * d;
+        const double E = pow2a_expmu(mu * oml, 0.0), Ei = fast_rcp(E);
         const double e2 = e * e;
         double sh = 1.0 / 6227020800.0;                       // sinh(e)/e = sum e^(2k) / (2k+1)!, |e| < 1/4: 1e-19 after e^12
         sh = hfma(sh, e2, 1.0 / 39916800.0);
