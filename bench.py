@@ -410,10 +410,25 @@ def main():
             if n == 10000 and os.path.exists(tr):
                 with open(tr) as fh:
                     tj = json.load(fh)
-                roofline["traffic"] = tj.get("hbm_bytes_per_launch")
-                roofline["traffic_source"] = "NOT measured in this run: profiles/%s (separate rocprofv3 --pmc passes of " \
-                                             "this command, commit %s); %s" % (TRAFFIC_PROFILE, tj.get("commit", "?"),
-                                                                               tj.get("note", ""))
+                if dag:
+                    # The persistent launch cannot be counted: rocprofv3 --pmc serialises kernels, and this launch waits for its
+                    # partner on the other stream (the diagonal-block engine).  What exists is the count for the SAME tile kernel
+                    # in separate launches (the plain schedule, round 3): per evaluation FETCH + WRITE for all 39 updates -- the
+                    # share of this launch by flops is an estimate, and it is labelled as one; `traffic` stays null.
+                    per_eval = 1e3 * (tj.get("FETCH_SIZE_KB_per_eval_raw", 0.0) + tj.get("WRITE_SIZE_KB_per_eval", 0.0))
+                    roofline["traffic_estimate"] = round(per_eval * st["dag_flops"] / flops, 1) if per_eval > 0 else None
+                    roofline["traffic_source"] = ("NOT measured: the persistent launch cannot run under rocprofv3 --pmc (kernels are "
+                                                  "serialised there and it waits for the engine on the other stream).  "
+                                                  "`traffic_estimate` = this launch's share (by flops) of FETCH_SIZE (raw) + "
+                                                  "WRITE_SIZE per evaluation of the same tile kernel in 39 separate launches, "
+                                                  "profiles/%s (commit %s); its C tiles move by the same L2-bypassing "
+                                                  "read-modify-write, its operands through the same L2" % (TRAFFIC_PROFILE,
+                                                                                                           tj.get("commit", "?")))
+                else:
+                    roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+                    roofline["traffic_source"] = "NOT measured in this run: profiles/%s (separate rocprofv3 --pmc passes of " \
+                                                 "this command, commit %s); %s" % (TRAFFIC_PROFILE, tj.get("commit", "?"),
+                                                                                   tj.get("note", ""))
         chol_tf = chol_flops(n) / (stages["cholesky_ms"] * 1e-3) / 1e12
         pairs = n * (n + 1) / 2.0
         assembly = {"kernel": "cocons::pair_sym_kernel<0, false> (general-nu Bessel-K branch)", "bound": "fp64 valu",
