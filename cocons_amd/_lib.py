@@ -90,15 +90,35 @@ SIGNATURES = {
 
 # every symbol include/cocons_hip_diag.h declares (probes and pointwise diagnostics: not the drop-in boundary)
 DIAG_SIGNATURES = {
-    "cocons_mfma_f64_probe": (c_int, [c_int, c_dp]),
-    "cocons_mfma_f64_probe_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_dp]),
-    "cocons_vfma_f64_probe": (c_int, [c_int, c_dp]),
     "cocons_debug_matern": (c_int, [c_int, c_dp, c_dp, c_dp]),
-    "cocons_corun_probe": (c_int, [c_int, c_int, c_int, c_int, c_dp]),
     "cocons_debug_tune": (c_int, [ctypes.c_char_p, c_int]),
     "cocons_debug_dag_trace": (ctypes.c_longlong, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                                    ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]),
 }
+
+
+# include/cocons_hip_probes.h: bare-instruction probes, in a library of their own (tools only)
+PROBES_PATH = os.path.join(_HERE, "csrc", "libcocons_hip_probes.so")
+PROBE_SIGNATURES = {
+    "cocons_probe_last_error": (ctypes.c_char_p, []),
+    "cocons_mfma_f64_probe": (c_int, [c_int, c_dp]),
+    "cocons_mfma_f64_probe_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_dp]),
+    "cocons_vfma_f64_probe": (c_int, [c_int, c_dp]),
+    "cocons_corun_probe": (c_int, [c_int, c_int, c_int, c_int, c_dp]),
+}
+_probes = None
+
+
+def load_probes():
+    """The probe library (tools/probe_mfma*.py); never loaded by the product path."""
+    global _probes
+    if _probes is None:
+        L = ctypes.CDLL(PROBES_PATH)
+        for name, (res, args) in PROBE_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _probes = L
+    return _probes
 
 
 def load():

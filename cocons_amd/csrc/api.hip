@@ -3118,65 +3118,3 @@ extern "C" int cocons_debug_matern(int n, const double *nu, const double *u, dou
     return rc;
 }
 
-// ---------------------------------------------------------------------------
-extern "C" int cocons_mfma_f64_probe(int blocks_per_cu, double *tflops)
-{
-    if (!tflops || blocks_per_cu < 1 || blocks_per_cu > 8) return fail(-1, "cocons_mfma_f64_probe: bad argument");
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, 0));
-    int blocks = prop.multiProcessorCount * blocks_per_cu;
-    double *d = nullptr;
-    HIPCHK(hipMalloc(&d, (size_t)blocks * 256 * sizeof(double)));
-    // blocks_per_cu > 0: MFMA probe; the vector-FMA companion is reported through cocons_vfma_f64_probe
-    hipStream_t ps = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
-    *tflops = run_mfma_f64_probe(ps, blocks, 20000, d);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamDestroy(ps));
-    HIPCHK(hipFree(d));
-    return 0;
-}
-
-// extended probe: see run_mfma_f64_probe_ex (chol.hip) for the meaning of out[0..3]
-extern "C" int cocons_mfma_f64_probe_ex(int blocks_per_cu, int nacc, int form, int iters, int gap_us, int reps, double *out4)
-{
-    if (!out4 || blocks_per_cu < 1 || blocks_per_cu > 8 || (nacc != 4 && nacc != 8 && nacc != 16) || form < 0 || form > 3 || form == 2 ||
-        iters < 1 || reps < 1 || gap_us < 0)
-        return fail(-1, "cocons_mfma_f64_probe_ex: bad argument");
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, 0));
-    if (run_mfma_f64_probe_ex(prop.multiProcessorCount * blocks_per_cu, nacc, form, iters, gap_us, reps, out4))
-        return fail(-100, "cocons_mfma_f64_probe_ex: HIP error");
-    return 0;
-}
-
-extern "C" int cocons_vfma_f64_probe(int blocks_per_cu, double *tflops)
-{
-    if (!tflops || blocks_per_cu < 1 || blocks_per_cu > 8) return fail(-1, "cocons_vfma_f64_probe: bad argument");
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, 0));
-    int blocks = prop.multiProcessorCount * blocks_per_cu;
-    double *d = nullptr;
-    HIPCHK(hipMalloc(&d, (size_t)blocks * 256 * sizeof(double)));
-    hipStream_t ps = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
-    *tflops = run_vfma_f64_probe(ps, blocks, 20000, d);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamDestroy(ps));
-    HIPCHK(hipFree(d));
-    return 0;
-}
-
-// diagnostic (not part of the public header): MFMA and FMA probes concurrently on two streams
-extern "C" int cocons_corun_probe(int bpc_mfma, int bpc_vfma, int iters_mfma, int iters_vfma, double *out4)
-{
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, 0));
-    int bm = prop.multiProcessorCount * bpc_mfma, bv = prop.multiProcessorCount * bpc_vfma;
-    double *d = nullptr;
-    HIPCHK(hipMalloc(&d, (size_t)(bm + bv) * 256 * sizeof(double)));
-    run_corun_probe(bm, bv, iters_mfma, iters_vfma, d, out4);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipFree(d));
-    return 0;
-}

@@ -216,10 +216,4 @@ void launch_row_reduce(const double *A, size_t lda, int n, int rowy, int row0, i
 void launch_trmm_lower(const double *A, size_t lda, int n, const double *E, int lde, int nsim,
                        const double *trend, double *Y, int ldy, hipStream_t s);
 
-// fp64 MFMA issue-rate probe (TFLOP/s); dbuf must hold blocks*256 doubles
-double run_mfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf);
-double run_vfma_f64_probe(hipStream_t s, int blocks, int iters, double *dbuf);
-int run_mfma_f64_probe_ex(int blocks, int nacc, int form, int iters, int gap_us, int reps, double *out);
-void run_corun_probe(int blocks_mfma, int blocks_vfma, int iters_mfma, int iters_vfma, double *dbuf, double *out);
-
 }  // namespace cocons

@@ -197,35 +197,60 @@ SEXP _cocons_hip_fit_create(SEXP locs, SEXP X, SEXP z, SEXP x_betas, SEXP smooth
 /* ---- handle cache for callers that pass no handle (the reference's signatures have none) ---------------------------
  * cocoOptim's closures call GetNeg2loglikelihood(theta, par.pos, locs, x_covariates, smooth.limits, z, n, lambda) with
  * the SAME R objects at every parameter step (R/optim.R:237-259), so the cache keys on what is O(1) to check: the
- * process, the addresses and dimensions of the four arrays, smooth.limits, and a fingerprint of a few dozen sampled
- * elements per array (an object R modified in place keeps its address; the sample includes its first and last element).
- * Only when that check misses are the data themselves compared, against the host copies each cached handle keeps
- * (cocons_fit_same_data: O(n), no hashing, no extra package) -- a copy of the same data then re-keys its entry -- and
- * only when that misses too is a handle created.  Per call on the hit path: ~30 comparisons and ~260 loads.
- * (Round 3 hashed all inputs with rlang::hash on EVERY call: ~0.5 MB per 10 ms evaluation at n = 10^4.)               */
+ * process, the addresses and dimensions of the four arrays and smooth.limits.
+ *
+ * What makes the address a sound key (round 5; rounds 3-4 relied on a fingerprint of 64 sampled elements, which an
+ * R-level `z[i] <- v` on an object with one reference -- modified in place, same address -- passes for almost every i):
+ *   - while an entry is cached its four arrays are held with R_PreserveObject: the collector cannot free them, so
+ *     their addresses cannot be handed to another object of the same shape;
+ *   - they are marked MARK_NOT_MUTABLE (NAMED / reference count at its maximum): any modification through R -- `[<-`,
+ *     `[[<-`, `dim<-`, ... -- must duplicate first, and the duplicate has another address => miss => data compared.
+ * Left open by R itself: C code that writes into a vector it was handed (against the API's rules).  HIP_VERIFY_HIT (default 1)
+ * closes that too: an address hit is confirmed by comparing the data with the handle's host copies (cocons_fit_same_data:
+ * three memcmp over (2 + p + r) n doubles, 0.5 MB at n = 10^4 = some 25 us beside a 9 ms evaluation); build with
+ * -DHIP_VERIFY_HIT=0 to trust the addresses alone (the hit then touches no data at all).
+ * On an address miss the data are compared against every cached handle (a copy of the same data re-keys its entry --
+ * e.g. as.matrix(z) of a plain vector makes a new object per call), and only when that misses too is a handle created.
+ * No hash, no package beyond base R.  (Round 3 hashed all inputs with rlang::hash on EVERY call.)                      */
 #define HIP_CACHE_SLOTS 8
-#define HIP_FP_SAMPLES 64
+#ifndef HIP_VERIFY_HIT
+#define HIP_VERIFY_HIT 1
+#endif
 typedef struct {
     int pid, n, p, r, q;
     const double *a_locs, *a_X, *a_z, *a_xb;
-    double sl[2], fp;
+    double sl[2];
     SEXP handle;                /* external pointer, R_PreserveObject'ed while cached */
+    SEXP held[4];               /* locs, X, z, x_betas (or R_NilValue): preserved + immutable while they key the entry */
     unsigned long stamp;        /* least recently used goes first */
 } hip_cache_entry;
 static hip_cache_entry hip_cache[HIP_CACHE_SLOTS];
 static unsigned long hip_cache_clock = 0;
 
-static double sample_sum(const double *a, size_t len)
+static void hip_cache_release_keys(hip_cache_entry *e)
 {
-    if (!a || len == 0) return 0.0;
-    double s = a[0] + 3.0 * a[len - 1];
-    const size_t step = len / HIP_FP_SAMPLES + 1;
-    for (size_t i = step; i < len; i += step) s += a[i] * (double)(1 + (i & 7));
-    return s;
+    for (int k = 0; k < 4; ++k)
+        if (e->held[k] && e->held[k] != R_NilValue) { R_ReleaseObject(e->held[k]); e->held[k] = NULL; }
+}
+
+/* the arrays become the key of entry e: preserved (their addresses stay theirs) and immutable for R code */
+static void hip_cache_hold_keys(hip_cache_entry *e, SEXP locs, SEXP X, SEXP z, SEXP x_betas)
+{
+    SEXP v[4] = {locs, X, z, x_betas};
+    hip_cache_release_keys(e);
+    for (int k = 0; k < 4; ++k) {
+        e->held[k] = NULL;
+        if (v[k] == R_NilValue) continue;
+        MARK_NOT_MUTABLE(v[k]);
+        R_PreserveObject(v[k]);
+        e->held[k] = v[k];
+    }
+    e->a_locs = REAL(locs); e->a_X = REAL(X); e->a_z = REAL(z); e->a_xb = x_betas == R_NilValue ? NULL : REAL(x_betas);
 }
 
 static void hip_cache_drop(hip_cache_entry *e)
 {
+    hip_cache_release_keys(e);
     if (e->handle) R_ReleaseObject(e->handle);
     memset(e, 0, sizeof *e);
 }
@@ -245,16 +270,20 @@ SEXP _cocons_hip_fit_cached(SEXP locs, SEXP X, SEXP z, SEXP x_betas, SEXP smooth
     if (!Rf_isReal(locs) || !Rf_isReal(X) || !Rf_isReal(z) || (q && !Rf_isReal(x_betas)) || !Rf_isReal(smooth_limits))
         Rf_error("locs, x_covariates, z, x_betas and smooth.limits must be double");
     if (Rf_nrows(locs) != n || Rf_ncols(locs) != 2 || XLENGTH(z) != (R_xlen_t)n * r) Rf_error("locs must be n x 2 and z n x r");
+    if (XLENGTH(smooth_limits) != 2) Rf_error("smooth.limits must have two elements");
     const double *a_locs = REAL(locs), *a_X = REAL(X), *a_z = REAL(z), *a_xb = q ? REAL(x_betas) : NULL;
     const double *sl = REAL(smooth_limits);
     const int pid = (int)getpid();
-    const double fp = sample_sum(a_locs, (size_t)2 * n) + sample_sum(a_X, (size_t)n * p) + sample_sum(a_z, (size_t)n * r) +
-                      sample_sum(a_xb, (size_t)n * q);
-    /* 1: the O(1) check */
+    /* 1: the O(1) check -- addresses of preserved, immutable objects */
     for (int i = 0; i < HIP_CACHE_SLOTS; ++i) {
         hip_cache_entry *e = &hip_cache[i];
         if (e->handle && e->pid == pid && e->a_locs == a_locs && e->a_X == a_X && e->a_z == a_z && e->a_xb == a_xb &&
-            e->n == n && e->p == p && e->r == r && e->q == q && e->sl[0] == sl[0] && e->sl[1] == sl[1] && e->fp == fp) {
+            e->n == n && e->p == p && e->r == r && e->q == q && e->sl[0] == sl[0] && e->sl[1] == sl[1]) {
+#if HIP_VERIFY_HIT
+            /* (belt and braces against C code that wrote into one of the arrays: see the header comment) */
+            cocons_fit *hf = (cocons_fit *)R_ExternalPtrAddr(e->handle);
+            if (!hf || !cocons_fit_same_data(hf, n, p, r, q, a_locs, a_X, a_z, a_xb, sl)) { hip_cache_drop(e); break; }
+#endif
             e->stamp = ++hip_cache_clock;
             return e->handle;
         }
@@ -267,7 +296,7 @@ SEXP _cocons_hip_fit_cached(SEXP locs, SEXP X, SEXP z, SEXP x_betas, SEXP smooth
         if (!e->handle) { victim = i; continue; }
         cocons_fit *f = (cocons_fit *)R_ExternalPtrAddr(e->handle);
         if (f && cocons_fit_same_data(f, n, p, r, q, a_locs, a_X, a_z, a_xb, sl)) {
-            e->a_locs = a_locs; e->a_X = a_X; e->a_z = a_z; e->a_xb = a_xb; e->fp = fp;
+            hip_cache_hold_keys(e, locs, X, z, q ? x_betas : R_NilValue);      /* re-key: the new objects are held, the old released */
             e->stamp = ++hip_cache_clock;
             return e->handle;
         }
@@ -287,7 +316,8 @@ SEXP _cocons_hip_fit_cached(SEXP locs, SEXP X, SEXP z, SEXP x_betas, SEXP smooth
     hip_cache_drop(e);
     R_PreserveObject(ptr);
     e->handle = ptr; e->pid = pid; e->n = n; e->p = p; e->r = r; e->q = q;
-    e->a_locs = a_locs; e->a_X = a_X; e->a_z = a_z; e->a_xb = a_xb; e->sl[0] = sl[0]; e->sl[1] = sl[1]; e->fp = fp;
+    e->sl[0] = sl[0]; e->sl[1] = sl[1];
+    hip_cache_hold_keys(e, locs, X, z, q ? x_betas : R_NilValue);
     e->stamp = ++hip_cache_clock;
     UNPROTECT(2);
     return ptr;

@@ -52,4 +52,5 @@ typedef void (*R_CFinalizer_t)(SEXP);
 void R_RegisterCFinalizerEx(SEXP, R_CFinalizer_t, Rboolean);
 void R_PreserveObject(SEXP);
 void R_ReleaseObject(SEXP);
+void (MARK_NOT_MUTABLE)(SEXP);     /* R >= 3.5: NAMED / reference count to its maximum -- R code must duplicate before modifying */
 #endif

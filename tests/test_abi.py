@@ -34,6 +34,13 @@ def test_header_symbols_are_exported_and_bound():
     exported = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
     for nm in re.findall(r" T (cocons_[a-z0-9_]+)", exported):
         assert nm in names or nm in diag, "exported but declared in no header: " + nm
+    # the bare-instruction probes are NOT in the product library: their own header, their own library
+    probes = _declared("cocons_hip_probes.h")
+    assert probes and sorted(_lib.PROBE_SIGNATURES) == probes and not set(probes) & (set(names) | set(diag))
+    assert "probe" not in exported
+    pl = _lib.load_probes()
+    for nm in probes:
+        assert hasattr(pl, nm), "missing export " + nm
 
 
 def test_no_oracle_or_torch_in_product_library():
@@ -102,11 +109,13 @@ def test_glue_covers_the_reference_call_surface():
         assert sym in table, sym
 
 
-def test_glue_handle_lookup_hashes_nothing_on_the_hit_path():
+def test_glue_handle_lookup_is_sound_and_hashes_nothing():
     """The closures keep the reference's signatures (no handle argument: R/neg2loglikelihood.R:183-191), so every call looks
-    its handle up.  That look-up must be O(1) on a hit: no hashing / digest / serialisation of the data anywhere in the R
-    glue, no package beyond base R, and in the native look-up nothing that walks the data (memcmp, cocons_fit_same_data,
-    a loop over all elements) before the address check has returned."""
+    its handle up.  No hashing / digest / serialisation of the data anywhere in the R glue and no package beyond base R; the
+    native look-up keys on ADDRESSES, which is only sound because the keyed objects are preserved (their addresses cannot be
+    recycled) and marked immutable (R code must duplicate before modifying) -- and an address hit is confirmed against the
+    handle's host copies unless the glue is built with -DHIP_VERIFY_HIT=0.  (Round 4's fingerprint of 64 sampled elements let
+    an R-level `z[i] <- v` through; tests/test_glue_exec.py runs that case.)"""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rfile = open(os.path.join(root, "glue", "R", "cocons_hip.R")).read()
@@ -117,15 +126,17 @@ def test_glue_handle_lookup_hashes_nothing_on_the_hit_path():
     body = body[:body.index("\n}\n") + 3]
     assert "_cocons_hip_fit_cached" in body
     glue = open(os.path.join(root, "glue", "cocons_hip_glue.c")).read()
+    hold = glue[glue.index("static void hip_cache_hold_keys("):]
+    hold = hold[:hold.index("\n}\n")]
+    assert "MARK_NOT_MUTABLE(v[k])" in hold and "R_PreserveObject(v[k])" in hold
     fn = glue[glue.index("SEXP _cocons_hip_fit_cached("):]
-    hit = fn[fn.index("/* 1: the O(1) check */"):fn.index("/* 2:")]
-    assert "return e->handle;" in hit
-    for walker in ("memcmp", "cocons_fit_same_data", "sample_sum"):
-        assert walker not in hit, walker
-    # the fingerprint that is computed before the check reads a bounded number of elements per array
-    fp = glue[glue.index("static double sample_sum("):]
-    fp = fp[:fp.index("\n}\n")]
-    assert "HIP_FP_SAMPLES" in fp and re.search(r"i \+= step", fp)
+    hit = fn[fn.index("/* 1: the O(1) check"):fn.index("/* 2:")]
+    assert "return e->handle;" in hit and "sample_sum" not in glue
+    ver = hit[hit.index("#if HIP_VERIFY_HIT"):hit.index("#endif")]
+    assert "cocons_fit_same_data" in ver and "hip_cache_drop(e)" in ver
+    assert "cocons_fit_same_data" not in hit.replace(ver, "")        # without the option the hit touches no data
+    # every path that stores an entry goes through hip_cache_hold_keys (new entry and re-key)
+    assert len(re.findall(r"hip_cache_hold_keys\(e, locs, X, z,", fn)) == 2
 
 
 def test_glue_compiles_against_declared_apis():

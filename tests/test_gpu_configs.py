@@ -100,6 +100,40 @@ def test_c3_n10000_properties():
     assert abs(parts2[1] - parts[1] / s ** 2) < 1e-9 * abs(parts2[1])
 
 
+def test_c3_n10000_vs_cpu(oracle):
+    """C3 at full size against the CPU oracle: cov_rns restatement (serial, ~7 s) + LAPACK dpotrf / dtrtrs on every host
+    core, the same inputs, -2 loglik within the north star's 1e-8 relative; log det and the quadratic form separately
+    (R/neg2loglikelihood.R:183-222)."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    from scipy.linalg import lapack, solve_triangular
+    locs, X, th, z = _grid_problem(100)
+    n = 10000
+    th = {k: np.array(v, dtype=float) for k, v in th.items()}
+    th["mean"] = np.array([0.2, -0.1, 0.05])
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    val, parts = fit.neg2loglik_core(th)
+    assert fit.engine_state()["active"]                 # the shipped schedule (engine + DAG head), not a fall-back
+    S = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    R, info = lapack.dpotrf(S, lower=0, clean=0, overwrite_a=1)
+    assert info == 0
+    logdet = float(np.sum(np.log(np.diag(R))))
+    y = solve_triangular(R, z - X @ th["mean"], trans="T", lower=False, check_finite=False)
+    quad = float(y @ y)
+    want = n * math.log(2 * math.pi) + 2 * logdet + quad
+    assert abs(parts[0] - logdet) <= 1e-10 * abs(logdet)
+    assert abs(parts[1] - quad) <= 1e-8 * abs(quad)
+    assert abs(val - want) <= 1e-8 * abs(want)
+    # the public closure with the penalty on top (host arithmetic) against the oracle's, same Sigma
+    pp = wl.par_pos_full()
+    pp["mean"] = [True, True, True]
+    tv = np.concatenate([th["mean"], wl.theta_vector_from_lists(th, wl.par_pos_full())])
+    lam = (0.1, 0.05, 0.2)
+    got = ca.GetNeg2loglikelihood(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    tl = oracle.getModelLists(tv, pp, "diff")
+    assert abs(got - (want + oracle.getPen(n, lam, tl, wl.SMOOTH_LIMITS))) <= 1e-8 * abs(want)
+
+
 def test_c4_optimizer_in_the_loop(oracle):
     """C4 pattern at a size the oracle affords: L-BFGS-B with central differences
     (ndeps = eps^(1/4), 1 + 2P evaluations per gradient) on the GPU objective; the GPU and the
@@ -206,6 +240,24 @@ def test_c5_predict_8192_properties():
     assert np.all(np.isfinite(out["stochastic"])) and np.all(np.isfinite(out["sd.pred"]))
     dvar = 1 / np.exp(-(Xp @ th["std.dev"])) + np.exp(Xp @ th["nugget"])
     assert np.all(out["sd.pred"] ** 2 <= dvar * (1 + 1e-9))
+
+
+def test_c5_predict_8192_vs_cpu(oracle):
+    """C5 at full size against the CPU oracle: the GPU predicts at all m = 8192 shifted-grid locations; 512 of them
+    (every 16th) are predicted by oracle.cocoPredict_dense -- cov_rns + cov_rns_pred restatements and LAPACK's LU solve,
+    R/predict.R:136-183 -- on the same training set.  Every prediction row's solve is independent of the others, so the
+    rows must agree one by one: stochastic part and prediction standard deviation."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, z, lp, Xp = _c5_problem()
+    got = ca.cocoPredict_dense(th, locs, lp, X, Xp, wl.SMOOTH_LIMITS, z)
+    idx = np.arange(0, 8192, 16)
+    assert idx.size == 512
+    want = oracle.cocoPredict_dense(th, locs, lp[idx], X, Xp[idx], wl.SMOOTH_LIMITS, z)
+    scale = np.max(np.abs(want["stochastic"]))
+    assert np.max(np.abs(got["stochastic"][idx] - want["stochastic"])) <= 1e-8 * scale
+    assert np.max(np.abs(got["systematic"][idx] - want["systematic"])) <= 1e-13 * max(1.0, np.max(np.abs(want["systematic"])))
+    assert np.max(np.abs(got["sd.pred"][idx] - want["sd.pred"]) / want["sd.pred"]) <= 1e-8
 
 
 def _free_port():

@@ -1,7 +1,7 @@
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "cocons_amd", "csrc", "libcocons_hip.so"))
+L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "cocons_amd", "csrc", "libcocons_hip_probes.so"))
 L.cocons_corun_probe.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_double)]
 out = np.zeros(4)
 for bm, bv in ((4, 4), (4, 2), (2, 4), (6, 2), (8, 0), (0, 8)):

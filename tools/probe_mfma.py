@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cocons_amd import _lib
 
-L = _lib.load()
+L = _lib.load_probes()          # libcocons_hip_probes.so: the probes are not in the product library
 for bpc in (1, 2, 4, 8):
     t = ctypes.c_double()
     _lib.check(L.cocons_mfma_f64_probe(bpc, ctypes.byref(t)), "probe")

@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cocons_amd import _lib
 
-L = _lib.load()
+L = _lib.load_probes()          # libcocons_hip_probes.so: the probes are not in the product library
 rows = []
 
 
