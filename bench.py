@@ -48,6 +48,9 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (= fp64 vector 
 #                                  x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 issues every 64 cycles
 MFMA_UTIL_PROFILE = "r03_update_kernel_mfma_util.json"      # matrix pipe busy fraction of the update kernel (rocprofv3 --pmc)
 TRAFFIC_PROFILE = "r03_update_kernel_hbm_traffic.json"
+# the persistent launch (dag_kernel) replayed alone under the counters (round 5: tools/dag_replay.py, tools/r5_pmc_dag.sh)
+DAG_UTIL_PROFILE = "r05_dag_kernel_mfma_util.json"
+DAG_TRAFFIC_PROFILE = "r05_dag_kernel_hbm_traffic.json"
 
 
 def chol_flops(n):
@@ -96,6 +99,133 @@ def cpu_baseline(n, locs, X, th, z, want_value=True):
     }, (val if info == 0 else float("nan"))
 
 
+def other_configs(device, steps_c2=60, evals_c4=50):
+    """BASELINE configs C2, C4 and C5 on this GPU, measured after the timed region of the headline (C3) -- supplementary
+    numbers on the same line, never `value`.
+      C2  64 x 64 grid, n = 4096, full nonstationary model: sequential -2 loglik evaluations/s, stages, Cholesky TFLOP/s.
+      C4  the same problem inside L-BFGS-B as cocoOptim configures it (R/optim.R:237-259, R/profile.R:11-18: central
+          differences, 1 + 2P points per gradient), ~50 evaluations: evaluations/s with the points one after the other and
+          with each gradient's points through the batch entry -- and the HOST / DEVICE split: the very parameter vectors the
+          optimiser visited are evaluated again (a) through the C ABI alone (cocons_neg2loglik_dense: device + one launch
+          sequence + one synchronisation each) and (b) through the full host closure (getModelLists, penalty, ctypes) without
+          the optimiser, so that what the loop costs beyond the device is attributed: closure plumbing, optimiser, the rest.
+      C5  cocoPredict core, n = m = 8192 (128 x 64 grid, half-cell-shifted prediction grid): wall ms, TFLOP/s on
+          n^3/3 + n^2 m (R/predict.R:136-183)."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from optim_loop import lbfgsb_central
+    out = {}
+    # ---- C2
+    g = 64
+    n = g * g
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    th = wl.theta_full()
+    z = wl.synthetic_z(n)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, device=device)
+    for _ in range(5):
+        fit.neg2loglik_core(th)
+    t0 = time.perf_counter()
+    for _ in range(steps_c2):
+        v2 = fit.neg2loglik_core(th)[0]
+    dt = (time.perf_counter() - t0) / steps_c2
+    st = fit.profile_stages(th, reps=5)
+    ctf = chol_flops(n) / (st["cholesky_ms"] * 1e-3) / 1e12
+    out["C2"] = {"workload": "64x64 grid n=4096, p=3, full nonstationary cov_rns, dense -2loglik, sequential",
+                 "evals_per_s": round(1.0 / dt, 2), "ms_per_eval": round(1e3 * dt, 4), "evals": steps_c2,
+                 "stages_ms": {k: round(st[k], 4) for k in ("assembly_ms", "cholesky_ms", "reduce_ms", "eval_ms")},
+                 "cholesky_tflops_fp64": round(ctf, 3), "cholesky_frac": round(ctf / FP64_MFMA_PEAK_TFLOPS, 4),
+                 "host_turnaround_ms": round(1e3 * dt - st["eval_ms"], 4), "neg2loglik": v2,
+                 "engine": fit.engine_state()}
+    # ---- C4
+    pp = wl.par_pos_full()
+    x0 = wl.theta_vector_from_lists(th, pp) + 0.1
+    lam = (0.0, 0.0, 0.0)
+    visited = []
+
+    def fn(t):
+        visited.append(np.array(t, dtype=float))
+        return ca.GetNeg2loglikelihood(t, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+
+    def fnb(ts):
+        return ca.GetNeg2loglikelihood_batch(ts, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+
+    fn(x0)
+    visited.clear()
+    t0 = time.perf_counter()
+    res = lbfgsb_central(fn, x0, x0 - 3, x0 + 3, max_evals=evals_c4)
+    dt_loop = time.perf_counter() - t0
+    pts = list(visited)
+    tls = [ca.getModelLists(t, pp, "diff") for t in pts]
+    # (a) the same points through the C ABI alone; Cholesky failures (a line search may leave the positive definite region)
+    #     cost what a success costs and are counted
+    fails = 0
+    t0 = time.perf_counter()
+    for tl in tls:
+        try:
+            fit.neg2loglik_core(tl)
+        except ca.CholeskyError:
+            fails += 1
+    dt_abi = time.perf_counter() - t0
+    # (b) through the host closure, no optimiser
+    t0 = time.perf_counter()
+    for t in pts:
+        ca.GetNeg2loglikelihood(t, pp, locs, X, wl.SMOOTH_LIMITS, z, n, lam, fit=fit)
+    dt_clo = time.perf_counter() - t0
+    # (c) device time alone at the first and the last point the optimiser visited that is positive definite
+    dev_ms = []
+    for tl in (tls[0], tls[-1]):
+        try:
+            dev_ms.append(round(fit.profile_stages(tl, reps=3)["eval_ms"], 4))
+        except ca.CholeskyError:
+            dev_ms.append(None)
+    nev = max(len(pts), 1)
+    fnb([x0, x0])
+    t0 = time.perf_counter()
+    resb = lbfgsb_central(fn, x0, x0 - 3, x0 + 3, max_evals=evals_c4, fn_batch=fnb)
+    dt_b = time.perf_counter() - t0
+    out["C4"] = {"workload": "C2's problem inside L-BFGS-B (central differences, P = %d, 1 + 2P points per gradient), ~%d evaluations"
+                             % (x0.size, evals_c4),
+                 "sequential": {"evals": res["nfev"], "evals_per_s": round(res["nfev"] / dt_loop, 2),
+                                "ms_per_eval": round(1e3 * dt_loop / res["nfev"], 4)},
+                 "batched_gradient_points": {"evals": resb["nfev"], "evals_per_s": round(resb["nfev"] / dt_b, 2),
+                                             "ms_per_eval": round(1e3 * dt_b / resb["nfev"], 4)},
+                 "split_ms_per_eval": {"device_eval_ms_first_last_point": dev_ms,
+                                       "c_abi_call": round(1e3 * dt_abi / nev, 4),
+                                       "host_closure": round(1e3 * (dt_clo - dt_abi) / nev, 4),
+                                       "optimiser_and_rest": round(1e3 * (dt_loop - dt_clo) / nev, 4),
+                                       "loop_total": round(1e3 * dt_loop / nev, 4)},
+                 "cholesky_failures_among_visited_points": fails,
+                 "f_start_end": [float(fn(x0)), float(res["fun"])], "engine": fit.engine_state()}
+    fit.close()
+    # ---- C5
+    locs = wl.grid_locs(128, 64)
+    sc = wl.design_from_locs(locs)
+    X = sc["std.covs"]
+    th5 = wl.theta_full()
+    th5["mean"] = np.array([0.3, -0.1, 0.2])
+    z = wl.synthetic_z(8192)
+    lp = locs + np.array([0.5 / 127, 0.5 / 63])
+    Xp = wl.design_from_locs(lp, sc["mean.vector"], sc["sd.vector"])["std.covs"]
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, device=device)
+    fit.predict_core(th5, lp, Xp)
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        fit.predict_core(th5, lp, Xp)
+        ts.append(time.perf_counter() - t0)
+    n5 = m5 = 8192
+    fl = n5 ** 3 / 3.0 + float(m5) * n5 * n5
+    out["C5"] = {"workload": "cocoPredict core n_train = m_pred = 8192 (128x64 grid, half-cell-shifted prediction grid), one GPU",
+                 "wall_ms_min": round(1e3 * min(ts), 3), "wall_ms_median": round(1e3 * sorted(ts)[len(ts) // 2], 3),
+                 "tflops_fp64": round(fl / min(ts) / 1e12, 2), "frac": round(fl / min(ts) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                 "flops": fl, "note": "n^3/3 + n^2 m flop: bordered Cholesky with the m cross-covariance rows as border; host "
+                                      "vectors in, (stochastic, quadratic form) out", "engine": fit.engine_state()}
+    fit.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +234,7 @@ def main():
     ap.add_argument("--n", type=int, default=10000, help="number of locations (square grid edge^2)")
     ap.add_argument("--mode", choices=["shard", "replica"], default="shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the supplementary C2 / C4 / C5 measurements")
     ap.add_argument("--inflight", type=int, default=2,
                     help="extra measurement at N=1: this many independent evaluations in flight on the GPU "
                          "(separate fit handles / streams, as optimParallel's workers issue them); 0 = skip")
@@ -364,6 +495,15 @@ def main():
         except Exception as e:                          # noqa: BLE001 -- supplementary: reported, not fatal
             taper = {"error": repr(e)}
 
+    # extra (N=1, n = 10^4 only): BASELINE's other configurations on the same GPU (C2, C4, C5) -- see other_configs()
+    configs = None
+    if world == 1 and n == 10000 and not args.no_configs:
+        try:
+            configs = other_configs(local_rank)
+        except Exception as e:                          # noqa: BLE001 -- supplementary: reported, not fatal
+            import traceback
+            configs = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
+
     out = None
     if rank == 0:
         # (stage timings and the dominant kernel's roofline: `st`, taken right behind the timed steps above)
@@ -410,7 +550,32 @@ def main():
             if n == 10000 and os.path.exists(tr):
                 with open(tr) as fh:
                     tj = json.load(fh)
-                if dag:
+                dtr = os.path.join(ROOT, "profiles", DAG_TRAFFIC_PROFILE)
+                dmu = os.path.join(ROOT, "profiles", DAG_UTIL_PROFILE)
+                if dag and os.path.exists(dtr) and os.path.exists(dmu):
+                    # Round 5: the SAME launch replayed alone under rocprofv3 --pmc (same task list, products and C traffic; what
+                    # the engine publishes prepared beforehand -- cocons_debug_dag_replay).  Per launch, separate passes.
+                    with open(dtr) as fh:
+                        dj = json.load(fh)
+                    with open(dmu) as fh:
+                        uj = json.load(fh)
+                    roofline["traffic"] = dj.get("hbm_bytes_per_launch")
+                    roofline["traffic_high"] = dj.get("hbm_bytes_per_launch_high")
+                    roofline["traffic_l2_hit_rate"] = dj.get("l2_hit_rate")
+                    # what the K = 256 blocking needs: every C tile of every step read and written once (16 B per element
+                    # and step) + the panels once
+                    roofline["traffic_algorithmic"] = round(16.0 * st["dag_flops"] / (2.0 * 256.0), 1)
+                    roofline["traffic_source"] = ("NOT measured in this run: profiles/%s (FETCH_SIZE raw + WRITE_SIZE of cocons::dag_kernel "
+                                                  "replayed alone, tools/r5_pmc_dag.sh, commit %s); `traffic_high` applies the guide's "
+                                                  "x2 to FETCH_SIZE (calibrated for 16 B/lane reads; the C tiles are read 8 B/lane); "
+                                                  "`traffic_algorithmic` = C read + write once per step at K = 256"
+                                                  % (DAG_TRAFFIC_PROFILE, dj.get("commit", "?")))
+                    roofline["pipe_busy_frac_pmc"] = round(uj.get("mfma_busy_over_simd_cycles", 0.0), 3)
+                    roofline["pipe_busy_source"] = ("NOT measured in this run: profiles/%s (SQ_VALU_MFMA_BUSY_CYCLES over SIMD cycles of "
+                                                    "the replayed launch, %.0f us under the counters, clock %.2f GHz)"
+                                                    % (DAG_UTIL_PROFILE, uj.get("launch_us_under_pmc", 0.0),
+                                                       uj.get("clock_GHz_from_GRBM_GUI_ACTIVE", 0.0)))
+                elif dag:
                     # The persistent launch cannot be counted: rocprofv3 --pmc serialises kernels, and this launch waits for its
                     # partner on the other stream (the diagonal-block engine).  What exists is the count for the SAME tile kernel
                     # in separate launches (the plain schedule, round 3): per evaluation FETCH + WRITE for all 39 updates -- the
@@ -476,6 +641,7 @@ def main():
             "throughput_inflight": inflight,
             "throughput_batch_api": batch,
             "taper_path": taper,
+            "configs": configs,
             "replica_mode": replica,
             "parity_rel_err_vs_cpu": parity,
             "roofline": roofline,

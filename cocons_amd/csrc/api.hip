@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -145,6 +146,7 @@ struct RcclApi {
     ncclResult_t (*CommAbort)(ncclComm_t);
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *);      // optional (RCCL >= 2.18): may be null
 };
 
 static RcclApi *rccl_api()
@@ -197,6 +199,7 @@ static RcclApi *rccl_api()
         RSYM(Send, "ncclSend")
         RSYM(Recv, "ncclRecv")
 #undef RSYM
+        *(void **)(&api.CommSplit) = dlsym(h, "ncclCommSplit");
         state = 1;
     }
     return state == 1 ? &api : nullptr;
@@ -281,6 +284,7 @@ struct cocons_fit {
     void *ddag_steps; int dag_nsteps; unsigned dag_ntasks;
     int dag_key[9];               // (nt, mt, trim, kskip, lead, min_tiles, split, lead2, lead3) the step table was built for
     unsigned long long *ddag_trace; size_t dag_trace_tasks;   // diagnostics (cocons_debug_tune("dag_trace", 1)): 4 stamps per task
+    size_t dag_trace_elems;       // allocated 64-bit words of ddag_trace (5 per task + 8 per tile pair)
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
     bool dag_used;                // the factorisation enqueued last ran the DAG schedule: its factor is split over dA and dP
     double dag_flops; int dag_events;   // profile runs: update flops inside the DAG launch; 1 = the first event pair is that launch
@@ -305,7 +309,13 @@ struct cocons_fit {
     cocons_allgather_fn cb_allgather;
     struct ShardState *shard;     // plan, buffers and events of the sharded evaluation (row-block ownership)
     void *cb_user;
-    hipStream_t cstream;          // stream the panel broadcasts are issued on
+    hipStream_t cstream;          // stream the bulk exchange (all-gather of the solved rows) is issued on
+    hipStream_t cstream_l;        // stream the 0.56 MB broadcasts of the factored diagonal blocks are issued on: the chain from one
+                                  // diagonal block to the next never queues behind an all-gather (== cstream when the
+                                  // broadcasts have no communicator of their own)
+    ncclComm_t comm_l;            // RCCL: a second communicator over the same ranks (ncclCommSplit) for those broadcasts --
+                                  // operations of ONE communicator are serialised whatever stream they are given; null: comm
+    bool comm_l_own;
     double *dcoll;                // device staging of the final all-reduce (RCCL)
     double upd_flops;             // algorithmic flops of the event-timed trailing updates (profile runs)
     // host copies of the inputs + lazily created clones: the slots of cocons_neg2loglik_batch
@@ -316,6 +326,18 @@ struct cocons_fit {
 };
 
 static void shard_state_free(struct ShardState *S);
+
+// Every live handle of the process: engine_warm tests a new handle's streams against the streams of the others (a resident
+// engine of one handle must not share a hardware queue with the main stream of another: the batch slots and callers with
+// several handles in flight run exactly that combination).
+static std::mutex g_reg_mutex;
+static std::vector<cocons_fit *> g_registry;
+static void registry_add(cocons_fit *f) { std::lock_guard<std::mutex> lk(g_reg_mutex); g_registry.push_back(f); }
+static void registry_remove(cocons_fit *f)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    g_registry.erase(std::remove(g_registry.begin(), g_registry.end(), f), g_registry.end());
+}
 
 static int fit_check(cocons_fit *f)
 {
@@ -347,6 +369,7 @@ static int fit_alloc_matrix(cocons_fit *f, int rhs_rows)
 extern "C" void cocons_fit_destroy(cocons_fit *f)
 {
     if (!f) return;
+    registry_remove(f);
     if (f->pid == getpid()) {
         hipSetDevice(f->device);
         if (f->stream) hipStreamSynchronize(f->stream);
@@ -361,9 +384,11 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         hipFree(f->dflags);
         hipFree(f->dP); hipFree(f->dWt); hipFree(f->ddag); hipFree(f->ddag_steps); hipFree(f->ddag_trace); hipFree(f->dpart);
         hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_thi);
+        if (f->cstream_l && f->cstream_l != f->cstream) { hipStreamSynchronize(f->cstream_l); hipStreamDestroy(f->cstream_l); }
         if (f->cstream) { hipStreamSynchronize(f->cstream); hipStreamDestroy(f->cstream); }
         shard_state_free(f->shard);
         hipFree(f->dcoll);
+        if (f->comm_l && f->comm_l_own) rccl_comm_destroy(f->comm_l);
         if (f->comm && f->comm_own) rccl_comm_destroy(f->comm);
         if (f->slots) { for (auto c : *f->slots) cocons_fit_destroy(c); delete f->slots; f->slots = nullptr; }
         if (f->unsorted) { cocons_fit_destroy(f->unsorted); f->unsorted = nullptr; }
@@ -543,6 +568,7 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     if (!defer_matrix && fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
 #undef CK
     if (engine_warm(f) != 0) { cocons_fit_destroy(f); return nullptr; }
+    registry_add(f);
     return f;
 }
 
@@ -927,7 +953,8 @@ struct Tunables {
     int dag_min_tiles = 3000;  // COCONS_DAG_MIN_TILES: the DAG launch covers the leading steps of at least this many update tiles
                              // (n = 10^4: 21 of the 39 steps, 87 % of the flops; below n ~ 5200 no step at all)
     int dag_split = 1;       // COCONS_DAG_SPLIT: the diagonal-block tiles of a DAG step in two halves, the first one off the chain
-    int dag_xcc_quota = 208; // workgroups of the DAG launch that take part on the engine's XCD (of the 255 that land there; 0: all)
+    int dag_xcc_quota = -1;  // workgroups of the DAG launch that take part on the engine's XCD (of the 255 that land there; 0: all;
+                             // -1: derived from the device, dag_xcc_quota() -- 208 on MI355X)
     int dag_trace = 0;       // (diagnostics) time stamps per task, cocons_debug_dag_trace
     int gate_sabotage = 0;   // (tests) the next N engine-schedule factorisations wait at the gate for a word nobody raises:
                              // a genuine 5 ms time-out, abort code 0x600, to exercise the fall-back and its book-keeping
@@ -973,6 +1000,28 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "c_wt") set_update_c_wt(value);
     else return fail(-1, "cocons_debug_tune: unknown switch %s", name);
     return 0;
+}
+
+// Workgroups of the persistent launch that may take part on the XCD that also hosts the engine.
+// Measured there: an XCD that runs kernels of two queues does not hold eight of these workgroups on every CU -- 227 instead of
+// 248 beside the engine's CU: seven on most, eight on some -- and the set that fits changes when the driver's save / restore
+// moves the engine.  The quota keeps the launch below what fits in ANY placement: seven per CU on the XCD's other CUs, less
+// one CU's worth and one: (CUs per XCD - 1) x 7 - 9 = 208 for the 32 CUs per XCD of MI355X (the value of round 4's soak runs:
+// 0 time-outs in 40 000 evaluations), from hipDeviceProp instead of a constant; COCONS_DAG_XCC_QUOTA overrides.
+static int dag_xcc_quota()
+{
+    if (tun().dag_xcc_quota >= 0) return tun().dag_xcc_quota;
+    static int derived = -1;
+    if (derived < 0) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int xcds = 8;                                 // gfx950: eight accelerator dies (no HIP attribute reports it)
+        const int cpx = cus % xcds == 0 ? cus / xcds : 32;
+        derived = (cpx - 1) * 7 - 9;
+        if (derived < 8) derived = 8;
+    }
+    return derived;
 }
 
 // COCONS_ENGINE: 1 (default) = diagonal tiles are factored by the resident engine while the trailing
@@ -1075,6 +1124,45 @@ static int engine_warm(cocons_fit *f)
             f->stream2 = nullptr;
             if (hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking) != hipSuccess) { ok = -1; break; }
         }
+        // ... and across handles: this handle's engine beside every other live handle's main stream, and every other live
+        // handle's engine beside this handle's main stream.  (The own-pair test above says nothing about those: with a few
+        // more streams in the process -- a batch slot, a second handle of the caller, torch's -- A.main can share a queue
+        // with B.engine and B.main with A.engine: each engine then blocks the kernels the OTHER evaluation waits for, and only
+        // the bounded waits end it -- correct values, seconds lost.)  Streams of handles that are busy right now are not
+        // probed (the probe needs idle streams); a collision redraws THIS handle's stream and repeats all tests.
+        unsigned *words = f->dflags + 3 * (size_t)f->flags_cap + 8;
+        for (int round = 0; ok == 1 && round < 8; ++round) {
+            std::vector<cocons_fit *> others;
+            {
+                std::lock_guard<std::mutex> lk(g_reg_mutex);
+                for (cocons_fit *o : g_registry)
+                    if (o != f && o->pid == f->pid && o->device == f->device && o->stream && o->stream2 && o->engine_ok &&
+                        hipStreamQuery(o->stream) == hipSuccess && hipStreamQuery(o->stream2) == hipSuccess)
+                        others.push_back(o);
+            }
+            (void)hipGetLastError();
+            int clash = 0;                 // 1: this engine stream beside another main stream; 2: this main stream beside another engine
+            for (cocons_fit *o : others) {
+                int a = streams_run_concurrently(f->stream2, o->stream, words);
+                if (a < 0) { ok = -1; break; }
+                if (a == 0) { clash = 1; break; }
+                if (f->own_stream) {
+                    int b = streams_run_concurrently(o->stream2, f->stream, words);
+                    if (b < 0) { ok = -1; break; }
+                    if (b == 0) { clash = 2; break; }
+                }
+            }
+            if (ok != 1 || clash == 0) break;
+            hipStream_t &mine = clash == 1 ? f->stream2 : f->stream;
+            losers.push_back(mine);
+            mine = nullptr;
+            if (hipStreamCreateWithFlags(&mine, hipStreamNonBlocking) != hipSuccess) { ok = -1; break; }
+            // the redrawn stream must still pair with this handle's other stream
+            int again = streams_run_concurrently(f->stream2, f->stream, words);
+            if (again < 0) { ok = -1; break; }
+            if (again == 0) { ok = 0; break; }
+            if (round == 7) ok = 0;        // no assignment found: this handle stays on the plain schedule
+        }
         for (hipStream_t l : losers) hipStreamDestroy(l);
         if (ok < 0) { (void)hipGetLastError(); return fail(-100, "engine_warm: stream self-test failed"); }
         if (ok == 0) { f->engine_ok = false; return 0; }
@@ -1143,13 +1231,19 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         }
     }
     HIPCHK(hipMemsetAsync(f->ddag, 0, f->ddag_words * sizeof(unsigned), f->stream));
-    if (tun().dag_trace && f->dag_trace_tasks < f->dag_ntasks) {
-        if (f->ddag_trace) { HIPCHK(hipFree(f->ddag_trace)); f->ddag_trace = nullptr; }
-        HIPCHK(hipMalloc(&f->ddag_trace, ((size_t)f->dag_ntasks * 5 + 8 * (size_t)(v.nt + 2)) * sizeof(unsigned long long)));   // + the engine's + hw_where() per task
-        f->dag_trace_tasks = f->dag_ntasks;
+    // trace buffer: 4 stamps + one word of hw_where() pairs per task, 8 stamps per tile pair of the engine -- sized by BOTH
+    // the task count and the tile count of THIS step table (a later table with fewer tasks and more tiles must not run past it)
+    const size_t trace_elems = (size_t)f->dag_ntasks * 5 + 8 * (size_t)(v.nt + 2);
+    if (tun().dag_trace && f->dag_trace_elems < trace_elems) {
+        HIPCHK(hipStreamSynchronize(f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->ddag_trace) { HIPCHK(hipFree(f->ddag_trace)); f->ddag_trace = nullptr; f->dag_trace_elems = 0; }
+        HIPCHK(hipMalloc(&f->ddag_trace, trace_elems * sizeof(unsigned long long)));
+        f->dag_trace_elems = trace_elems;
     }
-    if (tun().dag_trace && f->ddag_trace)
-        HIPCHK(hipMemsetAsync(f->ddag_trace, 0, ((size_t)f->dag_ntasks * 5 + 8 * (size_t)(v.nt + 2)) * sizeof(unsigned long long), f->stream));
+    f->dag_trace_tasks = (tun().dag_trace && f->ddag_trace) ? f->dag_ntasks : 0;      // 0: the buffer does not describe this table
+    if (f->dag_trace_tasks)
+        HIPCHK(hipMemsetAsync(f->ddag_trace, 0, trace_elems * sizeof(unsigned long long), f->stream));
     return 0;
 }
 
@@ -1164,14 +1258,20 @@ extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int 
     if (!f->ddag_steps) return fail(-1, "cocons_debug_dag_trace: no DAG factorisation on this handle yet");
     if (nsteps_out) *nsteps_out = f->dag_nsteps;
     HIPCHK(hipStreamSynchronize(f->stream));
-    if (steps_out) HIPCHK(hipMemcpy(steps_out, f->ddag_steps, (size_t)f->dag_nsteps * sizeof(DagStepHost), hipMemcpyDeviceToHost));
+    // (asynchronous copies on the handle's own stream: a synchronous hipMemcpy runs on the NULL stream, gives it a hardware
+    // queue and shifts every later stream's assignment -- the tool would perturb what it observes)
+    if (steps_out)
+        HIPCHK(hipMemcpyAsync(steps_out, f->ddag_steps, (size_t)f->dag_nsteps * sizeof(DagStepHost), hipMemcpyDeviceToHost, f->stream));
     if (stamps_out) {
-        if (!f->ddag_trace) return fail(-1, "cocons_debug_dag_trace: tracing was off (cocons_debug_tune(\"dag_trace\", 1))");
-        HIPCHK(hipMemcpy(stamps_out, f->ddag_trace, (size_t)f->dag_ntasks * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (!f->ddag_trace || f->dag_trace_tasks != f->dag_ntasks)
+            return fail(-1, "cocons_debug_dag_trace: tracing was off (cocons_debug_tune(\"dag_trace\", 1))");
+        HIPCHK(hipMemcpyAsync(stamps_out, f->ddag_trace, (size_t)f->dag_ntasks * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                              f->stream));
         if (engine_out)
-            HIPCHK(hipMemcpy(engine_out, f->ddag_trace + 4 * (size_t)f->dag_ntasks, 8 * (size_t)(f->nt + 2) * sizeof(unsigned long long),
-                             hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpyAsync(engine_out, f->ddag_trace + 4 * (size_t)f->dag_ntasks, 8 * (size_t)(f->nt + 2) * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, f->stream));
     }
+    HIPCHK(hipStreamSynchronize(f->stream));
     return (long long)f->dag_ntasks;
 }
 
@@ -1192,7 +1292,7 @@ static int engine_start(cocons_fit *f, const FactorView &v)
     launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
                         f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dag_next ? f->dWt : nullptr,
                         f->dag_next ? f->dP : nullptr, f->dag_next ? 2 * f->dag_nsteps : 0,
-                        (f->dag_next && tun().dag_trace && f->ddag_trace) ? f->ddag_trace + 4 * (size_t)f->dag_ntasks : nullptr);
+                        (f->dag_next && f->dag_trace_tasks) ? f->ddag_trace + 4 * (size_t)f->dag_ntasks : nullptr);
     f->engine_live = true;
     return 0;
 }
@@ -1287,8 +1387,8 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
             hipEventRecord(ea, M);
         }
         launch_dag(v.A, v.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
-                   pdone, (int)T64, pall, f->dpart, dcount, in, out, xr, abort_word, M, tun().dag_trace ? f->ddag_trace : nullptr,
-                   alive, tun().dag_xcc_quota, f->ddag_trace ? (unsigned *)(f->ddag_trace + 4 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2)) : nullptr);
+                   pdone, (int)T64, pall, f->dpart, dcount, in, out, xr, abort_word, M, f->dag_trace_tasks ? f->ddag_trace : nullptr,
+                   alive, dag_xcc_quota(), f->dag_trace_tasks ? (unsigned *)(f->ddag_trace + 4 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2)) : nullptr);
         if (ev_upd) { hipEventRecord(eb, M); ev_upd->push_back(ea); ev_upd->push_back(eb); f->dag_events = 1; }
         k_first = 2 * f->dag_nsteps;
     }
@@ -1394,7 +1494,7 @@ static int info_status(cocons_fit *f)
                 char path[512];
                 snprintf(path, sizeof path, "%s.%d", dump, ndump++);
                 if (FILE *fp = fopen(path, "wb")) {
-                    const unsigned ntr = (tun().dag_trace && f->ddag_trace) ? 1u : 0u;
+                    const unsigned ntr = f->dag_trace_tasks ? 1u : 0u;
                     unsigned hdr[16] = {0xDA6D0001u, (unsigned)f->nt, (unsigned)f->dag_nsteps, f->dag_ntasks, (unsigned)f->ddag_words,
                                         (unsigned)f->flags_cap, ntr, (unsigned)f->hinfo[1], qn, now, 0, 0, 0, 0, 0, 0};
                     fwrite(hdr, sizeof hdr, 1, fp);
@@ -1418,7 +1518,7 @@ static int info_status(cocons_fit *f)
                     fprintf(stderr, "cocons: state written to %s\n", path);
                 }
             }
-            if (tun().dag_trace && f->ddag_trace && !getenv("COCONS_DEBUG_ABORT_DUMP")) {
+            if (f->dag_trace_tasks && !getenv("COCONS_DEBUG_ABORT_DUMP")) {
                 // which tasks were drawn and never finished (stamps: drawn, inputs complete, product done, stored)
                 std::vector<unsigned long long> st((size_t)f->dag_ntasks * 4);
                 hipMemcpyAsync(st.data(), f->ddag_trace, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, f->stream);
@@ -1481,6 +1581,12 @@ extern "C" int cocons_fit_engine_state(cocons_fit *f, int *out)
     out[0] = f->engine_active_last ? 1 : 0;
     out[1] = f->engine_retries;
     out[2] = f->engine_last_abort;
+    // (the slots of cocons_neg2loglik_batch are handles of their own: their time-outs count for this handle)
+    if (f->slots)
+        for (cocons_fit *c : *f->slots) {
+            out[1] += c->engine_retries;
+            if (!out[2]) out[2] = c->engine_last_abort;
+        }
     return 0;
 }
 
@@ -1545,15 +1651,17 @@ static cocons_fit *clone_for_slot(cocons_fit *f)
     bool ok = hipMalloc(&c->d_tci, nnz * sizeof(int)) == hipSuccess &&
               hipMalloc(&c->d_trp, (size_t)(f->n + 1) * sizeof(int)) == hipSuccess &&
               hipMalloc(&c->d_tval, nnz * sizeof(double)) == hipSuccess &&
-              hipMemcpy(c->d_tci, f->d_tci, nnz * sizeof(int), hipMemcpyDeviceToDevice) == hipSuccess &&
-              hipMemcpy(c->d_trp, f->d_trp, (size_t)(f->n + 1) * sizeof(int), hipMemcpyDeviceToDevice) == hipSuccess &&
-              hipMemcpy(c->d_tval, f->d_tval, nnz * sizeof(double), hipMemcpyDeviceToDevice) == hipSuccess;
+              // (asynchronous on the clone's own stream: the library makes no call on the NULL stream)
+              hipMemcpyAsync(c->d_tci, f->d_tci, nnz * sizeof(int), hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
+              hipMemcpyAsync(c->d_trp, f->d_trp, (size_t)(f->n + 1) * sizeof(int), hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
+              hipMemcpyAsync(c->d_tval, f->d_tval, nnz * sizeof(double), hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
     c->taper_hi = new std::vector<int>(*f->taper_hi);
     c->taper_inv = new std::vector<int>(*f->taper_inv);
     c->taper_maxband = f->taper_maxband;
     if (ok && f->d_thi)
         ok = hipMalloc(&c->d_thi, (size_t)f->nt * sizeof(int)) == hipSuccess &&
-             hipMemcpy(c->d_thi, f->d_thi, (size_t)f->nt * sizeof(int), hipMemcpyDeviceToDevice) == hipSuccess;
+             hipMemcpyAsync(c->d_thi, f->d_thi, (size_t)f->nt * sizeof(int), hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+    if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
     if (!ok) { cocons_fit_destroy(c); return nullptr; }
     c->taper_nnz = f->taper_nnz;
     c->engine_ok = f->engine_ok;              // a band-limited handle never uses the engine, nor do its clones
@@ -2484,6 +2592,8 @@ struct ShardState {
     double *lkk[2] = {nullptr, nullptr};
     hipEvent_t ev_main_L = nullptr, ev_comm_L[2] = {nullptr, nullptr}, ev_main_X[2] = {nullptr, nullptr},
                ev_comm_X[2] = {nullptr, nullptr};
+    hipEvent_t ev_main_U[2] = {nullptr, nullptr};    // main stream: the received L_kk in lkk[k & 1] has been unpacked (the buffer may be
+    bool unpacked[2] = {false, false};               // overwritten by the broadcast of L_(k+2)); unpacked[b]: recorded this evaluation
 };
 
 static void shard_state_free(ShardState *S)
@@ -2495,6 +2605,7 @@ static void shard_state_free(ShardState *S)
         if (S->ev_comm_L[b]) hipEventDestroy(S->ev_comm_L[b]);
         if (S->ev_main_X[b]) hipEventDestroy(S->ev_main_X[b]);
         if (S->ev_comm_X[b]) hipEventDestroy(S->ev_comm_X[b]);
+        if (S->ev_main_U[b]) hipEventDestroy(S->ev_main_U[b]);
     }
     delete S;
 }
@@ -2533,6 +2644,8 @@ static int shard_prepare(cocons_fit *f, int rank, int world)
         if (!S->ev_comm_L[b]) HIPCHK(hipEventCreateWithFlags(&S->ev_comm_L[b], hipEventDisableTiming));
         if (!S->ev_main_X[b]) HIPCHK(hipEventCreateWithFlags(&S->ev_main_X[b], hipEventDisableTiming));
         if (!S->ev_comm_X[b]) HIPCHK(hipEventCreateWithFlags(&S->ev_comm_X[b], hipEventDisableTiming));
+        if (!S->ev_main_U[b]) HIPCHK(hipEventCreateWithFlags(&S->ev_main_U[b], hipEventDisableTiming));
+        S->unpacked[b] = false;
     }
     if (!S->ev_main_L) HIPCHK(hipEventCreateWithFlags(&S->ev_main_L, hipEventDisableTiming));
     return 0;
@@ -2607,9 +2720,24 @@ static int shard_factor_diag(cocons_fit *f, int k)
 }
 
 // ---- collectives: RCCL on the communication stream, or the caller's transport ----
+// COCONS_SHARD_COMM2 (default 1): the broadcasts of the factored diagonal blocks get a stream -- and, under RCCL, a
+// communicator -- of their own, so that the chain from one diagonal block to the next never queues behind the bulk exchange
+static bool shard_comm2()
+{
+    static const int v = [] { const char *e = getenv("COCONS_SHARD_COMM2"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
 static int coll_prepare(cocons_fit *f)
 {
     if (!f->cstream) HIPCHK(hipStreamCreateWithFlags(&f->cstream, hipStreamNonBlocking));
+    if (!f->cstream_l) {
+        // RCCL serialises the operations of ONE communicator whatever streams they are given: a second stream only helps
+        // with a second communicator (split off by the caller of this function); a caller-provided transport has no such rule
+        const bool own = shard_comm2() && (f->coll_kind == 2 || (f->coll_kind == 1 && f->comm_l && f->comm_l != f->comm));
+        if (own) HIPCHK(hipStreamCreateWithFlags(&f->cstream_l, hipStreamNonBlocking));
+        else f->cstream_l = f->cstream;
+    }
     if (!f->dcoll) HIPCHK(hipMalloc(&f->dcoll, (size_t)(2 + (COCONS_P_MAX + f->r) * (COCONS_P_MAX + f->r)) * sizeof(double)));
     return 0;
 }
@@ -2642,6 +2770,14 @@ extern "C" int cocons_fit_comm_init(cocons_fit *f, int nranks, int rank, const v
     NCCLCHK(R->CommInitRank(&f->comm, nranks, id, rank));
     f->comm_own = true;
     f->coll_kind = 1; f->coll_rank = rank; f->coll_world = nranks;
+    // a second communicator over the same ranks for the small broadcasts on the chain (collective call: every rank is here).
+    // Not available / refused: the broadcasts share the one communicator and its stream.
+    f->comm_l = nullptr; f->comm_l_own = false;
+    if (shard_comm2() && R->CommSplit) {
+        ncclComm_t c2 = nullptr;
+        if (R->CommSplit(f->comm, 0, rank, &c2, nullptr) == ncclSuccess && c2) { f->comm_l = c2; f->comm_l_own = true; }
+        else (void)hipGetLastError();
+    }
     return coll_prepare(f);
 }
 
@@ -2671,17 +2807,19 @@ static int coll_bcast_L(cocons_fit *f, int k, bool in_group)
 {
     ShardState *S = f->shard;
     const int b = k & 1, owner = shard_owner(k, f->coll_world);
-    // (a receiver needs no event: the buffer's last reader on the main stream, the unpack of L_(k-2), precedes the pack that the
-    // all-gather of step k-1 -- the operation in front of this one on the communication stream -- has waited for)
-    if (f->coll_rank == owner) HIPCHK(hipStreamWaitEvent(f->cstream, S->ev_main_L, 0));
+    hipStream_t cs = f->cstream_l;
+    // the owner's copy is packed on its main stream; a receiver's buffer was last read by the unpack of L_(k-2) on ITS main
+    // stream (the broadcasts have a stream of their own since round 5: nothing else orders the two)
+    if (f->coll_rank == owner) HIPCHK(hipStreamWaitEvent(cs, S->ev_main_L, 0));
+    else if (S->unpacked[b]) HIPCHK(hipStreamWaitEvent(cs, S->ev_main_U[b], 0));
     if (f->coll_kind == 1) {
         RcclApi *R = rccl_api();
-        NCCLCHK(R->Broadcast(S->lkk[b], S->lkk[b], LKK_DOUBLES, ncclDouble, owner, f->comm, f->cstream));
-        if (!in_group) HIPCHK(hipEventRecord(S->ev_comm_L[b], f->cstream));
+        NCCLCHK(R->Broadcast(S->lkk[b], S->lkk[b], LKK_DOUBLES, ncclDouble, owner, f->comm_l ? f->comm_l : f->comm, cs));
+        if (!in_group) HIPCHK(hipEventRecord(S->ev_comm_L[b], cs));
     } else {
-        if (f->cb_bcast(f->cb_user, S->lkk[b], (long long)(LKK_DOUBLES * sizeof(double)), owner, (void *)f->cstream) != 0)
+        if (f->cb_bcast(f->cb_user, S->lkk[b], (long long)(LKK_DOUBLES * sizeof(double)), owner, (void *)cs) != 0)
             return fail(-6, "caller-provided broadcast failed");
-        HIPCHK(hipEventRecord(S->ev_comm_L[b], f->cstream));
+        HIPCHK(hipEventRecord(S->ev_comm_L[b], cs));
     }
     return 0;
 }
@@ -2725,6 +2863,8 @@ static int shard_step_pre(cocons_fit *f, int k, int nb)
                                 (size_t)PT * TILE * sizeof(double), (size_t)w * TILE * sizeof(double), (size_t)w * TILE,
                                 hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(f->dinv, L + (size_t)PT * TILE * PT * TILE, 2 * 2048 * sizeof(double), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipEventRecord(S->ev_main_U[k & 1], s));
+        S->unpacked[k & 1] = true;
     }
     if (tn >= mt) return 0;                                            // nothing below the block
     if (P.cnt[(size_t)k * W + rank] > 0) {
@@ -2798,8 +2938,9 @@ static int sharded_eval(cocons_fit *f, const double *theta, const double *mean, 
     if (rc < 0 && f->coll_kind == 1 && f->comm && f->coll_world > 1) {
         const std::string keep = g_err;
         RcclApi *R = rccl_api();
+        if (R && f->comm_l && f->comm_l != f->comm) (void)R->CommAbort(f->comm_l);
         if (R) (void)R->CommAbort(f->comm);
-        f->comm = nullptr;
+        f->comm = nullptr; f->comm_l = nullptr;
         f->coll_kind = -1;                      // poisoned: see cocons_neg2loglik_dense
         g_err = keep + " (communicator aborted)";
     }
@@ -2838,9 +2979,13 @@ static int sharded_eval_impl(cocons_fit *f, const double *theta, const double *m
     if (int rc = coll_bcast_L(f, 0, false)) return rc;
     for (int k = 0; k < nb; ++k) {
         if (int rc = shard_step_pre(f, k, nb)) return rc;
+        // (the broadcast of the NEXT diagonal block is issued in FRONT of this block's bulk exchange, in the same order on every
+        // rank: it depends on nothing but the owner's own rows -- collectives issued earlier --, so whether the two share a
+        // stream, a hardware queue or neither, the chain diagonal block -> diagonal block never waits for an all-gather.
+        // Until round 4 it was issued behind the all-gather on the one communication stream, and waited for it.)
         const bool exchange = k * PT + f->shard->plan.ncols[k] / TILE < f->nt;
-        if (exchange) if (int rc = coll_allgather_X(f, k, false)) return rc;
         if (k + 1 < nb) if (int rc = coll_bcast_L(f, k + 1, false)) return rc;
+        if (exchange) if (int rc = coll_allgather_X(f, k, false)) return rc;
         if (int rc = shard_step_post(f, k, nb)) return rc;
     }
     const int nr = f->r, len = 1 + nr * nr;
@@ -2848,6 +2993,7 @@ static int sharded_eval_impl(cocons_fit *f, const double *theta, const double *m
     int info = 0;
     if (int rc = shard_finish(f, part.data(), &info)) return rc;
     HIPCHK(hipStreamSynchronize(f->cstream));
+    if (f->cstream_l != f->cstream) HIPCHK(hipStreamSynchronize(f->cstream_l));
     double minfo = (double)info;                       // 0x7f7f7f7f = no failing minor (exact in a double)
     if (world > 1) {
         if (f->coll_kind == 1) {
@@ -2911,9 +3057,23 @@ extern "C" cocons_multi *cocons_multi_create(int n, int p, int r, const double *
         cocons_multi_destroy(m);
         return nullptr;
     }
+    // second communicators for the chain's broadcasts (one collective call per local rank, inside a group)
+    std::vector<ncclComm_t> c2(ndev, nullptr);
+    bool split_ok = shard_comm2() && R->CommSplit != nullptr;
+    if (split_ok) {
+        split_ok = R->GroupStart() == ncclSuccess;
+        for (int d = 0; d < ndev && split_ok; ++d) {
+            hipSetDevice(devices[d]);
+            if (R->CommSplit(m->comms[d], 0, d, &c2[d], nullptr) != ncclSuccess) split_ok = false;
+        }
+        if (R->GroupEnd() != ncclSuccess) split_ok = false;
+        for (int d = 0; d < ndev; ++d) if (!c2[d]) split_ok = false;
+        if (!split_ok) { for (auto c : c2) if (c) rccl_comm_destroy(c); (void)hipGetLastError(); }
+    }
     for (int d = 0; d < ndev; ++d) {
         cocons_fit *f = m->fits[d];
         f->comm = m->comms[d]; f->comm_own = false;
+        f->comm_l = split_ok ? c2[d] : nullptr; f->comm_l_own = split_ok;      // (destroyed with the fit)
         f->coll_kind = 1; f->coll_rank = d; f->coll_world = ndev;
         if (fit_check(f) != 0 || coll_prepare(f) != 0) { cocons_multi_destroy(m); return nullptr; }
     }
@@ -2937,15 +3097,23 @@ extern "C" int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *thet
     const int nb = cocons_shard_num_blocks(m->fits[0]);
     auto grouped = [&](int k, bool gather) -> int {
         NCCLCHK(R->GroupStart());
-        for (int d = 0; d < W; ++d) {
-            if (int rc = fit_check(m->fits[d])) return rc;
-            if (int rc = gather ? coll_allgather_X(m->fits[d], k, true) : coll_bcast_L(m->fits[d], k, true)) return rc;
+        int rc_in = 0;
+        std::string err_in;
+        for (int d = 0; d < W && rc_in == 0; ++d) {
+            rc_in = fit_check(m->fits[d]);
+            if (rc_in == 0) rc_in = gather ? coll_allgather_X(m->fits[d], k, true) : coll_bcast_L(m->fits[d], k, true);
+            if (rc_in != 0) err_in = g_err;
         }
-        NCCLCHK(R->GroupEnd());
+        // the group is closed on EVERY path: an error between ncclGroupStart and ncclGroupEnd used to leave it open, and every
+        // later RCCL call of the thread inside it
+        const ncclResult_t ge = R->GroupEnd();
+        if (rc_in != 0) { g_err = err_in; return rc_in; }
+        NCCLCHK(ge);
         for (int d = 0; d < W; ++d) {
             if (int rc = fit_check(m->fits[d])) return rc;
             ShardState *S = m->fits[d]->shard;
-            HIPCHK(hipEventRecord(gather ? S->ev_comm_X[k & 1] : S->ev_comm_L[k & 1], m->fits[d]->cstream));
+            HIPCHK(hipEventRecord(gather ? S->ev_comm_X[k & 1] : S->ev_comm_L[k & 1],
+                                  gather ? m->fits[d]->cstream : m->fits[d]->cstream_l));
         }
         return 0;
     };
@@ -2961,8 +3129,8 @@ extern "C" int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *thet
             if (int rc = shard_step_pre(m->fits[d], k, nb)) return rc;
         }
         const bool exchange = k * PT + m->fits[0]->shard->plan.ncols[k] / TILE < m->fits[0]->nt;
+        if (k + 1 < nb) if (int rc = grouped(k + 1, false)) return rc;     // (in front of the bulk exchange: see sharded_eval_impl)
         if (exchange) if (int rc = grouped(k, true)) return rc;
-        if (k + 1 < nb) if (int rc = grouped(k + 1, false)) return rc;
         for (int d = 0; d < W; ++d) {
             if (int rc = fit_check(m->fits[d])) return rc;
             if (int rc = shard_step_post(m->fits[d], k, nb)) return rc;
@@ -2977,6 +3145,7 @@ extern "C" int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *thet
         if (int rc = fit_check(m->fits[d])) return rc;
         if (int rc = shard_finish(m->fits[d], part.data(), &info)) return rc;
         HIPCHK(hipStreamSynchronize(m->fits[d]->cstream));
+        if (m->fits[d]->cstream_l != m->fits[d]->cstream) HIPCHK(hipStreamSynchronize(m->fits[d]->cstream_l));
         for (int i = 0; i < len; ++i) tot[i] += part[i];
         if (info < info_min) info_min = info;
     }
@@ -3090,6 +3259,149 @@ extern "C" int cocons_fit_comm_info(cocons_fit *f, int *count, int *user_rank, i
     if (user_rank) *user_rank = u;
     if (device) *device = dv;
     return 0;
+}
+
+// ---------------------------------------------------------------------------
+// diagnostic: the persistent launch of the dependency-driven schedule (dag_kernel) REPLAYED ALONE -- the same task list, the
+// same products, the same C traffic, but nobody to wait for: what the engine would publish while the launch runs (the
+// inverses W of the diagonal tiles, the strips X(t+1,t), the raised out[] / xr[] words) is put there beforehand, taken from
+// a factorisation of the same matrix on the plain schedule.  This is what makes the launch countable: rocprofv3 --pmc
+// serialises kernels, and the real launch waits for the engine on the other stream.
+// Sequence: (1) evaluation on the plain schedule -> the complete factor L in the handle's buffer; (2) W(t) = L(t,t)^-1
+// (host, 128 x 128 triangular) and L(t+1,t) for every diagonal block of the head into the W buffer / the second buffer P, and
+// a copy of L for the check; (3) per repetition: Sigma assembled again, first panel by the classic kernels, task words zeroed,
+// in[] / out[] / xr[] raised, dag_kernel launched between two events.  The launch leaves the diagonal blocks updated but
+// unfactored (no engine), so no value comes out of a replay; the check is the panels it formed against the plain factor.
+// out[0] = mean duration of the launch in ms, out[1] = its update flops (as bench.py counts them), out[2] = max |P - L| over
+// the panels the launch formed relative to max |L| there, out[3] = tasks, out[4] = steps.
+__global__ void __launch_bounds__(256)
+panel_diff_kernel(const double *P, const double *L, size_t lda, int c0, int c1, int rend, unsigned long long *out)
+{
+    const int c = c0 + (int)blockIdx.x;
+    if (c >= c1) return;
+    const int r0 = 2 * TILE * (c / (2 * TILE) + 1);          // first row below column c's diagonal block
+    double md = 0.0, ml = 0.0;
+    for (int r = r0 + (int)threadIdx.x; r < rend; r += (int)blockDim.x) {
+        const double l = L[(size_t)r + (size_t)c * lda], d = fabs(P[(size_t)r + (size_t)c * lda] - l);
+        md = d > md || d != d ? d : md;
+        ml = fabs(l) > ml ? fabs(l) : ml;
+    }
+    // (non-negative doubles order like their bit patterns; a NaN difference has the largest pattern of all)
+    atomicMax(out, (unsigned long long)__double_as_longlong(md));
+    atomicMax(out + 1, (unsigned long long)__double_as_longlong(ml));
+}
+
+extern "C" int cocons_debug_dag_replay(cocons_fit *f, const double *theta, const double *mean, int reps, double *out)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (int rc = no_taper(f, "cocons_debug_dag_replay")) return rc;
+    if (!theta || !mean || !out || reps < 1) return fail(-1, "cocons_debug_dag_replay: bad argument");
+    if (f->r < 1 || f->coll_kind) return fail(-1, "cocons_debug_dag_replay: needs a plain dense fit with z");
+    // (1) the factor, on the plain schedule
+    const int engine_saved = tun().engine;
+    tun().engine = 0;
+    int st = enqueue_eval(f, theta, mean, true, nullptr, 0, nullptr, false);
+    if (st == 0) { HIPCHK(hipStreamSynchronize(f->stream)); st = info_status(f); }
+    tun().engine = engine_saved;
+    if (st) return st;
+    const int nrhs = f->r;
+    const bool slots = f->nslot >= nrhs && f->nslot > 0;
+    FactorView fv = main_view(f);
+    if (slots) fv.mt = fv.nt; else fv.trim = (f->rhs_act - nrhs >= 64) ? 1 : 0;
+    fv.dag_ok = true;
+    if (!(tun().dag != 0 && !fv.hi && !fv.skew && fv.nt > 4)) return fail(-1, "cocons_debug_dag_replay: the DAG schedule does not apply to this fit");
+    if (int rc = flags_reset(f, fv.nt)) return rc;
+    if (int rc = dag_prepare(f, fv)) return rc;
+    if (f->dag_nsteps < 2) return fail(-1, "cocons_debug_dag_replay: problem too small for a DAG head");
+    hipStream_t M = f->stream;
+    const size_t lda = fv.lda;
+    const int nt_head = 2 * f->dag_nsteps + 2;                 // diagonal tiles 2 .. nt_head - 1 belong to the head's blocks
+    // (2) what the engine would publish
+    double *Lcopy = nullptr;
+    HIPCHK(hipMalloc(&Lcopy, lda * (size_t)f->npad * sizeof(double)));
+    int rc = 0;
+    std::vector<double> tile((size_t)TILE * TILE), W((size_t)TILE * TILE);
+    unsigned long long *dcmp = nullptr;
+    do {
+#define CKR(expr) { hipError_t e__ = (expr); if (e__ != hipSuccess) { rc = fail(-100 - (int)e__, "cocons_debug_dag_replay: %s", hipGetErrorString(e__)); break; } }
+        CKR(hipMemcpyAsync(Lcopy, f->dA, lda * (size_t)f->npad * sizeof(double), hipMemcpyDeviceToDevice, M));
+        bool bad = false;
+        for (int t = 2; t < nt_head && t < fv.nt && !bad; ++t) {
+            const double *src = f->dA + (size_t)t * TILE + (size_t)t * TILE * lda;
+            if (hipMemcpy2DAsync(tile.data(), TILE * sizeof(double), src, lda * sizeof(double), TILE * sizeof(double), TILE,
+                                 hipMemcpyDeviceToHost, M) != hipSuccess || hipStreamSynchronize(M) != hipSuccess) { bad = true; break; }
+            std::fill(W.begin(), W.end(), 0.0);
+            for (int j = 0; j < TILE; ++j)                     // column j of W = L^-1: forward substitution on e_j
+                for (int i = j; i < TILE; ++i) {
+                    double sacc = i == j ? 1.0 : 0.0;
+                    for (int k = j; k < i; ++k) sacc -= tile[(size_t)i + (size_t)k * TILE] * W[(size_t)k + (size_t)j * TILE];
+                    W[(size_t)i + (size_t)j * TILE] = sacc / tile[(size_t)i + (size_t)i * TILE];
+                }
+            if (hipMemcpyAsync(f->dWt + (size_t)t * TILE * TILE, W.data(), W.size() * sizeof(double), hipMemcpyHostToDevice, M) != hipSuccess ||
+                hipStreamSynchronize(M) != hipSuccess) { bad = true; break; }
+            if ((t & 1) == 0 && t + 1 < fv.nt) {               // X(t+1,t) = L(t+1,t): the engine's second copy, in P
+                const size_t off = (size_t)(t + 1) * TILE + (size_t)t * TILE * lda;
+                if (hipMemcpy2DAsync(f->dP + off, lda * sizeof(double), f->dA + off, lda * sizeof(double), TILE * sizeof(double), TILE,
+                                     hipMemcpyDeviceToDevice, M) != hipSuccess) { bad = true; break; }
+            }
+        }
+        if (bad) { rc = fail(-100, "cocons_debug_dag_replay: copying the diagonal tiles failed"); break; }
+        CKR(hipMalloc(&dcmp, 2 * sizeof(unsigned long long)));
+        // (3) the launch, alone
+        const size_t T64 = 2 * (size_t)fv.mt;
+        unsigned *in = f->dflags, *outw = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
+        unsigned *abort_word = (unsigned *)(f->dinfo + 1);
+        unsigned *queue = f->ddag, *tdone = f->ddag + 64, *pdone = tdone + T64 * (T64 + 1) / 2;
+        unsigned *pall = pdone + ((size_t)f->dag_nsteps + 2) * T64;
+        unsigned *dcount = pall + (size_t)f->dag_nsteps + 64;
+        f->upd_flops = 0.0;
+        f->nrhs_cur = nrhs;
+        for (int s2 = 0; s2 < f->dag_nsteps; ++s2) count_update_flops(f, 2, 2 * s2 + 2);
+        const double flops = f->upd_flops;
+        hipEvent_t ea = nullptr, eb = nullptr;
+        CKR(hipEventCreate(&ea));
+        CKR(hipEventCreate(&eb));
+        double ms_sum = 0.0;
+        for (int it = 0; it < reps && rc == 0; ++it) {
+            if ((rc = reset_info(f))) break;
+            assemble_sigma(f, theta, 0, 0, f->npad);
+            assemble_rhs(f, mean, true, nullptr, 0, 0, f->npad, true, slots);
+            launch_front_identity(fv.A, fv.lda, f->pad0, fv.mt * TILE, M);
+            panel_ops(f, fv, 0, M);
+            CKR(hipMemsetAsync(f->ddag, 0, f->ddag_words * sizeof(unsigned), M));
+            CKR(hipMemsetD32Async((hipDeviceptr_t)f->dflags, 0x3fffffff, 3 * (size_t)f->flags_cap, M));   // in / out / xr: all raised
+            CKR(hipEventRecord(ea, M));
+            launch_dag(fv.A, fv.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
+                       pdone, (int)T64, pall, f->dpart, dcount, in, outw, xr, abort_word, M, nullptr, nullptr, 0, nullptr);
+            CKR(hipEventRecord(eb, M));
+            CKR(hipGetLastError());
+            CKR(hipStreamSynchronize(M));
+            float ms = 0;
+            CKR(hipEventElapsedTime(&ms, ea, eb));
+            ms_sum += ms;
+        }
+        if (ea) hipEventDestroy(ea);
+        if (eb) hipEventDestroy(eb);
+        if (rc) break;
+        CKR(hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, M));
+        CKR(hipStreamSynchronize(M));
+        if (f->hinfo[1] != 0) { rc = fail(ENGINE_ABORT, "cocons_debug_dag_replay: a wait of the replayed launch ran out"); break; }
+        // the check: every panel the launch formed (blocks 1 .. nsteps - 1) against the plain factor
+        CKR(hipMemsetAsync(dcmp, 0, 2 * sizeof(unsigned long long), M));
+        const int c0 = 2 * TILE, c1 = 2 * TILE * f->dag_nsteps, rend = fv.mt * TILE - 64 * fv.trim;
+        hipLaunchKernelGGL(panel_diff_kernel, dim3(c1 - c0), dim3(256), 0, M, (const double *)f->dP, (const double *)Lcopy, lda, c0, c1, rend, dcmp);
+        unsigned long long h[2] = {0, 0};
+        CKR(hipMemcpyAsync(h, dcmp, sizeof h, hipMemcpyDeviceToHost, M));
+        CKR(hipStreamSynchronize(M));
+        double md, ml;
+        memcpy(&md, &h[0], 8); memcpy(&ml, &h[1], 8);
+        out[0] = ms_sum / reps; out[1] = flops; out[2] = ml > 0 ? md / ml : NAN; out[3] = (double)f->dag_ntasks; out[4] = (double)f->dag_nsteps;
+#undef CKR
+    } while (0);
+    hipFree(Lcopy); hipFree(dcmp);
+    f->border_clean = -1; f->border_pending = -1;        // (the buffer holds a half-done factorisation)
+    f->dag_used = false;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------

@@ -64,6 +64,12 @@ __device__ __forceinline__ double fast_rcp(double x)
 // sqrt(x) for x >= 0 of ordinary magnitude (squared distances over squared ranges, ratios of determinants): v_rsq_f64 (24
 // bits) + one third-order step + one Heron correction, ~1 ulp in ten instructions; zero stays zero.  The library square root
 // spends as many again on scaling for operands near the ends of the exponent range, which do not occur here.
+// A NEGATIVE or NaN argument comes out as NaN, like sqrt's (v_rsq_f64 gives NaN for both): a quadratic form that degenerate
+// parameters turned into NaN -- overflowing link functions, inf - inf in the averaged kernel matrix -- must poison the entry
+// as it does in the reference (src/cocons_full.cpp:286-305: NaN fails both branch tests and reaches Sigma; the Cholesky then
+// fails and GetNeg2loglikelihood's tryCatch contract fires, R/neg2loglikelihood.R:200-206).  Until round 4 this returned 0
+// for anything not > 0, which sent such a pair down the `u <= epsilon` branch with the DIAGONAL value.  (+inf gives NaN
+// here where sqrt gives +inf: either way the entry is not a number the reference would have produced a finite value from.)
 __device__ __forceinline__ double sqrt_pos(double x)
 {
     const double y0 = __builtin_amdgcn_rsq(x);
@@ -72,7 +78,7 @@ __device__ __forceinline__ double sqrt_pos(double x)
     const double y = fma(y0 * t, fma(t, 0.375, 0.5), y0);
     double s_ = x * y;
     s_ = fma(fma(-s_, s_, x), 0.5 * y, s_);
-    return x > 0.0 ? s_ : 0.0;
+    return x == 0.0 ? 0.0 : s_;
 }
 
 // One Horner step p t + C with the coefficient in a SCALAR register pair.  Written out because the compiler's own choice for
@@ -443,6 +449,7 @@ __device__ __forceinline__ double pair_value_idx(const double *base_a, size_t sa
     double u = sqrt_pos((8 * smtns) * (rgr * rdet) *
                         fma(kahan(s22, dx * dx, -s11, dy * dy), 1.0, -2 * s12 * dx * dy));
     if (u <= epsilon) return FA(11);
+    if (u != u) return u;       // NaN geometry (degenerate parameters): the entry is NaN, as in the reference (sqrt_pos)
     double m;
     if (MODE == MODE_HALF) m = exp(-u);
     else if (MODE == MODE_THREEHALF) m = (1 + u) * exp(-u);

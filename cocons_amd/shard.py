@@ -10,7 +10,8 @@ solves and updates ITS rows of every column:
         broadcast L_kk from owner(k)                                           <- 0.5 MB, on the chain
         every rank: solve ITS rows of the panel, X = B L_kk^-T
         owner(k+1): update its diagonal block (k+1,k+1) with its own rows of X, factor it, start its broadcast
-                    (the chain diagonal block -> diagonal block never waits for the bulk exchange)
+                    (issued in front of the all-gather below, on a stream and communicator of its own: the chain
+                    diagonal block -> diagonal block never waits for the bulk exchange)
         all-gather of the solved rows, packed by owner                         <- B_k / world per rank
         every rank: update ITS rows of the trailing matrix with the gathered panel   (MFMA fp64)
     all-reduce of {sum log diag, Gram of the rhs rows} (1 + r^2 doubles) and of the failing minor
@@ -230,8 +231,9 @@ def sharded_neg2loglik_core(engine, theta_list, dist, rank, world, group=None, l
     Returns (sum_logliks, parts), identical on every rank; raises CholeskyError on every rank if any pivot failed.
 
     Look-ahead (the library's order): the owner of block k+1 updates its diagonal block with its OWN solved rows and
-    factors it before the bulk exchange of step k, and the broadcast of L_(k+1,k+1) is issued right behind the all-gather
-    of step k -- the chain of diagonal blocks never waits for a trailing update.  lookahead=False: every step in plain
+    factors it before the bulk exchange of step k, and the broadcast of L_(k+1,k+1) is issued IN FRONT of the all-gather
+    of step k (round 5; the library gives it a stream and a communicator of its own) -- the chain of diagonal blocks waits
+    neither for a trailing update nor for a bulk exchange.  lookahead=False: every step in plain
     order (factor | broadcast | solve | all-gather | update), the same arithmetic."""
     engine.begin(theta_list, rank, world)
     nb = engine.num_blocks()
@@ -266,10 +268,10 @@ def sharded_neg2loglik_core(engine, theta_list, dist, rank, world, group=None, l
         if ahead and rank == owner_of(k + 1):
             engine.ahead(k + 1)                           # own rows of X: local
             engine.factor_diag(k + 1)
-        if engine.exchanges(k):
-            gather(k)
         if lookahead and k + 1 < nb:
             bcast_diag(k + 1)
+        if engine.exchanges(k):
+            gather(k)
         if engine.exchanges(k):
             engine.update(k, skip_diag=(k + 1 if (ahead and rank == owner_of(k + 1)) else None))
     part, info = engine.finish()

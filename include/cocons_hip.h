@@ -214,12 +214,15 @@ int cocons_fit_profile(cocons_fit *fit, const double *theta, const double *mean,
 int cocons_fit_engine_state(cocons_fit *fit, int *out3);
 
 /* ---- natively sharded evaluation across the GPUs of one node ----------------------
- * Sigma row blocks (= column panels of the lower factor kept here, 256 columns each) are dealt
- * block-cyclically over the ranks; per panel the owner factors it and the library broadcasts it with
- * RCCL over xGMI on a stream of its own (two panels in flight), every rank updates its own panels, and
- * the 1 + r^2 partial sums (+ the failing minor) are all-reduced at the end.  No data-path call leaves
- * the library: once a fit has collectives, cocons_neg2loglik_dense on it IS the sharded evaluation and
- * returns the same value on every rank.
+ * Sigma is ROW-BLOCK partitioned (block b = rows 256 b .. 256 b + 255; blocks dealt in groups, see
+ * cocons_shard_block_owner below): a rank assembles, solves and updates ITS rows of every column.  Per 256-column
+ * block the owner of the diagonal block factors it and the library broadcasts it (0.56 MB, RCCL over xGMI, on a
+ * stream -- and communicator -- of its own, issued in front of the bulk exchange), every rank solves its rows of
+ * the panel, the owner of the NEXT diagonal block updates and factors it from its own rows at once, the solved rows
+ * are all-gathered packed by owner (second communication stream), every rank updates its rows of the trailing
+ * matrix; the 1 + r^2 partial sums (+ the failing minor) are all-reduced at the end.  No
+ * data-path call leaves the library: once a fit has collectives, cocons_neg2loglik_dense on it IS the sharded
+ * evaluation and returns the same value on every rank.
  *
  * (a) one process per GPU (torch.distributed.run, MPI, optimParallel workers ...): rank 0 calls
  *     cocons_comm_unique_id, the 128 bytes reach the other ranks by whatever channel the host has, and
@@ -233,7 +236,8 @@ int cocons_fit_engine_state(cocons_fit *fit, int *out3);
 int cocons_comm_unique_id(void *id_out /* COCONS_UNIQUE_ID_BYTES */);
 int cocons_fit_comm_init(cocons_fit *fit, int nranks, int rank, const void *id /* COCONS_UNIQUE_ID_BYTES */);
 /* broadcast `bytes` at device pointer dev_ptr from rank `root` to every rank; `stream` (hipStream_t) is the
- * library's communication stream: the function may enqueue on it or block.  Return 0 on success.        */
+ * library's communication stream for these broadcasts (ordered behind whatever produced / last read the buffer):
+ * the function may enqueue on it or block.  Return 0 on success.        */
 typedef int (*cocons_bcast_fn)(void *user, void *dev_ptr, long long bytes, int root, void *stream);
 /* in-place all-reduce of `count` HOST doubles, op 0 = sum, 1 = min; blocking.                            */
 typedef int (*cocons_allreduce_fn)(void *user, double *host_inout, int count, int op);

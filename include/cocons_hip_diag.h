@@ -34,6 +34,15 @@ struct cocons_fit;
 long long cocons_debug_dag_trace(struct cocons_fit *fit, int *nsteps_out, int *steps_out, unsigned long long *stamps_out,
                                  unsigned long long *engine_out);   /* engine_out (may be null): 8 stamps per pair of tiles, room for 8 (nt + 2) */
 
+
+/* The persistent launch of the dependency-driven schedule replayed ALONE (counter passes: rocprofv3 --pmc serialises kernels,
+ * and the real launch waits for the diagonal-block engine on another stream): what the engine would publish is prepared from
+ * a plain-schedule factorisation of the same matrix, all hand-off words are raised, and dag_kernel runs the same task list --
+ * same products, same C traffic -- between two HIP events, `reps` times.  out[0] = mean duration in ms, out[1] = the update
+ * flops of the launch, out[2] = max |panel formed - plain factor| relative to max |factor| (the check), out[3] = tasks,
+ * out[4] = steps.  tools/dag_replay.py.  */
+int cocons_debug_dag_replay(struct cocons_fit *fit, const double *theta, const double *mean, int reps, double *out5);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,6 +171,33 @@ def test_chol_not_positive_definite():
     assert rc == 151
 
 
+@pytest.mark.parametrize("aspect,value", [("scale", 300.0), ("aniso", 400.0)])
+def test_degenerate_parameters_poison_sigma_like_the_reference(oracle, aspect, value):
+    """Overflowing link functions (exp(2 scale' x) = inf at some locations, 0 at others) make inf - inf in the averaged kernel
+    matrix: the reference's sqrt / Bessel chain then returns NaN for those pairs (src/cocons_full.cpp:286-305; NaN fails both
+    branch tests), the Cholesky fails and the objective's tryCatch contract fires (R/neg2loglikelihood.R:200-206).  The HIP path
+    must produce NaN for exactly the pairs the CPU restatement does -- until round 4 its square root returned 0 for NaN, which
+    sent such pairs down the `u <= epsilon` branch with the diagonal value -- and agree where the entry is finite."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, X, th, rng = _problem(150, seed=0)
+    th = {k: np.array(v, dtype=float) for k, v in th.items()}
+    th[aspect][1] = value
+    S = ca.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    So = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
+    assert np.isnan(So).mean() > 0.2                       # (the case is what it claims to be)
+    assert np.array_equal(np.isnan(S), np.isnan(So))
+    fin = np.isfinite(So) & (np.abs(So) > 1e-280)
+    assert np.max(np.abs(S[fin] - So[fin]) / np.abs(So[fin])) < ENTRY_RTOL
+    pp = wl.par_pos_full()
+    tv = wl.theta_vector_from_lists(th, pp)
+    z = rng.standard_normal(150)
+    assert oracle.GetNeg2loglikelihood(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, 150, (0, 0, 0)) == 1e6
+    assert ca.GetNeg2loglikelihood(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, 150, (0, 0, 0)) == 1e6
+    with pytest.raises(RuntimeError, match="Cholesky error"):
+        ca.GetNeg2loglikelihood(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, 150, (0, 0, 0), safe=False)
+
+
 @pytest.mark.parametrize("n", [300, 700])
 def test_neg2loglik_vs_cpu(oracle, n):
     import cocons_amd as ca
