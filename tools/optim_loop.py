@@ -12,6 +12,9 @@ import sys
 import time
 
 import numpy as np
+from scipy.optimize import minimize     # (imported HERE: inside lbfgsb_central the first call paid scipy.optimize's import --
+#                                         a quarter of a second -- inside every timing of the loop: rounds 1-4's "C4 sequential
+#                                         154-180 evals/s" against 433 for the same evaluations outside the loop was that import)
 
 NDEPS = np.finfo(float).eps ** 0.25
 
@@ -19,7 +22,6 @@ NDEPS = np.finfo(float).eps ** 0.25
 def lbfgsb_central(fn, x0, lower, upper, max_evals=50, log=None, fn_batch=None):
     """fn_batch (optional): evaluates a list of points at once (the 2P gradient points, which
     optimParallel hands to its workers in parallel)."""
-    from scipy.optimize import minimize
     count = {"n": 0}
 
     class Stop(Exception):
