@@ -132,6 +132,8 @@ def load():
                 "`make -C cocons_amd/csrc`); there is no CPU fallback" % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in list(SIGNATURES.items()) + list(DIAG_SIGNATURES.items()):
+            if name in DIAG_SIGNATURES and os.environ.get("COCONS_HIP_LIB") and not hasattr(L, name):
+                continue                   # (an older build alternated on the same box: diagnostics it does not have yet)
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

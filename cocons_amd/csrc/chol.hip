@@ -425,6 +425,14 @@ potrf_tile_kernel(double *A, size_t lda, int c0, double *q_out, int *info)
 // of that story).  A waiter that stands still does not poll, so a pause of whatever length never turns into a time-out; a
 // true deadlock still ends after ticks / 100 polls, and WALL_BACKSTOP_TICKS ends anything else.
 #define WALL_BACKSTOP_TICKS 500000000ull    // 5 s
+// The engine's waits for its INPUT words are paced by the HOST: the launch that raises in[t] may not have been enqueued yet
+// when the engine -- resident since before the factorisation began -- asks for it.  A host thread that loses the CPU in the
+// middle of enqueueing an evaluation (round 5: the first evaluation behind a LAPACK call on every core of a box whose
+// process group is CPU-limited; abort 0x112 = the engine waiting for tile 18 at n = 4096, once in two runs of the test suite,
+// never in 6000 evaluations of a loop that does nothing else) must not look like a lost partner: these waits get 3 s of
+// polling.  Every genuine circular wait contains a waiter on the OTHER side -- a main-stream kernel waiting for out[] / xr[],
+// bounded by ENGINE_TIMEOUT_TICKS -- which gives up first and takes everybody with it.
+#define HOST_PACED_TICKS (30ull * ENGINE_TIMEOUT_TICKS)
 
 // (diagnostics) where a wave runs: XCC id in bits 28..31, HW_ID (wave, SIMD, CU, SH, SE ...) below
 __device__ __forceinline__ unsigned hw_where()
@@ -575,7 +583,7 @@ potrf_engine_kernel(EngineArgs e)
     // (the word also says WHERE: 1 + the id of the XCD the workgroup runs on -- dag_kernel keeps that XCD less than full)
     if (tid == 0) __hip_atomic_store(e.alive, 1u + (hw_where() >> 28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int t = e.t0; t < e.nt; t += 2) {
-        if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t) ? 1 : 0;
+        if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t, HOST_PACED_TICKS) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
@@ -598,7 +606,7 @@ potrf_engine_kernel(EngineArgs e)
         if (tr && tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
         if (t + 1 >= e.nt) return;
 
-        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t) ? 1 : 0;
+        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t, HOST_PACED_TICKS) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;

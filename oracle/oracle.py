@@ -229,6 +229,12 @@ def getPen(n, lam, theta_list, smooth_limits) -> float:
 def _chol_upper(S):
     from scipy.linalg import lapack
     R, info = lapack.dpotrf(S, lower=0, clean=1, overwrite_a=0)   # base::chol -> dpotrf('U')
+    # A NaN pivot is a failure too: the reference LAPACK R ships (dpotrf -> dpotrf2 / dpotf2) tests
+    # `AJJ.LE.ZERO .OR. DISNAN(AJJ)` at every pivot, so chol() of a matrix poisoned by NaN raises the error that
+    # R/neg2loglikelihood.R:200-206 maps to 1e6; scipy's OpenBLAS dpotrf has its own kernels, which let NaN through with
+    # info = 0.  (A NaN anywhere in the part of Sigma that is read reaches a later pivot.)
+    if info == 0 and not np.all(np.isfinite(np.diag(R))):
+        info = int(np.argmax(~np.isfinite(np.diag(R)))) + 1
     return (None if info != 0 else R), info
 
 

@@ -1,6 +1,14 @@
 import os
 import sys
 
+# The CPU oracle's LAPACK calls (scipy / OpenBLAS) start one thread per core the machine reports -- 256 on a GPU box whose
+# process group is limited to a fraction of them.  Such a burst exhausts the group's CPU quota and the kernel then throttles
+# every thread of the process, the one that enqueues GPU work included, for tens of milliseconds: bounded hand-off waits on the
+# GPU (cocons_fit_engine_state counts them) have run out that way right behind an oracle call.  Sixteen threads are what a
+# one-GPU box is given; set before numpy loads its BLAS.
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "16")
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
