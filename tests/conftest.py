@@ -6,8 +6,8 @@ import sys
 # every thread of the process, the one that enqueues GPU work included, for tens of milliseconds: bounded hand-off waits on the
 # GPU (cocons_fit_engine_state counts them) have run out that way right behind an oracle call.  Sixteen threads are what a
 # one-GPU box is given; set before numpy loads its BLAS.
-os.environ.setdefault("OPENBLAS_NUM_THREADS", "16")
-os.environ.setdefault("OMP_NUM_THREADS", "16")
+os.environ.setdefault("OPENBLAS_NUM_THREADS", str(min(16, os.cpu_count() or 16)))
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 16)))
 
 import pytest
 
