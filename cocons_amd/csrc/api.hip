@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <time.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -282,10 +283,14 @@ struct cocons_fit {
     double *dpart;                // early halves of the split diagonal-block tiles (2 x 16 x 64 x 64 doubles)
     unsigned *ddag; size_t ddag_words;      // [queue (64 words)] [tdone] [pdone]
     void *ddag_steps; int dag_nsteps; unsigned dag_ntasks;
-    int dag_key[9];               // (nt, mt, trim, kskip, lead, min_tiles, split, lead2, lead3) the step table was built for
+    unsigned dag_nctasks;         // chain layout: tasks of the chain helpers (0: classic layout -- everything in the one list)
+    void *ddag_chain;             // chain layout: device copy of the launch's task words for the helpers (launch_chain_args)
+    int dag_key[10];              // (nt, mt, trim, kskip, lead, min_tiles, split, lead2, lead3, chain) the step table was built for
     unsigned long long *ddag_trace; size_t dag_trace_tasks;   // diagnostics (cocons_debug_tune("dag_trace", 1)): 4 stamps per task
     size_t dag_trace_elems;       // allocated 64-bit words of ddag_trace (5 per task + 8 per tile pair)
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
+    int dag_helpers_live;         // chain helpers in the engine launch of the factorisation being enqueued (0: none)
+    double enq_host_us; long long enq_calls;      // (diagnostics) host time spent enqueueing evaluations, calls: cocons_debug_host_enqueue
     bool dag_used;                // the factorisation enqueued last ran the DAG schedule: its factor is split over dA and dP
     double dag_flops; int dag_events;   // profile runs: update flops inside the DAG launch; 1 = the first event pair is that launch
     // taper fit (cocons_fit_create_taper): the spam pattern (1-based CSR) with the taper's entries; the
@@ -383,6 +388,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->ev_eng) hipEventDestroy(f->ev_eng);
         hipFree(f->dflags);
         hipFree(f->dP); hipFree(f->dWt); hipFree(f->ddag); hipFree(f->ddag_steps); hipFree(f->ddag_trace); hipFree(f->dpart);
+        hipFree(f->ddag_chain);
         hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_thi);
         if (f->cstream_l && f->cstream_l != f->cstream) { hipStreamSynchronize(f->cstream_l); hipStreamDestroy(f->cstream_l); }
         if (f->cstream) { hipStreamSynchronize(f->cstream); hipStreamDestroy(f->cstream); }
@@ -955,6 +961,12 @@ struct Tunables {
     int dag_split = 1;       // COCONS_DAG_SPLIT: the diagonal-block tiles of a DAG step in two halves, the first one off the chain
     int dag_xcc_quota = -1;  // workgroups of the DAG launch that take part on the engine's XCD (of the 255 that land there; 0: all;
                              // -1: derived from the device, dag_xcc_quota() -- 208 on MI355X)
+    int dag_chain = 0;       // COCONS_DAG_CHAIN: 1 = the tasks on the chain between two diagonal blocks are drawn by chain helpers --
+                             // workgroups of the engine's launch, a CU each -- instead of sitting in the persistent launch's list.
+                             // Built and measured in round 5: a chain-bound step takes 116 us instead of
+                             // the classic schedule's 125, and the eleven CUs it holds cost the chip-bound head as much again:
+                             // +0.1 .. +0.4 % at n = 10^4 (alternated in one process) -- not the default.
+    int dag_helpers = 10;    // COCONS_DAG_HELPERS: that many of them (one round of the ten tiles of a diagonal block)
     int dag_trace = 0;       // (diagnostics) time stamps per task, cocons_debug_dag_trace
     int gate_sabotage = 0;   // (tests) the next N engine-schedule factorisations wait at the gate for a word nobody raises:
                              // a genuine 5 ms time-out, abort code 0x600, to exercise the fall-back and its book-keeping
@@ -974,6 +986,10 @@ static Tunables &tun()
         rd("COCONS_DAG_MIN_TILES", t.dag_min_tiles);
         rd("COCONS_DAG_SPLIT", t.dag_split);
         rd("COCONS_DAG_XCC_QUOTA", t.dag_xcc_quota);
+        rd("COCONS_DAG_CHAIN", t.dag_chain);
+        rd("COCONS_DAG_HELPERS", t.dag_helpers);
+        if (t.dag_helpers < 1) t.dag_helpers = 1;
+        if (t.dag_helpers > 24) t.dag_helpers = 24;
         t.init = true;
     }
     return t;
@@ -994,6 +1010,8 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "dag_split") t.dag_split = value;
     else if (k == "dag_xcc_quota") t.dag_xcc_quota = value;
     else if (k == "dag_trace") t.dag_trace = value;
+    else if (k == "dag_chain") t.dag_chain = value;
+    else if (k == "dag_helpers") t.dag_helpers = value < 1 ? 1 : (value > 24 ? 24 : value);
     else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
@@ -1207,11 +1225,13 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         f->dWt_tiles = v.nt;
     }
     const int kskip = (f->pad0 / 16) * 16;
-    const int key[9] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, tun().dag_lead2, tun().dag_lead3};
+    const int chain = tun().dag_chain ? 1 : 0;
+    const int key[10] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, tun().dag_lead2, tun().dag_lead3, chain};
     if (memcmp(key, f->dag_key, sizeof key) != 0 || !f->ddag_steps) {
         std::vector<DagStepHost> steps;
+        unsigned nctasks = 0;
         const unsigned ntasks = dag_build_steps(v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, steps,
-                                                tun().dag_lead2, tun().dag_lead3);
+                                                tun().dag_lead2, tun().dag_lead3, chain, &nctasks);
         HIPCHK(hipStreamSynchronize(f->stream));
         HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->ddag_steps) { HIPCHK(hipFree(f->ddag_steps)); f->ddag_steps = nullptr; }
@@ -1220,7 +1240,8 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         // hardware queue of its own and shifted every later stream's assignment)
         HIPCHK(hipMemcpyAsync(f->ddag_steps, steps.data(), steps.size() * sizeof(DagStepHost), hipMemcpyHostToDevice, f->stream));
         HIPCHK(hipStreamSynchronize(f->stream));
-        f->dag_nsteps = (int)steps.size(); f->dag_ntasks = ntasks;
+        f->dag_nsteps = (int)steps.size(); f->dag_ntasks = ntasks; f->dag_nctasks = nctasks;
+        if (!f->ddag_chain) HIPCHK(hipMalloc(&f->ddag_chain, dag_chain_args_bytes()));
         memcpy(f->dag_key, key, sizeof key);
         const size_t T64 = 2 * (size_t)v.mt;
         const size_t words = 64 + T64 * (T64 + 1) / 2 + (steps.size() + 2) * T64 + steps.size() + 64 + 16 * (steps.size() + 2);
@@ -1233,7 +1254,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
     HIPCHK(hipMemsetAsync(f->ddag, 0, f->ddag_words * sizeof(unsigned), f->stream));
     // trace buffer: 4 stamps + one word of hw_where() pairs per task, 8 stamps per tile pair of the engine -- sized by BOTH
     // the task count and the tile count of THIS step table (a later table with fewer tasks and more tiles must not run past it)
-    const size_t trace_elems = (size_t)f->dag_ntasks * 5 + 8 * (size_t)(v.nt + 2);
+    const size_t trace_elems = (size_t)f->dag_ntasks * 5 + 8 * (size_t)(v.nt + 2) + 4 * (size_t)f->dag_nctasks;     // (+ 4 stamps per chain task)
     if (tun().dag_trace && f->dag_trace_elems < trace_elems) {
         HIPCHK(hipStreamSynchronize(f->stream));
         HIPCHK(hipStreamSynchronize(f->stream2));
@@ -1275,6 +1296,22 @@ extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int 
     return (long long)f->dag_ntasks;
 }
 
+// ... and of the chain helpers' tasks (chain layout): stamps_out = nctasks x 4 ticks (drawn, inputs complete, product done, stored).
+// Returns the number of chain tasks (0: classic layout); null output: the count only.
+extern "C" long long cocons_debug_chain_trace(cocons_fit *f, unsigned long long *stamps_out)
+{
+    if (int rc = fit_check(f)) return rc;
+    if (!f->ddag_steps) return fail(-1, "cocons_debug_chain_trace: no DAG factorisation on this handle yet");
+    if (stamps_out && f->dag_nctasks) {
+        if (!f->ddag_trace || f->dag_trace_tasks != f->dag_ntasks) return fail(-1, "cocons_debug_chain_trace: tracing was off");
+        HIPCHK(hipStreamSynchronize(f->stream));
+        HIPCHK(hipMemcpyAsync(stamps_out, f->ddag_trace + 5 * (size_t)f->dag_ntasks + 8 * (size_t)(f->nt + 2),
+                              4 * (size_t)f->dag_nctasks * sizeof(unsigned long long), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+    }
+    return (long long)f->dag_nctasks;
+}
+
 static int engine_start(cocons_fit *f, const FactorView &v)
 {
     if (f->engine_live) return 0;
@@ -1289,10 +1326,23 @@ static int engine_start(cocons_fit *f, const FactorView &v)
     }
     HIPCHK(hipEventRecord(f->ev_eng, M));                    // (behind the resets of the flag and task words, and of W / P when new)
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
+    unsigned *alive_w = f->dflags + 3 * (size_t)f->flags_cap;
+    const bool helpers = f->dag_next && f->dag_nctasks > 0;
+    if (helpers) {
+        const size_t T64 = 2 * (size_t)v.mt;
+        unsigned *queue = f->ddag, *tdone = f->ddag + 64, *pdone = tdone + T64 * (T64 + 1) / 2;
+        unsigned *pall = pdone + ((size_t)f->dag_nsteps + 2) * T64;
+        unsigned *dcount = pall + (size_t)f->dag_nsteps + 64;
+        launch_chain_args(f->ddag_chain, v.A, v.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_nctasks,
+                          queue, tdone, pdone, (int)T64, pall, f->dpart, dcount, in, out, xr, (unsigned *)(f->dinfo + 1), alive_w,
+                          f->stream2, f->dag_trace_tasks ? f->ddag_trace + 5 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2) : nullptr);
+    }
+    f->dag_helpers_live = helpers ? tun().dag_helpers : 0;
     launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
-                        f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dag_next ? f->dWt : nullptr,
+                        alive_w, f->stream2, f->dag_next ? f->dWt : nullptr,
                         f->dag_next ? f->dP : nullptr, f->dag_next ? 2 * f->dag_nsteps : 0,
-                        (f->dag_next && f->dag_trace_tasks) ? f->ddag_trace + 4 * (size_t)f->dag_ntasks : nullptr);
+                        (f->dag_next && f->dag_trace_tasks) ? f->ddag_trace + 4 * (size_t)f->dag_ntasks : nullptr,
+                        helpers ? f->ddag_chain : nullptr, f->dag_helpers_live);
     f->engine_live = true;
     return 0;
 }
@@ -1364,8 +1414,9 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     unsigned *abort_word = (unsigned *)(f->dinfo + 1);
     unsigned *alive = f->dflags + 3 * (size_t)f->flags_cap;
     if (tun().gate_sabotage > 0) { --tun().gate_sabotage; alive += 1; }      // (tests: a word that stays zero)
-    launch_engine_gate(alive, abort_word, M, false, f->engine_ops++ == 0);
+    launch_engine_gate(alive, abort_word, M, false, f->engine_ops++ == 0, f->dag_next ? f->dag_helpers_live : 0);
     panel_ops(f, v, 0, M);
+    if (f->dag_next && f->dag_helpers_live > 0) launch_raise_word(alive + 3, M);      // the chain helpers may touch the matrix now
     f->dag_used = f->dag_next;
     int k_first = 0;                 // first block step the classic loop below runs in full
     if (f->dag_next) {
@@ -1388,7 +1439,8 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         }
         launch_dag(v.A, v.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
                    pdone, (int)T64, pall, f->dpart, dcount, in, out, xr, abort_word, M, f->dag_trace_tasks ? f->ddag_trace : nullptr,
-                   alive, dag_xcc_quota(), f->dag_trace_tasks ? (unsigned *)(f->ddag_trace + 4 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2)) : nullptr);
+                   alive, dag_xcc_quota(), f->dag_trace_tasks ? (unsigned *)(f->ddag_trace + 4 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2)) : nullptr,
+                   f->dag_helpers_live > 0 ? f->dag_nctasks : 0u);
         if (ev_upd) { hipEventRecord(eb, M); ev_upd->push_back(ea); ev_upd->push_back(eb); f->dag_events = 1; }
         k_first = 2 * f->dag_nsteps;
     }
@@ -1430,8 +1482,32 @@ static int reset_info(cocons_fit *f)
 }
 
 // enqueue one full evaluation with nrhs right-hand-side rows; results land in hout/hinfo
+static int enqueue_eval_impl(cocons_fit *f, const double *theta, const double *mean, bool use_trend,
+                             const double *xb, int nxb, std::vector<hipEvent_t> *ev_upd, bool stage_events);
 static int enqueue_eval(cocons_fit *f, const double *theta, const double *mean, bool use_trend,
                         const double *xb, int nxb, std::vector<hipEvent_t> *ev_upd, bool stage_events)
+{
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    const int rc = enqueue_eval_impl(f, theta, mean, use_trend, xb, nxb, ev_upd, stage_events);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    f->enq_host_us += (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+    f->enq_calls++;
+    return rc;
+}
+
+// (diagnostics) out[0] = mean host microseconds per enqueued evaluation of this handle and its batch slots, out[1] = evaluations
+extern "C" int cocons_debug_host_enqueue(cocons_fit *f, double *out)
+{
+    if (!f || !out) return fail(-1, "cocons_debug_host_enqueue: null argument");
+    double us = f->enq_host_us; long long n = f->enq_calls;
+    if (f->slots) for (cocons_fit *c : *f->slots) { us += c->enq_host_us; n += c->enq_calls; }
+    out[0] = n ? us / (double)n : 0.0; out[1] = (double)n;
+    return 0;
+}
+
+static int enqueue_eval_impl(cocons_fit *f, const double *theta, const double *mean, bool use_trend,
+                             const double *xb, int nxb, std::vector<hipEvent_t> *ev_upd, bool stage_events)
 {
     const int nrhs = f->r + nxb;
     f->nrhs_cur = nrhs;
@@ -1477,6 +1553,17 @@ static int info_status(cocons_fit *f)
     // 0x800 panel product (mode 3), 0x900 the reductions waiting for the engine's last tile)
     if (f->hinfo[1] != 0 && getenv("COCONS_DEBUG_ABORT")) {
         fprintf(stderr, "cocons: hand-off time-out, code 0x%x\n", f->hinfo[1]);
+        if (f->dag_used && f->dag_helpers_live > 0 && f->dflags) {
+            // where the chain helpers stand (chain_helper_loop's progress words) and the engine's flag words
+            unsigned w[64], cq[64];
+            hipMemcpyAsync(w, f->dflags + 3 * (size_t)f->flags_cap, sizeof w, hipMemcpyDeviceToHost, f->stream);
+            hipMemcpyAsync(cq, f->ddag, sizeof cq, hipMemcpyDeviceToHost, f->stream);
+            hipStreamSynchronize(f->stream);
+            fprintf(stderr, "cocons: chain helpers: alive %u, resident %u, go %u, chain counter %u of %u; per helper (task, stage):", w[0], w[2], w[3],
+                    cq[32], f->dag_nctasks);
+            for (int h = 1; h <= f->dag_helpers_live && h < 32; ++h) fprintf(stderr, " (%u,%u)", w[24 + h] >> 4, w[24 + h] & 15u);
+            fprintf(stderr, "\n");
+        }
         if (f->dag_used && f->ddag && (f->hinfo[1] & 0xf00) >= 0xa00) {
             // a wait of the DAG launch: what it waited for (dag_wait's record) and what the word holds NOW
             unsigned rec[7] = {0, 0, 0, 0, 0, 0, 0}, now = 0, qn = 0;
@@ -3311,7 +3398,13 @@ extern "C" int cocons_debug_dag_replay(cocons_fit *f, const double *theta, const
     fv.dag_ok = true;
     if (!(tun().dag != 0 && !fv.hi && !fv.skew && fv.nt > 4)) return fail(-1, "cocons_debug_dag_replay: the DAG schedule does not apply to this fit");
     if (int rc = flags_reset(f, fv.nt)) return rc;
-    if (int rc = dag_prepare(f, fv)) return rc;
+    // (the replayed launch runs EVERY task itself -- the classic layout: under the counters no chain helper could run beside it;
+    // the handle's next evaluation rebuilds its own table)
+    const int chain_saved = tun().dag_chain;
+    tun().dag_chain = 0;
+    const int prc = dag_prepare(f, fv);
+    tun().dag_chain = chain_saved;
+    if (prc) return prc;
     if (f->dag_nsteps < 2) return fail(-1, "cocons_debug_dag_replay: problem too small for a DAG head");
     hipStream_t M = f->stream;
     const size_t lda = fv.lda;

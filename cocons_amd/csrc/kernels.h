@@ -128,8 +128,12 @@ void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, h
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
                          double *wbuf = nullptr, double *pbuf = nullptr, int dag_until = 0,
-                         unsigned long long *trace = nullptr);
-void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false, bool patient = false);
+                         unsigned long long *trace = nullptr,
+                         const void *chain = nullptr, int nhelp = 0);   // chain helpers of the DAG schedule (chol.hip: chain_helper_loop):
+                                                                         // device copy of the task words (launch_chain_args), workgroups
+// nhelp > 0: also waits until that many chain helpers of the engine's launch are resident
+void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false, bool patient = false, int nhelp = 0);
+void launch_raise_word(unsigned *word, hipStream_t s);      // *word = 1 (agent scope) by a one-lane kernel: "everything in front of me on this stream is done"
 // 1: a kernel on `first` and a kernel launched behind it on `second` overlap (the streams sit on different hardware queues);
 // 0: they run one after the other; -1: HIP error.  words: two device words; both streams idle.
 int streams_run_concurrently(hipStream_t first, hipStream_t second, unsigned *words);
@@ -181,20 +185,30 @@ struct DagStepHost {
     unsigned base, near, tpos, nT;
     int H, W, tj0, k0, K, nstrip, two, need, nd_next, split;
     unsigned p2, p3;
+    int nc, cs;               // chain layout (see DagStep)
+    unsigned cbase, cnt;
 };
 // only the leading steps with at least min_tiles update tiles are taken (the head of the factorisation); the last of them has
 // no panel tasks: the panel behind it is left to the caller's classic kernels
 // split != 0: the diagonal-block tiles of the steps from 1 on are computed in two halves (nd_next / split, see DagStep)
 // lead: far tiles of a step in front of its T1 tasks (and the early halves); lead2 / lead3: far tiles between them and the T2
 // tasks, between those and the T3 tasks
+// chain != 0: the chain layout -- the tasks on the chain between two diagonal blocks are left out of the list and counted in
+// *nctasks_out (drawn by the chain helpers of the engine's launch)
 unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, int split, std::vector<DagStepHost> &out,
-                         int lead2 = 0, int lead3 = 0);
+                         int lead2 = 0, int lead3 = 0, int chain = 0, unsigned *nctasks_out = nullptr);
+// device copy of a launch's task words for the chain helpers: dag_chain_args_bytes() bytes at `dev`, written on stream s
+size_t dag_chain_args_bytes();
+void launch_chain_args(void *dev, double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps,
+                       unsigned nctasks, unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall,
+                       double *partbuf, unsigned *dcount, unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word,
+                       const unsigned *alive, hipStream_t s, unsigned long long *trace = nullptr);   // trace: 4 stamps per chain task
 // dsteps: DEVICE copy of the table.  queue, tdone (2 mt (2 mt + 1) / 2 words), pdone ((nsteps + 1) * pstride words,
 // pstride >= 2 mt), pall (nsteps + 1 words): zero at launch.  sig / out / xr: the engine's words (launch_potrf_engine with wbuf = Wt, pbuf = P).
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
                 unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, double *partbuf, unsigned *dcount,
                 unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace = nullptr,
-                const unsigned *alive = nullptr, int xcc_quota = 0, unsigned *hw = nullptr);
+                const unsigned *alive = nullptr, int xcc_quota = 0, unsigned *hw = nullptr, unsigned nctasks = 0);
                 // alive: the engine's alive word (1 + its XCD); xcc_quota: workgroups of the launch that take part on that XCD
                 // partbuf: 2 x 16 x 64 x 64 doubles; dcount: 16 words per step (+ 1 step), zero at launch
 

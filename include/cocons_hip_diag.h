@@ -28,12 +28,18 @@ int cocons_debug_matern(int n, const double *nu, const double *u, double *out);
 int cocons_debug_tune(const char *name, int value);
 
 /* Per-task time stamps of the last dependency-driven factorisation (cocons_debug_tune("dag", 1) and ("dag_trace", 1)) of a
- * fit handle: steps_out = nsteps x 16 ints (base, near, tpos, nT, H, W, tj0, k0, K, nstrip, two, need, nd_next, split, p2, p3), stamps_out =
+ * fit handle: steps_out = nsteps x 20 ints (base, near, tpos, nT, H, W, tj0, k0, K, nstrip, two, need, nd_next, split, p2, p3, nc, cs, cbase, cnt), stamps_out =
  * ntasks x 4 ticks of the 100 MHz clock (drawn, inputs complete, product done, stored).  Returns ntasks; null outputs: sizes only. */
 struct cocons_fit;
 long long cocons_debug_dag_trace(struct cocons_fit *fit, int *nsteps_out, int *steps_out, unsigned long long *stamps_out,
                                  unsigned long long *engine_out);   /* engine_out (may be null): 8 stamps per pair of tiles, room for 8 (nt + 2) */
 
+
+/* ... and of the chain helpers' tasks (chain layout): nctasks x 4 ticks (drawn, inputs complete, product done, stored); returns nctasks */
+long long cocons_debug_chain_trace(struct cocons_fit *fit, unsigned long long *stamps_out);
+
+/* host time spent ENQUEUEING evaluations on this handle and its batch slots: out2[0] = mean microseconds per evaluation, out2[1] = evaluations */
+int cocons_debug_host_enqueue(struct cocons_fit *fit, double *out2);
 
 /* The persistent launch of the dependency-driven schedule replayed ALONE (counter passes: rocprofv3 --pmc serialises kernels,
  * and the real launch waits for the diagonal-block engine on another stream): what the engine would publish is prepared from

@@ -33,6 +33,9 @@ for g in (64, 100):
         t0 = time.perf_counter()
         v, s = fit.neg2loglik_batch_core(ths)
         best = min(best, time.perf_counter() - t0)
-    print("[%s] n=%d: sequential %.1f evals/s, batch of 33 %.1f evals/s (x%.2f), all ok %s, engine %s"
-          % (tag, g * g, 33 / dts, 33 / best, dts / best, bool((s == 0).all()), fit.engine_state()))
+    from cocons_amd import _lib
+    eo = np.zeros(2)
+    _lib.load().cocons_debug_host_enqueue(fit._h, eo.ctypes.data_as(_lib.c_dp))
+    print("[%s] n=%d: sequential %.1f evals/s, batch of 33 %.1f evals/s (x%.2f), all ok %s, engine %s, host enqueue %.0f us per evaluation (%d)"
+          % (tag, g * g, 33 / dts, 33 / best, dts / best, bool((s == 0).all()), fit.engine_state(), eo[0], int(eo[1])))
     fit.close()
