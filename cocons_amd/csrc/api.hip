@@ -410,7 +410,8 @@ static int engine_warm(cocons_fit *f);
 
 static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *locs,
                                    const double *X, const double *z, const double *x_betas,
-                                   const double *smooth_limits, int device, bool allow_sort, bool defer_matrix = false)
+                                   const double *smooth_limits, int device, bool allow_sort, bool defer_matrix = false,
+                                   bool want_engine = true)
 {
     if (n <= 0 || p <= 0 || p > COCONS_P_MAX || r < 0 || q < 0 || !locs || !X || !smooth_limits ||
         (r > 0 && !z) || (q > 0 && !x_betas)) {
@@ -427,7 +428,6 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     f->smooth_limits[0] = smooth_limits[0];
     f->smooth_limits[1] = smooth_limits[1];
     f->world = 1;
-    f->engine_ok = true;
 #define CK(expr)                                                                  \
     do {                                                                          \
         hipError_t e__ = (expr);                                                  \
@@ -566,7 +566,11 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
         f->hinfo_init[0] = 0x7f7f7f7f; f->hinfo_init[1] = 0;
     }
     for (auto &e : f->ev) CK(hipEventCreate(&e));
-    CK(hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking));
+    // (the engine's stream is created by engine_warm, and only for handles that may use the engine: every stream a process
+    // holds takes a place in the round robin over the few hardware queues -- a batch slot on the plain schedule that created
+    // one pushed the NEXT slot's main stream onto a queue already taken, and kernels of streams that share a queue run one
+    // after the other: four "concurrent" slots ran on two queues, round 5's kernel trace)
+    f->engine_ok = want_engine;
     CK(hipEventCreateWithFlags(&f->ev_eng, hipEventDisableTiming));
     // (two streams per handle and no more: every stream a process holds competes for the few hardware queues -- a third one
     // per handle, for a panel-overlap experiment since removed, halved the throughput of the batch slots)
@@ -779,7 +783,7 @@ extern "C" int cocons_fit_set_stream(cocons_fit *f, void *stream)
     // both streams idle before the swap: no event wait of the panel stream may refer to work on a
     // stream that is about to be destroyed
     HIPCHK(hipStreamSynchronize(f->stream));
-    HIPCHK(hipStreamSynchronize(f->stream2));
+    if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
     if (f->own_stream) { HIPCHK(hipStreamDestroy(f->stream)); f->own_stream = false; }
     f->stream = (hipStream_t)stream;
     return 0;
@@ -1100,7 +1104,7 @@ static bool engine_wanted(cocons_fit *f, const FactorView &v)
 static int flags_reset(cocons_fit *f, int nt)
 {
     if (f->flags_cap < nt) {
-        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->dflags) { HIPCHK(hipFree(f->dflags)); f->dflags = nullptr; }
         f->flags_cap = round_up(nt + 8, 64);
         HIPCHK(hipMalloc(&f->dflags, (4 * (size_t)f->flags_cap + 64) * sizeof(unsigned)));
@@ -1125,7 +1129,8 @@ static unsigned *tile_queue(cocons_fit *f, int k)
 // outside any bounded wait.
 static int engine_warm(cocons_fit *f)
 {
-    if (!engine_enabled() || f->nt <= 4) return 0;
+    if (!engine_enabled() || f->nt <= 4 || !f->engine_ok) { f->engine_ok = f->engine_ok && f->stream2 != nullptr; return 0; }
+    if (!f->stream2) HIPCHK(hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking));
     if (int rc = flags_reset(f, f->nt)) return rc;
     HIPCHK(hipStreamSynchronize(f->stream));
     // The engine's stream must not share a hardware queue with the main stream (HIP multiplexes streams onto a few queues;
@@ -1193,7 +1198,7 @@ static int engine_warm(cocons_fit *f)
         launch_potrf_engine(nullptr, 0, 0, 0, f->dinv, f->dinfo, f->dflags, f->dflags, f->dflags, (unsigned *)(f->dinfo + 1),
                             f->dflags + 3 * (size_t)f->flags_cap, f->stream2, f->dinv, f->dinv, 0);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(f->stream2));
+    if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
     return 0;
 }
 
@@ -1209,7 +1214,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
     const size_t elems = v.lda * (size_t)f->npad;
     if (f->dP_elems != elems) {
         HIPCHK(hipStreamSynchronize(f->stream));
-        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->dP) { HIPCHK(hipFree(f->dP)); f->dP = nullptr; f->dP_elems = 0; }
         HIPCHK(hipMalloc(&f->dP, elems * sizeof(double)));
         HIPCHK(hipMemsetAsync(f->dP, 0, elems * sizeof(double), f->stream));
@@ -1218,7 +1223,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
     if (!f->dpart) HIPCHK(hipMalloc(&f->dpart, (size_t)2 * 16 * 64 * 64 * sizeof(double)));
     if (f->dWt_tiles < v.nt) {
         HIPCHK(hipStreamSynchronize(f->stream));
-        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->dWt) { HIPCHK(hipFree(f->dWt)); f->dWt = nullptr; }
         HIPCHK(hipMalloc(&f->dWt, (size_t)v.nt * TILE * TILE * sizeof(double)));
         HIPCHK(hipMemsetAsync(f->dWt, 0, (size_t)v.nt * TILE * TILE * sizeof(double), f->stream));   // zero above the diagonals, for good
@@ -1233,7 +1238,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         const unsigned ntasks = dag_build_steps(v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, steps,
                                                 tun().dag_lead2, tun().dag_lead3, chain, &nctasks);
         HIPCHK(hipStreamSynchronize(f->stream));
-        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->ddag_steps) { HIPCHK(hipFree(f->ddag_steps)); f->ddag_steps = nullptr; }
         HIPCHK(hipMalloc(&f->ddag_steps, (steps.size() + 1) * sizeof(DagStepHost)));
         // (on the handle's own stream: the library never touches the NULL stream -- a synchronous hipMemcpy here gave it a
@@ -1257,7 +1262,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
     const size_t trace_elems = (size_t)f->dag_ntasks * 5 + 8 * (size_t)(v.nt + 2) + 4 * (size_t)f->dag_nctasks;     // (+ 4 stamps per chain task)
     if (tun().dag_trace && f->dag_trace_elems < trace_elems) {
         HIPCHK(hipStreamSynchronize(f->stream));
-        HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->ddag_trace) { HIPCHK(hipFree(f->ddag_trace)); f->ddag_trace = nullptr; f->dag_trace_elems = 0; }
         HIPCHK(hipMalloc(&f->ddag_trace, trace_elems * sizeof(unsigned long long)));
         f->dag_trace_elems = trace_elems;
@@ -1656,7 +1661,7 @@ static bool engine_retry(cocons_fit *f, int st)
     f->engine_skip = 1 << f->engine_fails;
     f->engine_live = false;
     f->engine_used = false;
-    hipStreamSynchronize(f->stream2);
+    if (f->stream2) hipStreamSynchronize(f->stream2);
     return true;
 }
 
@@ -1724,11 +1729,46 @@ static void dense_collect(cocons_fit *f, double *sum_logliks, double *parts)
 // A second handle over the same data with its own factorisation buffer and streams: one slot of
 // cocons_neg2loglik_batch.  A taper handle's clone shares nothing on the device (pattern and taper entries are
 // copied device to device) and keeps the order and the envelope of its original.
-static cocons_fit *clone_for_slot(cocons_fit *f)
+// A slot's main stream must run BESIDE the main streams of the handle and of its other slots (kernels of streams that share
+// a hardware queue run one after the other): tested like the engine's stream, redrawn on a clash.
+static void slot_stream_apart(cocons_fit *f, cocons_fit *c)
 {
-    if (f->taper_nnz <= 0)
-        return cocons_fit_create(f->n_user, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
-                                 f->smooth_limits, f->device);
+    if (!c->own_stream || !c->dflags) return;
+    unsigned *words = c->dflags + 3 * (size_t)c->flags_cap + 8;
+    std::vector<hipStream_t> losers;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        bool clash = false;
+        std::vector<cocons_fit *> peers{f};
+        if (f->slots) for (cocons_fit *o : *f->slots) if (o != c) peers.push_back(o);
+        for (cocons_fit *o : peers) {
+            if (hipStreamQuery(o->stream) != hipSuccess) { (void)hipGetLastError(); continue; }      // (busy: not probed)
+            const int r = streams_run_concurrently(o->stream, c->stream, words);
+            if (r == 0) { clash = true; break; }
+            if (r < 0) { (void)hipGetLastError(); break; }
+        }
+        if (!clash) break;
+        losers.push_back(c->stream);
+        c->stream = nullptr;
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->stream = losers.back(); losers.pop_back(); break; }
+    }
+    for (hipStream_t l : losers) hipStreamDestroy(l);
+    if (c->stream2 && streams_run_concurrently(c->stream2, c->stream, words) == 0) c->engine_ok = false;     // (its own pair again)
+    (void)hipMemsetAsync(c->dflags, 0, (4 * (size_t)c->flags_cap + 64) * sizeof(unsigned), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+}
+
+static cocons_fit *clone_for_slot(cocons_fit *f, bool want_engine)
+{
+    if (f->taper_nnz <= 0) {
+        cocons_fit *c = fit_create_impl(f->n_user, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
+                                        f->smooth_limits, f->device, true, false, want_engine);
+        if (c) {
+            if (!c->dflags && flags_reset(c, c->nt) != 0) { cocons_fit_destroy(c); return nullptr; }
+            hipStreamSynchronize(c->stream);
+            slot_stream_apart(f, c);
+        }
+        return c;
+    }
     cocons_fit *c = fit_create_impl(f->n_user, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
                                     f->smooth_limits, f->device, false, true);      // h_* of a taper handle are in ITS order
     if (!c) return nullptr;
@@ -1762,31 +1802,38 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
     if (nb < 0 || (nb > 0 && (!thetas || !means || !values || !status)))
         return fail(-1, "cocons_neg2loglik_batch: bad argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_batch: fit has no z");
-    static int nslots_env = -1;
+    // How many evaluations in flight, and on which schedule (round 5, from the kernel trace of a batch,
+    // tools/diag/batch_trace.py): a process's streams share FOUR hardware queues, and kernels of streams that share one run one
+    // after the other.  A resident engine holds its queue for the whole evaluation, so two engine-schedule evaluations -- 2
+    // main + 2 engine streams -- are all that fits; a third runs behind one of them (n = 4096: 862 evaluations/s with two
+    // slots, 695 with three).  On the plain schedule a slot needs ONE queue -- once the slots no longer create engine streams
+    // they never use, which had put four slots' main streams on two queues (one queue busy 88 % of the time in the trace) --
+    // and four evaluations in flight beat two with engines at every size measured: n = 4096 1067 against 862 evaluations/s,
+    // n = 10^4 134 against 128 (33-point gradient).  More hardware queues (GPU_MAX_HW_QUEUES = 8, 12) make it WORSE (642 ... 996
+    // at n = 4096): four is what the chip runs side by side.  COCONS_BATCH_ENGINE=1 (two engine slots) and COCONS_BATCH_SLOTS override.
+    static int nslots_env = -1, batch_engine = -2;
     if (nslots_env < 0) {
         const char *e = getenv("COCONS_BATCH_SLOTS");
-        nslots_env = e ? atoi(e) : 2;
-        if (nslots_env < 1) nslots_env = 1;
+        nslots_env = e ? atoi(e) : 0;
+        if (nslots_env < 0) nslots_env = 0;
         if (nslots_env > 8) nslots_env = 8;
+        const char *e2 = getenv("COCONS_BATCH_ENGINE");
+        batch_engine = e2 ? (atoi(e2) ? 1 : 0) : -1;
     }
-    int S = nb < nslots_env ? (nb > 0 ? nb : 1) : nslots_env;
+    const bool eng_mode = batch_engine >= 0 ? batch_engine == 1 : false;
+    const int nslots = nslots_env > 0 ? nslots_env : (eng_mode ? 2 : 4);
+    int S = nb < nslots ? (nb > 0 ? nb : 1) : nslots;
     if (!f->slots) f->slots = new std::vector<cocons_fit *>();
     // every extra slot is a clone of the handle with its own n x n factorisation buffer
     // (lda * npad * 8 bytes: 0.83 GB at n = 10^4); if one cannot be created (out of memory) the
     // batch runs on the slots that exist -- slot 0 is the fit itself, so it always completes
     while ((int)f->slots->size() < S - 1) {
-        cocons_fit *c = clone_for_slot(f);
+        cocons_fit *c = clone_for_slot(f, eng_mode);
         if (!c) { (void)hipGetLastError(); break; }
         f->slots->push_back(c);
     }
-    // Two evaluations in flight, each on the engine + DAG schedule (round 4; n = 10^4, 40 points: 123 evaluations/s against
-    // 105 one after the other -- the chain-bound tail of one runs beside the chip-filling head of the other).  Until round 3
-    // the slots ran the plain schedule, three deep: 106 (COCONS_BATCH_ENGINE=0 COCONS_BATCH_SLOTS=3); engine + 3 slots: 116,
-    // engine + 4: 122, plain + 2: 116.
     const bool engine_saved = f->engine_ok;
-    static int batch_engine = -1;
-    if (batch_engine < 0) { const char *e = getenv("COCONS_BATCH_ENGINE"); batch_engine = e ? atoi(e) : 1; }
-    if (!batch_engine) {
+    if (!eng_mode) {
         if (S > 1) f->engine_ok = false;
         for (auto c : *f->slots) c->engine_ok = false;
     }
