@@ -9,6 +9,13 @@ while the owner of block k + 1 -- between its solve and its pack -- updates its 
 the broadcast of L_(k+1,k+1).  So a step lasts
     max( chain, rank ),   chain = bcast(L) + unpack + solve + diagonal update + diagonal factor      (independent of N)
                           rank  = unpack + solve + pack + allgather(B_k) + U_k / N
+The chain term holds no all-gather because the code issues the broadcast of L_(k+1,k+1) IN FRONT of the all-gather of step k, on
+a stream -- under RCCL also a communicator (ncclCommSplit) -- of its own (round 5; until round 4 it was queued behind the
+all-gather on the one communication stream, so the chain did wait for the bulk exchange and this model was optimistic).
+What forbids more: the chain's solve (three launches of latency-bound kernels, 45 us: a launch over 4 strips takes as long as one
+over 80 -- solving the next diagonal block's 256 rows first would not shorten it) and its diagonal factor (78 us: one launch of
+the engine kernel; the same two tile factorisations that bound the single-GPU tail); at N = 2 the rank term (one link, half the
+updates).
 """
 from __future__ import annotations
 
@@ -56,6 +63,8 @@ def predict(n: int, world: int, single_gpu_evals_per_s: float | None = None) -> 
         total += step
     out = {"evals_per_s": round(1e6 / total, 1), "ms_per_eval": round(total * 1e-3, 3), "chain_us_per_block": round(chain, 1),
            "blocks": nb, "blocks_bound_by_the_chain": int(chain_bound),
+           "forbidding_term": ("chain" if chain_bound * 2 >= nb else "rank work (updates / N + all-gather over the links)") if world > 1 else None,
+           "status": "unverified: no multi-GPU node has run the sharded evaluation yet",
            "assumptions": {"link_GBps_per_direction": LINK_GBPS, "collective_latency_us": COLL_LATENCY,
                            "diag_factor_us": T_DIAG_FACTOR, "solve_us": T_SOLVE, "updates_ms_one_gpu": round(upd_total_us * 1e-3, 2)}}
     if single_gpu_evals_per_s:
