@@ -928,6 +928,16 @@ static int band_hi(const FactorView &v, int k)
     return h < v.nt ? h : v.nt;
 }
 
+// tile factorisation + the panel solve below it.  (ONE launch for the two -- the solve's workgroups fetch their rows, wait for
+// a word the factorising workgroup raises, take L and solve -- was built and measured in round 5: SLOWER, taper path 4.18 -> 4.57
+// ms, batch at n = 4096 1066 -> 1031 evaluations/s: the boundary between the two launches costs less than the write-through
+// factor and the serialised fetch of L behind the word; removed.)
+static void potrf_solve(cocons_fit *f, double *A, size_t lda, int tile, int r0, int r1, double *q, hipStream_t s, int br, int er)
+{
+    launch_potrf_tile(A, lda, tile * TILE, q, f->dinfo, s);
+    launch_trsm_tile(A, lda, tile * TILE, r0, r1, q, s, nullptr, nullptr, br, er);
+}
+
 static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
 {
     const int nt = v.nt, mt = v.mt;
@@ -936,14 +946,12 @@ static void panel_ops(cocons_fit *f, const FactorView &v, int k, hipStream_t s)
     double *q0 = f->dinv, *q1 = f->dinv + 8 * 256;
     const int hb = band_hi(v, k);                       // rows [.., hb) of the band, then the rows under the matrix [nt, mt)
     const int br = hb >= 0 ? hb * TILE : -1, er = nt * TILE;
-    launch_potrf_tile(A, lda, k * TILE, q0, f->dinfo, s);
     const int r1 = mt * TILE - 64 * v.trim;
-    launch_trsm_tile(A, lda, k * TILE, (k + 1) * TILE, r1, q0, s, nullptr, nullptr, br, er);
+    potrf_solve(f, A, lda, k, (k + 1) * TILE, r1, q0, s, br, er);
     if (k + 1 < nt) {
         launch_update(A, lda, k * TILE, TILE, k + 1, mt, k + 1, k + 2, true, s, nullptr, -1, nullptr, nullptr, nullptr, hb, nt,
                       0, v.trim);
-        launch_potrf_tile(A, lda, (k + 1) * TILE, q1, f->dinfo, s);
-        launch_trsm_tile(A, lda, (k + 1) * TILE, (k + 2) * TILE, r1, q1, s, nullptr, nullptr, br, er);
+        potrf_solve(f, A, lda, k + 1, (k + 2) * TILE, r1, q1, s, br, er);
     }
 }
 
@@ -1152,7 +1160,10 @@ static int engine_warm(cocons_fit *f)
         // more streams in the process -- a batch slot, a second handle of the caller, torch's -- A.main can share a queue
         // with B.engine and B.main with A.engine: each engine then blocks the kernels the OTHER evaluation waits for, and only
         // the bounded waits end it -- correct values, seconds lost.)  Streams of handles that are busy right now are not
-        // probed (the probe needs idle streams); a collision redraws THIS handle's stream and repeats all tests.
+        // probed (the probe needs idle streams); a collision redraws THIS handle's stream and repeats all tests.  Only the
+        // four most recent other handles are looked at, and a handle that finds no clash-free draw KEEPS its engine: four
+        // hardware queues cannot keep a dozen live handles apart, and a clash only matters between handles that work at
+        // the same moment (a test that holds twelve idle handles must not lose the engine on four of them).
         unsigned *words = f->dflags + 3 * (size_t)f->flags_cap + 8;
         for (int round = 0; ok == 1 && round < 8; ++round) {
             std::vector<cocons_fit *> others;
@@ -1162,6 +1173,7 @@ static int engine_warm(cocons_fit *f)
                     if (o != f && o->pid == f->pid && o->device == f->device && o->stream && o->stream2 && o->engine_ok &&
                         hipStreamQuery(o->stream) == hipSuccess && hipStreamQuery(o->stream2) == hipSuccess)
                         others.push_back(o);
+                if (others.size() > 4) others.erase(others.begin(), others.end() - 4);
             }
             (void)hipGetLastError();
             int clash = 0;                 // 1: this engine stream beside another main stream; 2: this main stream beside another engine
@@ -1183,8 +1195,23 @@ static int engine_warm(cocons_fit *f)
             // the redrawn stream must still pair with this handle's other stream
             int again = streams_run_concurrently(f->stream2, f->stream, words);
             if (again < 0) { ok = -1; break; }
-            if (again == 0) { ok = 0; break; }
-            if (round == 7) ok = 0;        // no assignment found: this handle stays on the plain schedule
+            if (again == 0) {
+                // (the redrawn stream shares a queue with this handle's other stream: draw again next round -- the own pair
+                // is what must never share)
+                hipStream_t &other = clash == 1 ? f->stream2 : f->stream;
+                (void)other;
+                bool fixed = false;
+                for (int t2 = 0; t2 < 4 && !fixed; ++t2) {
+                    losers.push_back(mine);
+                    mine = nullptr;
+                    if (hipStreamCreateWithFlags(&mine, hipStreamNonBlocking) != hipSuccess) { ok = -1; break; }
+                    const int r2 = streams_run_concurrently(f->stream2, f->stream, words);
+                    if (r2 < 0) { ok = -1; break; }
+                    fixed = r2 == 1;
+                }
+                if (ok != 1) break;
+                if (!fixed) { ok = 0; break; }
+            }
         }
         for (hipStream_t l : losers) hipStreamDestroy(l);
         if (ok < 0) { (void)hipGetLastError(); return fail(-100, "engine_warm: stream self-test failed"); }
@@ -1394,9 +1421,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
                 double *q = f->dinv + (size_t)(k & 1) * 2048;
                 double *Ak = band_base(v.A, k, v.skew);
                 const int e0 = v.skew ? k + v.skew : nt, e1 = e0 + (mt - nt);      // tile rows under the matrix
-                launch_potrf_tile(Ak, v.lda, k * TILE, q, f->dinfo, M);
-                launch_trsm_tile(Ak, v.lda, k * TILE, (k + 1) * TILE, e1 * TILE - 64 * v.trim, q, M, nullptr, nullptr, hb * TILE,
-                                 e0 * TILE);
+                potrf_solve(f, Ak, v.lda, k, (k + 1) * TILE, e1 * TILE - 64 * v.trim, q, M, hb * TILE, e0 * TILE);
                 if (k + 1 < nt)
                     launch_update(v.A, v.lda, k * TILE, TILE, k + 1, mt, k + 1, hb < nt ? hb : nt, true, M, nullptr, -1,
                                   nullptr, nullptr, nullptr, hb, nt, v.skew, v.trim);
@@ -1770,8 +1795,11 @@ static cocons_fit *clone_for_slot(cocons_fit *f, bool want_engine)
         return c;
     }
     cocons_fit *c = fit_create_impl(f->n_user, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
-                                    f->smooth_limits, f->device, false, true);      // h_* of a taper handle are in ITS order
-    if (!c) return nullptr;
+                                    f->smooth_limits, f->device, false, true, false);      // h_* of a taper handle are in ITS order;
+    if (!c) return nullptr;                                                                  // band-limited: never an engine
+    if (!c->dflags && flags_reset(c, c->nt) != 0) { cocons_fit_destroy(c); return nullptr; }
+    hipStreamSynchronize(c->stream);
+    slot_stream_apart(f, c);
     c->skew = f->skew;                        // the same (packed) buffer layout as the original
     if (fit_alloc_matrix(c, f->r + f->p) != 0) { cocons_fit_destroy(c); return nullptr; }
     const size_t nnz = (size_t)f->taper_nnz;

@@ -6,11 +6,13 @@
 #
 # The device-resident data of a fit live in an explicit handle (external pointer).  Callers that hold
 # one pass it as `fit = `; otherwise -- cocoOptim calls the closures with the reference's signatures, which have no
-# handle -- the native side keeps up to eight handles per process and finds the right one in O(1): addresses and
-# dimensions of (locs, x_covariates, z, x_betas), smooth.limits and a fingerprint of sampled elements; only when that
-# misses are the data compared with the copies the handles keep, and only then is a handle created
+# handle -- the native side keeps up to eight handles per process and finds the right one in O(1) by the addresses and
+# dimensions of (locs, x_covariates, z, x_betas) and smooth.limits.  An address is a sound key because the cached objects
+# are PRESERVED (no other object can get the address) and marked NOT MUTABLE (R code that modifies one must duplicate
+# it first: new address, miss, data compared), and a hit is confirmed against the handle's copy of the data; only when
+# the addresses miss are the data compared with every cached handle, and only then is a handle created
 # (glue/cocons_hip_glue.c, _cocons_hip_fit_cached).  No hash of the data on any path, no package beyond base R.
-# cocons_hip_forget() drops the cached handles (e.g. after modifying a data object IN PLACE from C code).
+# cocons_hip_forget() drops the cached handles and releases the objects they key on.
 
 cocons_hip_fit <- function(locs, x_covariates, z, smooth.limits, x_betas = NULL, device = NULL) {
   if (is.null(device)) {
