@@ -717,18 +717,29 @@ potrf_engine_kernel(EngineArgs e)
         __syncthreads();
         if (tid == 0) signal_add(e.xr + t);
         if (tr && tid == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
-        // A(t+1,t+1) -= X X^T : lower blocks b = wave, wave + 8, ...
-        for (int bb = wave; bb < 36; bb += 8) {
-            const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
-            d4 acc = glb_blk_wt(A, lda, c1 + 16 * ib, c1 + 16 * kb, lane);
+        // A(t+1,t+1) -= X X^T : lower blocks b = wave, wave + 8, ... -- the next block of the wave is fetched while the current
+        // one is multiplied (round 5: its memory round trip used to stand in front of every block's products; all of a wave's
+        // 4 or 5 blocks up front spilled the kernel)
+        {
+            d4 cur = glb_blk_wt(A, lda, c1 + 16 * c_tri_ib[wave], c1 + 16 * (wave - c_tri_ib[wave] * (c_tri_ib[wave] + 1) / 2), lane);
+            for (int bb = wave; bb < 36; bb += 8) {
+                const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+                d4 nxt = cur;
+                if (bb + 8 < 36) {
+                    const int ib2 = c_tri_ib[bb + 8], kb2 = bb + 8 - ib2 * (ib2 + 1) / 2;
+                    nxt = glb_blk_wt(A, lda, c1 + 16 * ib2, c1 + 16 * kb2, lane);
+                }
+                d4 acc = cur;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                d4 P = lds_blk(XS + (ib * 8 + j) * 256, lane);
-                d4 Qk = lds_blk(XS + (kb * 8 + j) * 256, lane);
-                P = -P;
-                blk_mma(acc, P, Qk);
+                for (int j = 0; j < 8; ++j) {
+                    d4 P = lds_blk(XS + (ib * 8 + j) * 256, lane);
+                    d4 Qk = lds_blk(XS + (kb * 8 + j) * 256, lane);
+                    P = -P;
+                    blk_mma(acc, P, Qk);
+                }
+                glb_blk_store_wt(A, lda, c1 + 16 * ib, c1 + 16 * kb, lane, acc);
+                cur = nxt;
             }
-            glb_blk_store_wt(A, lda, c1 + 16 * ib, c1 + 16 * kb, lane, acc);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // X in LDS is dead; the tile is re-read from memory
