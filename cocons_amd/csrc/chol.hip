@@ -1297,7 +1297,7 @@ dag_kernel(DagArgs a)
             we = a.tdone + (ti * (ti + 1) / 2 + tj); ne = (unsigned)s;
             dn = we; dval = (unsigned)s + 1u;
             const int Ti = (ti >> 1) - t, Tj = (tj >> 1) - t;
-            if (Ti >= 0 && Ti <= 1 && Tj >= 0 && Tj <= Ti) {
+            if (Ti >= 0 && Ti <= st.two && Tj >= 0 && Tj <= Ti) {     // (a last block of ONE tile: rows of right-hand sides may lie below it)
                 sigT = t + Ti; prio = 3;
                 if (st.split) {
                     // One of the ten tiles the next diagonal block waits for.  Under load a tile's product is memory latency

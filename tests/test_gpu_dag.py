@@ -8,7 +8,9 @@ import os
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("COCONS_ENGINE", "1") == "0",
+                                 reason="COCONS_ENGINE=0: the dependency-driven schedule needs the diagonal-block engine")]
 
 
 def _tune(name, value):
@@ -209,6 +211,7 @@ def test_dag_chain_layout_vs_classic(gx, gy, min_tiles):
         _tune("dag", 1)
         _tune("dag_min_tiles", min_tiles)
         _tune("dag_chain", 0)
+        _tune("dag_split", 1)          # (the chain layout always splits the diagonal-block tiles: bit-identity is with that list)
         v_list, p_list = fit.neg2loglik_core(th)
         _tune("dag_chain", 1)
         v_chain, p_chain = fit.neg2loglik_core(th)
@@ -228,4 +231,5 @@ def test_dag_chain_layout_vs_classic(gx, gy, min_tiles):
     finally:
         _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
         _tune("dag_chain", int(os.environ.get("COCONS_DAG_CHAIN", "0")))
+        _tune("dag_split", int(os.environ.get("COCONS_DAG_SPLIT", "1")))
         _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "3000")))
