@@ -290,6 +290,8 @@ struct cocons_fit {
     size_t dag_trace_elems;       // allocated 64-bit words of ddag_trace (5 per task + 8 per tile pair)
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
     int dag_helpers_live;         // chain helpers in the engine launch of the factorisation being enqueued (0: none)
+    int engine_pair_live;         // 1: the engine launched for the next factorisation has a pair partner (counts itself like a helper)
+    double *dmbox; size_t dmbox_elems;   // the pair mode's mailboxes (engine_start)
     double enq_host_us; long long enq_calls;      // (diagnostics) host time spent enqueueing evaluations, calls: cocons_debug_host_enqueue
     bool dag_used;                // the factorisation enqueued last ran the DAG schedule: its factor is split over dA and dP
     double dag_flops; int dag_events;   // profile runs: update flops inside the DAG launch; 1 = the first event pair is that launch
@@ -387,6 +389,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         for (auto &e : f->ev) if (e) hipEventDestroy(e);
         if (f->ev_eng) hipEventDestroy(f->ev_eng);
         hipFree(f->dflags);
+        if (f->dmbox) hipFree(f->dmbox);
         hipFree(f->dP); hipFree(f->dWt); hipFree(f->ddag); hipFree(f->ddag_steps); hipFree(f->ddag_trace); hipFree(f->dpart);
         hipFree(f->ddag_chain);
         hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_thi);
@@ -979,6 +982,9 @@ struct Tunables {
                              // the classic schedule's 125, and the eleven CUs it holds cost the chip-bound head as much again:
                              // +0.1 .. +0.4 % at n = 10^4 (alternated in one process) -- not the default.
     int dag_helpers = 10;    // COCONS_DAG_HELPERS: that many of them (one round of the ten tiles of a diagonal block)
+    int engine_pair = 1;     // COCONS_ENGINE_PAIR: 1 = the engine is a PAIR of workgroups -- the second one follows the first tile's
+                             // factorisation column block by column block (strip solve, tile update) and factors the second tile
+                             // (chol.hip: engine_partner_loop); 0 = one workgroup does the four passes one behind the other
     int dag_trace = 0;       // (diagnostics) time stamps per task, cocons_debug_dag_trace
     int gate_sabotage = 0;   // (tests) the next N engine-schedule factorisations wait at the gate for a word nobody raises:
                              // a genuine 5 ms time-out, abort code 0x600, to exercise the fall-back and its book-keeping
@@ -1000,6 +1006,7 @@ static Tunables &tun()
         rd("COCONS_DAG_XCC_QUOTA", t.dag_xcc_quota);
         rd("COCONS_DAG_CHAIN", t.dag_chain);
         rd("COCONS_DAG_HELPERS", t.dag_helpers);
+        rd("COCONS_ENGINE_PAIR", t.engine_pair);
         if (t.dag_helpers < 1) t.dag_helpers = 1;
         if (t.dag_helpers > 24) t.dag_helpers = 24;
         t.init = true;
@@ -1024,6 +1031,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "dag_trace") t.dag_trace = value;
     else if (k == "dag_chain") t.dag_chain = value;
     else if (k == "dag_helpers") t.dag_helpers = value < 1 ? 1 : (value > 24 ? 24 : value);
+    else if (k == "engine_pair") t.engine_pair = value;
     else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
@@ -1356,6 +1364,19 @@ static int engine_start(cocons_fit *f, const FactorView &v)
         if (int rc = dag_prepare(f, v)) return rc;
         if (f->dag_nsteps < 2) f->dag_next = false;          // too small a problem for a head worth the launch: classic throughout
     }
+    f->engine_pair_live = tun().engine_pair != 0 ? 1 : 0;
+    if (f->engine_pair_live) {
+        // the mailboxes of the blocks' first tiles, every byte 0xff (potrf_tile_body: mbox): 88 KB per block, 3.6 MB at n = 10^4
+        const size_t need = ((size_t)nt / 2 + 2) * ENGINE_MBOX_DOUBLES;
+        if (f->dmbox_elems < need) {
+            HIPCHK(hipStreamSynchronize(M));
+            if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
+            if (f->dmbox) { HIPCHK(hipFree(f->dmbox)); f->dmbox = nullptr; f->dmbox_elems = 0; }
+            HIPCHK(hipMalloc(&f->dmbox, need * sizeof(double)));
+            f->dmbox_elems = need;
+        }
+        HIPCHK(hipMemsetAsync(f->dmbox, 0xff, ((size_t)nt / 2 + 2) * ENGINE_MBOX_DOUBLES * sizeof(double), M));
+    }
     HIPCHK(hipEventRecord(f->ev_eng, M));                    // (behind the resets of the flag and task words, and of W / P when new)
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
     unsigned *alive_w = f->dflags + 3 * (size_t)f->flags_cap;
@@ -1374,7 +1395,8 @@ static int engine_start(cocons_fit *f, const FactorView &v)
                         alive_w, f->stream2, f->dag_next ? f->dWt : nullptr,
                         f->dag_next ? f->dP : nullptr, f->dag_next ? 2 * f->dag_nsteps : 0,
                         (f->dag_next && f->dag_trace_tasks) ? f->ddag_trace + 4 * (size_t)f->dag_ntasks : nullptr,
-                        helpers ? f->ddag_chain : nullptr, f->dag_helpers_live);
+                        helpers ? f->ddag_chain : nullptr, f->dag_helpers_live,
+                        f->engine_pair_live ? f->dmbox : nullptr);
     f->engine_live = true;
     return 0;
 }
@@ -1444,7 +1466,8 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     unsigned *abort_word = (unsigned *)(f->dinfo + 1);
     unsigned *alive = f->dflags + 3 * (size_t)f->flags_cap;
     if (tun().gate_sabotage > 0) { --tun().gate_sabotage; alive += 1; }      // (tests: a word that stays zero)
-    launch_engine_gate(alive, abort_word, M, false, f->engine_ops++ == 0, f->dag_next ? f->dag_helpers_live : 0);
+    launch_engine_gate(alive, abort_word, M, false, f->engine_ops++ == 0,
+                       (f->dag_next ? f->dag_helpers_live : 0) + f->engine_pair_live);      // (chain helpers and the pair partner count themselves)
     panel_ops(f, v, 0, M);
     if (f->dag_next && f->dag_helpers_live > 0) launch_raise_word(alive + 3, M);      // the chain helpers may touch the matrix now
     f->dag_used = f->dag_next;

@@ -289,9 +289,29 @@ __constant__ int c_tri_ib[36] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5,
 #ifndef POTRF_S_WAVES
 #define POTRF_S_WAVES 7
 #endif
-template <bool WT>
+// FROM_LDS (the pair partner of the engine, round 5): the tile's image is in LDS already -- lower blocks in place, diagonal
+// blocks mirrored, a barrier passed -- and nothing is fetched.
+// mbox (may be null): MAILBOX of the tile for a consumer that FOLLOWS the factorisation column block by column block (the pair
+// partner): 44 blocks of 256 doubles, column block j -- blocks (j .. 7, j), then its Q operands -- contiguous at MBOX_OFF(j), in
+// the LDS block layout; the caller has filled it with the bit pattern ~0 (a NaN no arithmetic produces), and every finished block
+// is stored there too, the moment it is stored to the matrix.  The consumer reads the mailbox until no word of a column block
+// is the fill pattern any more: the data is its own flag (8-byte write-through stores are seen whole), which costs ONE round
+// trip per column block where a drained flag behind the stores cost the drain, the flag's trip and then the data's.
+// late (may be null): a word to be raised (+1) for stores the CALLER issued before the call -- drained in the first S phase (every
+// wave, behind ~1 us of other work), so that the caller need not wait for them (the pair partner's copy of X: 64 eight-byte
+// write-through stores per lane, which nothing on the chain needs).
+#define MBOX_OFF(j) (256 * (9 * (j) - (j) * ((j) - 1) / 2))
+__device__ __forceinline__ void mbox_store(double *mb, int lane, const d4 &v)
+{
+    store_wt(mb + lane, v[0]);
+    store_wt(mb + lane + 64, v[1]);
+    store_wt(mb + lane + 128, v[2]);
+    store_wt(mb + lane + 192, v[3]);
+}
+template <bool WT, bool FROM_LDS = false>
 __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, double *q_out, int *info, double *smem,
-                                                double *qall, double *winv = nullptr, double *xi = nullptr)
+                                                double *qall, double *winv = nullptr, double *xi = nullptr, double *mbox = nullptr,
+                                                unsigned *late = nullptr)
 {
     const bool INV = winv != nullptr;          // (wave-uniform; needs qall and xi)
     // lower-packed image: block (ib,kb), ib >= kb, at (ib (ib+1)/2 + kb) * 256  (72 KB), plus the
@@ -299,7 +319,12 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
     double *S = smem;
     double *QS = smem + 36 * 256;
 #define SB(ib, kb) (S + ((ib) * ((ib) + 1) / 2 + (kb)) * 256)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the thread index is taken afresh: the engine kernel holds several inlined copies of this body, and what the compiler
+    // derives from the index -- LDS addresses, the identity's lanes -- would otherwise be formed once at the kernel's entry
+    // for all of them and live, or spill, through everything else)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // (round 5) Wave 0 fetches the first diagonal block straight into registers -- blk layout, mirrored like below -- and
     // factors it WHILE the cooperative fetch of the tile is in flight (its own loads are issued first and return first); and
@@ -307,6 +332,14 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
     // it, instead of in a pass of its own at the end: the tile's fetch and store (4.5 of its 26 us) now run beside the first
     // and behind the last register factorisation.
     d4 D0 = {0.0, 0.0, 0.0, 0.0};
+    double Q0[4] = {0.0, 0.0, 0.0, 0.0};
+    if (FROM_LDS) {
+        if (wave == 0) {
+            D0 = lds_blk(S, lane);
+            int f = potrf16_regs(D0, Q0, lane);
+            if (f && lane == 0) atomicMin(info, c0 + f);
+        }
+    } else {
     if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -315,7 +348,6 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
             D0[r] = WT ? load_wt(sp) : *sp;
         }
     }
-    double Q0[4] = {0.0, 0.0, 0.0, 0.0};
     {   // 36 lower blocks, 18 per half-workgroup: every global load is issued before the
         // first LDS store (one round trip instead of 36; matters when the chip is busy)
         const int i = tid & 15, k = (tid >> 4) & 15;
@@ -343,15 +375,18 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
             SB(ib, kb)[k * 16 + i] = v[t];
         }
     }
+    }
     __syncthreads();
     if (wave == 0) {             // (over the unfactored copy the cooperative stores left there)
         lds_blk_store(S, lane, D0);
         if (WT) glb_blk_store_wt(A, lda, c0, c0, lane, D0); else glb_blk_store(A, lda, c0, c0, lane, D0);
+        if (mbox) mbox_store(mbox, lane, D0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             QS[s * 64 + lane] = Q0[s];
             if (WT) store_wt(q_out + s * 64 + lane, Q0[s]); else q_out[s * 64 + lane] = Q0[s];
             if (qall) qall[s * 64 + lane] = Q0[s];
+            if (mbox) store_wt(mbox + 8 * 256 + s * 64 + lane, Q0[s]);
         }
     }
     __syncthreads();
@@ -372,6 +407,7 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
             lds_blk_store(blk, lane, B);
             if (WT) glb_blk_store_wt(A, lda, c0 + 16 * ib, c0 + 16 * jb, lane, B);      // final: to memory now
             else glb_blk_store(A, lda, c0 + 16 * ib, c0 + 16 * jb, lane, B);
+            if (mbox) mbox_store(mbox + MBOX_OFF(jb) + (ib - jb) * 256, lane, B);
         }
         __syncthreads();
         // S: wave 0 -> next diagonal block, then its factorisation; others share the rest
@@ -385,9 +421,11 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
             double Q[4];
             int f = potrf16_regs(acc, Q, lane);
             if (f && lane == 0) atomicMin(info, c0 + 16 * nb + f);
+            if (late && jb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the caller's stores: issued > 2 us ago)
             lds_blk_store(blk, lane, acc);
             if (WT) glb_blk_store_wt(A, lda, c0 + 16 * nb, c0 + 16 * nb, lane, acc);      // final: to memory now
             else glb_blk_store(A, lda, c0 + 16 * nb, c0 + 16 * nb, lane, acc);
+            if (mbox) mbox_store(mbox + MBOX_OFF(nb), lane, acc);
             // the single Q buffer is still being read by the T phase of this jb?  No: T ended at
             // the barrier above; the next reader is the T phase after the barrier below.
 #pragma unroll
@@ -395,6 +433,7 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
                 QS[s * 64 + lane] = Q[s];
                 if (WT) store_wt(q_out + nb * 256 + s * 64 + lane, Q[s]); else q_out[nb * 256 + s * 64 + lane] = Q[s];
                 if (qall) qall[nb * 256 + s * 64 + lane] = Q[s];
+                if (mbox) store_wt(mbox + MBOX_OFF(nb) + (8 - nb) * 256 + s * 64 + lane, Q[s]);
             }
         } else {
             int cnt = 0;
@@ -415,6 +454,7 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
                     lds_blk_store(blk, lane, acc);
                 }
             }
+            if (late && jb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the caller's stores, see the header)
             // column block j = jb of the inverse's strips (see the header comment).  Strip w lives on wave INV_WAVE[w]: NOT on
             // wave 4, which shares its SIMD -- and the SIMD's double-precision unit -- with wave 0, whose pivot chain is what the
             // whole tile waits for (fp64 vector chains run up to three times slower beside fp64 MFMAs: DESIGN.md section 4a);
@@ -446,6 +486,7 @@ __device__ __forceinline__ void potrf_tile_body(double *A, size_t lda, int c0, d
             }
         }
         __syncthreads();
+        if (late && jb == 0 && tid == 448) __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (INV) {
         // the last column block (j = 7): its diagonal block was factored in the loop's last S phase; one strip per wave
@@ -601,10 +642,208 @@ struct EngineArgs {
                              // tile t factored, out[t] raised, in[t+1] seen, xr[t] raised, tile t+1 updated, factored, out[t+1] raised
     const struct DagArgs *chain; // DAG schedule, chain layout (round 5): device copy of the launch's task words -- the workgroups
     int nhelp;                   // 8, 16, ... 8 nhelp of this launch are CHAIN HELPERS (chain_helper_loop); null / 0: none
+    double *mbox;                // pair mode: mailboxes of the first tiles, 44 x 256 doubles per block, filled with ~0 (potrf_tile_body)
+    int partner;                 // pair mode: index of the PAIR PARTNER's workgroup in this launch (engine_partner_loop); 0: none
 };
 
 struct DagArgs;
 __device__ __forceinline__ void chain_helper_loop(const DagArgs *ap);
+
+// The pair partner (round 5, COCONS_ENGINE_PAIR): a second workgroup of the engine's launch, on a CU of its own, that takes the
+// SECOND tile of every diagonal block -- and everything between the two tiles -- off the engine's hands, and does the part that
+// depends on the first tile's factor WHILE that factor is being formed.  Until now a block was four passes of one workgroup,
+// one behind the other: tile t (25 us) | X = A(t+1,t) L(t)^-T (15) | A(t+1,t+1) -= X X^T (11.5) | tile t+1 (25).  But column block
+// j of X needs nothing of L(t) beyond ITS column block j, and the update of tile t+1 with column block j of X nothing beyond that:
+// the partner holds its strip of A(t+1,t) and its blocks of A(t+1,t+1) in registers, follows the engine's progress word
+// (potrf_tile_body: prog) column block by column block -- fetch L(j..7, j) and its Q operands into LDS, solve, exchange X(., j)
+// through LDS, update -- and is a few microseconds behind the engine when tile t is done; it then factors tile t+1 straight from
+// the image it holds (no trip through memory), while the engine is free for tile t+2.  Same operations on the same operands in
+// the same order as the one-workgroup form: the factor is bit-identical.
+// LDS of the partner: [0, 36) the image of tile t+1 (while it is factored) | QS | QALL | [45, 63) two stages for a column block of L(t)
+// and its Q operands | [63, 71) X(., j) -- both inside the region potrf_tile_body uses for the inverse's strips afterwards.
+template <bool DAG>
+__device__ __forceinline__ void engine_partner_loop(const EngineArgs &e, double *smem)
+{
+    double *QALL = smem + 37 * 256;
+    double *XI = smem + 45 * 256;
+    double *LST = smem + 45 * 256;                 // two stages of 9 blocks
+    double *XJ = smem + 63 * 256;
+    int *okp = (int *)(smem + 73 * 256);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *A = e.A;
+    const size_t lda = e.lda;
+    if (tid == 0) {
+        __hip_atomic_fetch_add(e.alive + 16 + ((hw_where() >> 28) & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(e.alive + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int t = e.t0; t + 1 < e.nt; t += 2) {
+        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t, HOST_PACED_TICKS) ? 1 : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (*okp == 0) return;
+        __syncthreads();
+        unsigned long long *tr = (DAG && e.trace) ? e.trace + 8 * (size_t)(t >> 1) : nullptr;
+        if (tr && tid == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
+        const bool dag_blk = DAG && t < e.dag_until;
+        const int c0 = t * TILE, c1 = (t + 1) * TILE;
+        // this wave's 16 x 128 strip of A(t+1,t) and its 4 or 5 lower blocks of A(t+1,t+1)  (addresses: see the strip solve below)
+        const double *Sb = A + (size_t)(c1 + 16 * wave) + (size_t)c0 * lda;
+        const unsigned ldab = 8u * (unsigned)lda;
+        unsigned lo = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldab;
+        asm volatile("" : "+v"(lo));
+        d4 B[8], C[5];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                B[j][r] = load_wt((const double *)((const char *)Sb + (lo + (unsigned)(16 * j + 4 * r) * ldab)));
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int bb = wave + 8 * i;
+            C[i] = (d4){0.0, 0.0, 0.0, 0.0};
+            if (bb < 36) {
+                const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+                C[i] = glb_blk_wt(A, lda, c1 + 16 * ib, c1 + 16 * kb, lane);
+            }
+        }
+        // Column block j of L(t) -- blocks (j .. 7, j), then its Q operands: (9 - j) x 256 values, contiguous in the tile's mailbox --
+        // travels mailbox -> registers -> LDS stage (two stages, in turn).  A fetch is complete when none of its words is the
+        // mailbox's fill pattern any more (potrf_tile_body: mbox); every wave looks at its own words and fetches again until
+        // then (bounded like every wait), the barrier behind the stage's stores makes it the workgroup's.  The fetch of column block
+        // j + 1 is issued BEFORE the tile update with column block j: while this workgroup lags behind the engine it comes back
+        // complete, and a column block costs max(fetch, solve + update); once it has caught up, one round trip behind the
+        // engine's stores.  (The first version waited for a progress word, then fetched, solved and updated one after the
+        // other: 6.4 us per column block against the engine's 3 .. 4, and 19 us behind it at the end; with the fetch ahead of the
+        // update, but still behind a drained flag: 12 us behind.)
+        const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
+        const double *mb = e.mbox + (size_t)(t >> 1) * (44 * 256);
+        double v[5];
+#define PARTNER_FETCH(jn)                                                                                                        \
+        {                                                                                                                        \
+            unsigned mo = 8u * (unsigned)tid;                                                                                    \
+            asm volatile("" : "+v"(mo));                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                                      \
+                v[i] = 0.0;                                                                                                      \
+                if (half + 2 * i <= 8 - (jn))                                                                                    \
+                    v[i] = load_wt((const double *)((const char *)(mb + MBOX_OFF(jn)) + (mo + 4096u * (unsigned)i)));            \
+            }                                                                                                                    \
+        }
+#define PARTNER_COMPLETE(jn)                                                                                                     \
+        for (unsigned it = 0;; ++it) {                                                                                           \
+            bool missing = false;                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                                        \
+                if (half + 2 * i <= 8 - (jn)) missing = missing || __double_as_longlong(v[i]) == -1ll;                           \
+            if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;                                                             \
+            const bool late_ = it > (unsigned)(ENGINE_TIMEOUT_TICKS / 100ull);                                                   \
+            if (late_ || ((it & 7u) == 7u && __hip_atomic_load(e.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { \
+                if (lane == 0) {                                                                                                 \
+                    if (late_) __hip_atomic_store(e.abort_word, 0x700u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                    *okp = 0;                                                                                                    \
+                }                                                                                                                \
+                break;                                                                                                           \
+            }                                                                                                                    \
+            __builtin_amdgcn_s_sleep(2);                                                                                         \
+            if ((it & 7u) == 7u) {      /* (a reader's own refill can leave it a stale line: poll_word -- a read-modify-write cannot) */ \
+                unsigned mo = 8u * (unsigned)tid;                                                                                \
+                asm volatile("" : "+v"(mo));                                                                                    \
+                _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                                    \
+                    if (half + 2 * i <= 8 - (jn) && __double_as_longlong(v[i]) == -1ll)                                          \
+                        v[i] = __longlong_as_double((long long)__hip_atomic_fetch_or(                                            \
+                            (unsigned long long *)((char *)const_cast<double *>(mb + MBOX_OFF(jn)) + (mo + 4096u * (unsigned)i)), 0ull, \
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));                                                        \
+            } else                                                                                                               \
+                PARTNER_FETCH(jn)                                                                                                \
+        }
+        PARTNER_FETCH(0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double *LS = LST + (j & 1) * (9 * 256);
+            PARTNER_COMPLETE(j)
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                if (half + 2 * i <= 8 - j) LS[tid + 512 * i] = v[i];
+            __syncthreads();
+            if (*okp == 0) return;
+            int ln = lane;               // (LDS addresses are formed here, per column block: hoisted out of the loops they spill)
+            asm volatile("" : "+v"(ln));
+            {
+                d4 L = lds_blk(LS, ln);
+                double Q[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Q[s] = LS[(8 - j) * 256 + s * 64 + ln];
+                trsm16(B[j], L, Q);
+                lds_blk_store(XJ + wave * 256, ln, B[j]);
+                d4 NX = -B[j];
+#pragma unroll
+                for (int jj = j + 1; jj < 8; ++jj) {
+                    d4 Lb = lds_blk(LS + (jj - j) * 256, ln);
+                    blk_mma(B[jj], NX, Lb);
+                }
+            }
+            __syncthreads();
+            if (j < 7) PARTNER_FETCH(j + 1)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int bb = wave + 8 * i;
+                if (bb < 36) {
+                    const int ib = c_tri_ib[bb], kb = bb - ib * (ib + 1) / 2;
+                    d4 P = lds_blk(XJ + ib * 256, ln);
+                    d4 Qk = lds_blk(XJ + kb * 256, ln);
+                    P = -P;
+                    blk_mma(C[i], P, Qk);
+                }
+            }
+        }
+#undef PARTNER_FETCH
+#undef PARTNER_COMPLETE
+        // X to memory (both buffers under the dependency-driven schedule), the updated tile into the image it is factored from
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                store_wt((double *)((char *)const_cast<double *>(Sb) + (lo + (unsigned)(16 * j + 4 * r) * ldab)), B[j][r]);
+        if (dag_blk) {
+            double *Pb = e.pbuf + (size_t)(c1 + 16 * wave) + (size_t)c0 * lda;
+            asm volatile("" : "+v"(lo));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    store_wt((double *)((char *)Pb + (lo + (unsigned)(16 * j + 4 * r) * ldab)), B[j][r]);
+        }
+        int ln2 = lane, tl = tid;
+        asm volatile("" : "+v"(ln2), "+v"(tl));
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int bb = wave + 8 * i;
+            if (bb < 36) lds_blk_store(smem + bb * 256, ln2, C[i]);
+        }
+        __syncthreads();
+        // (the diagonal blocks symmetric, like potrf_tile_body's fetch leaves them: upper half mirrored from the lower)
+        {
+            const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
+            const int k = (tl >> 4) & 15, r = tl & 15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = half + 2 * i;
+                double *blk = smem + (d * (d + 1) / 2 + d) * 256;
+                if (r < k) blk[k * 16 + r] = blk[r * 16 + k];
+            }
+        }
+        __syncthreads();
+        // (xr[t] is raised from inside the tile factorisation, once the copies of X have drained: nothing on the chain needs them)
+        if (tr && tid == 0) { tr[4] = __builtin_amdgcn_s_memrealtime(); tr[5] = tr[4]; }
+        potrf_tile_body<true, true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, dag_blk ? QALL : nullptr,
+                                    dag_blk ? e.wbuf + (size_t)(t + 1) * TILE * TILE : nullptr, XI, nullptr, e.xr + t);
+        if (tr && tid == 0) tr[6] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) signal_add(e.out + t + 1);
+        if (tr && tid == 0) tr[7] = __builtin_amdgcn_s_memrealtime();
+    }
+}
 
 // DAG: the instantiation for the dependency-driven schedule (dag_kernel): tile inverses and the second copy of X.  The
 // classic instantiation does not contain those paths at all (they would cost it registers).
@@ -621,13 +860,16 @@ potrf_engine_kernel(EngineArgs e)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *A = e.A;
     const size_t lda = e.lda;
-    if (DAG && blockIdx.x != 0) {
+    if (blockIdx.x != 0) {
         // Chain helpers (round 5): workgroups 8, 16, ... of this launch -- the ones the dispatcher deals to the same XCD as
         // workgroup 0 (round robin over the eight XCDs; affinity only: chain_helper_loop registers where it really runs) -- each
-        // on a CU of its own like the engine (the launch's LDS request keeps everything else off it).  The others leave at once.
-        if (e.chain && (blockIdx.x & 7u) == 0u && (int)(blockIdx.x >> 3) <= e.nhelp) chain_helper_loop(e.chain);
+        // on a CU of its own like the engine (the launch's LDS request keeps everything else off it); behind them the pair
+        // partner.  The others leave at once.
+        if (e.partner != 0 && (int)blockIdx.x == e.partner) engine_partner_loop<DAG>(e, smem);
+        else if (DAG && e.chain && (blockIdx.x & 7u) == 0u && (int)(blockIdx.x >> 3) <= e.nhelp) chain_helper_loop(e.chain);
         return;
     }
+    const bool pair = e.partner != 0;
     // (the word also says WHERE: 1 + the id of the XCD the workgroup runs on; word 16 + XCD counts the engine's and the chain
     // helpers' workgroups per XCD -- dag_kernel keeps those XCDs less than full)
     if (tid == 0) {
@@ -651,7 +893,8 @@ potrf_engine_kernel(EngineArgs e)
         const bool dag_blk = DAG && t < e.dag_until;
         // (DAG blocks: W = L^-1 of the tile comes out of the factorisation itself, complete before out[t])
         potrf_tile_body<true>(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem, QALL,
-                              dag_blk ? e.wbuf + (size_t)t * TILE * TILE : nullptr, XI);
+                              dag_blk ? e.wbuf + (size_t)t * TILE * TILE : nullptr, XI,
+                              pair ? e.mbox + (size_t)(t >> 1) * (44 * 256) : nullptr);
         __syncthreads();
         if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -659,6 +902,7 @@ potrf_engine_kernel(EngineArgs e)
         if (tid == 0) signal_add(e.out + t);
         if (tr && tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
         if (t + 1 >= e.nt) return;
+        if (pair) continue;              // (the rest of the block is the partner's)
 
         if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t, HOST_PACED_TICKS) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2012,7 +2256,8 @@ void launch_chain_args(void *dev, double *A, size_t lda, double *P, const double
 
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
-                         double *wbuf, double *pbuf, int dag_until, unsigned long long *trace, const void *chain, int nhelp)
+                         double *wbuf, double *pbuf, int dag_until, unsigned long long *trace, const void *chain, int nhelp,
+                         double *mbox)
 {
     EngineArgs e;
     e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
@@ -2020,16 +2265,20 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
     e.wbuf = wbuf; e.pbuf = pbuf; e.dag_until = dag_until; e.trace = trace;
     e.chain = (chain && nhelp > 0) ? (const DagArgs *)chain : nullptr;
     e.nhelp = e.chain ? nhelp : 0;
+    // (mbox: pair mode -- the partner is the workgroup behind the helpers' on workgroup 0's XCD: 8 (nhelp + 1))
+    e.mbox = mbox;
+    e.partner = mbox ? 8 * (e.nhelp + 1) : 0;
+    const int grid = e.partner ? e.partner + 1 : (e.nhelp > 0 ? 8 * e.nhelp + 1 : 1);
     const size_t shm = engine_lds_bytes();
     if (wbuf && pbuf) {
         static std::atomic<unsigned long long> attr_done{0};
         set_dynamic_lds_once((const void *)potrf_engine_kernel<true>, shm, attr_done);
         // (with helpers: workgroups 0, 8, 16, ... 8 nhelp do something -- the ones dealt to workgroup 0's XCD -- the rest leave)
-        hipLaunchKernelGGL(potrf_engine_kernel<true>, dim3(e.nhelp > 0 ? 8 * e.nhelp + 1 : 1), dim3(512), shm, s, e);
+        hipLaunchKernelGGL(potrf_engine_kernel<true>, dim3(grid), dim3(512), shm, s, e);
     } else {
         static std::atomic<unsigned long long> attr_done{0};
         set_dynamic_lds_once((const void *)potrf_engine_kernel<false>, shm, attr_done);
-        hipLaunchKernelGGL(potrf_engine_kernel<false>, dim3(1), dim3(512), shm, s, e);
+        hipLaunchKernelGGL(potrf_engine_kernel<false>, dim3(grid), dim3(512), shm, s, e);
     }
 }
 

@@ -129,8 +129,12 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
                          double *wbuf = nullptr, double *pbuf = nullptr, int dag_until = 0,
                          unsigned long long *trace = nullptr,
-                         const void *chain = nullptr, int nhelp = 0);   // chain helpers of the DAG schedule (chol.hip: chain_helper_loop):
+                         const void *chain = nullptr, int nhelp = 0,    // chain helpers of the DAG schedule (chol.hip: chain_helper_loop):
                                                                          // device copy of the task words (launch_chain_args), workgroups
+                         double *mbox = nullptr);                        // pair mode (engine_partner_loop): mailboxes of the blocks' first
+                                                                         // tiles (ENGINE_MBOX_DOUBLES each, index t / 2), every byte 0xff at
+                                                                         // launch; a second workgroup takes the second tile of every block
+constexpr size_t ENGINE_MBOX_DOUBLES = 44 * 256;
 // nhelp > 0: also waits until that many chain helpers of the engine's launch are resident
 void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false, bool patient = false, int nhelp = 0);
 void launch_raise_word(unsigned *word, hipStream_t s);      // *word = 1 (agent scope) by a one-lane kernel: "everything in front of me on this stream is done"

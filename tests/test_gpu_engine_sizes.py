@@ -295,3 +295,35 @@ def test_repeated_evaluations_are_bit_identical():
         assert fit.neg2loglik_core(th2)[0] == b0
         assert np.array_equal(fit.predict_core(th, lp, Xp)[0], p0)
     assert a0 != b0
+
+
+@pytest.mark.parametrize("gx,gy", [(28, 25), (45, 47), (64, 64), (72, 64)])
+def test_engine_pair_same_bits_as_one_workgroup(gx, gy):
+    """The engine as a PAIR of workgroups (COCONS_ENGINE_PAIR, round 5: the second one follows the first tile's factorisation
+    column block by column block and factors the second tile, chol.hip engine_partner_loop) performs the same operations on
+    the same operands in the same order as the one-workgroup engine: -2 loglik and the reduction outputs are BIT-identical; sizes with a last block of one tile, right-hand sides in slots and under the
+    matrix, two realisations."""
+    import cocons_amd as ca
+    from cocons_amd import _lib, workloads as wl
+    if ENGINE_OFF:
+        pytest.skip("COCONS_ENGINE=0")
+    L = _lib.load()
+    locs, sc = _grid(gx, gy)
+    n = locs.shape[0]
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.1, -0.2, 0.05])
+    rng = np.random.default_rng(n + 1)
+    z = rng.standard_normal((n, 2)) + (X @ np.array([0.2, 0.3, -0.1]))[:, None]
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    try:
+        _lib.check(L.cocons_debug_tune(b"engine_pair", 1), "tune")
+        v1, p1 = fit.neg2loglik_core(th)
+        v1b = fit.neg2loglik_core(th)[0]
+        assert fit.engine_state()["active"]
+        _lib.check(L.cocons_debug_tune(b"engine_pair", 0), "tune")
+        v0, p0 = fit.neg2loglik_core(th)
+        assert fit.engine_state()["active"]
+        assert v1 == v0 and v1b == v1 and np.array_equal(p1, p0)
+    finally:
+        _lib.check(L.cocons_debug_tune(b"engine_pair", int(os.environ.get("COCONS_ENGINE_PAIR", "1"))), "tune")
