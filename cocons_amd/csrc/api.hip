@@ -985,6 +985,8 @@ struct Tunables {
     int engine_pair = 1;     // COCONS_ENGINE_PAIR: 1 = the engine is a PAIR of workgroups -- the second one follows the first tile's
                              // factorisation column block by column block (strip solve, tile update) and factors the second tile
                              // (chol.hip: engine_partner_loop); 0 = one workgroup does the four passes one behind the other
+    int panel_fused = 1;     // COCONS_PANEL_FUSED: 1 = the panel of a two-tile block of the engine schedule is ONE launch (chol.hip:
+                             // panel_pair_kernel); 0 = solve | in-panel update | solve, three launches
     int dag_trace = 0;       // (diagnostics) time stamps per task, cocons_debug_dag_trace
     int gate_sabotage = 0;   // (tests) the next N engine-schedule factorisations wait at the gate for a word nobody raises:
                              // a genuine 5 ms time-out, abort code 0x600, to exercise the fall-back and its book-keeping
@@ -1007,6 +1009,7 @@ static Tunables &tun()
         rd("COCONS_DAG_CHAIN", t.dag_chain);
         rd("COCONS_DAG_HELPERS", t.dag_helpers);
         rd("COCONS_ENGINE_PAIR", t.engine_pair);
+        rd("COCONS_PANEL_FUSED", t.panel_fused);
         if (t.dag_helpers < 1) t.dag_helpers = 1;
         if (t.dag_helpers > 24) t.dag_helpers = 24;
         t.init = true;
@@ -1032,6 +1035,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "dag_chain") t.dag_chain = value;
     else if (k == "dag_helpers") t.dag_helpers = value < 1 ? 1 : (value > 24 ? 24 : value);
     else if (k == "engine_pair") t.engine_pair = value;
+    else if (k == "panel_fused") t.panel_fused = value;
     else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
@@ -1126,6 +1130,22 @@ static int flags_reset(cocons_fit *f, int nt)
         HIPCHK(hipMalloc(&f->dflags, (4 * (size_t)f->flags_cap + 64) * sizeof(unsigned)));
     }
     HIPCHK(hipMemsetAsync(f->dflags, 0, (4 * (size_t)f->flags_cap + 64) * sizeof(unsigned), f->stream));
+    return 0;
+}
+
+// the mailboxes of the engine's pair mode -- one per diagonal block, for its first tile -- filled with the pattern that means
+// "not written yet" (every byte 0xff; potrf_tile_body: mbox) on the main stream: 88 KB per block, 3.6 MB at n = 10^4
+static int mbox_reset(cocons_fit *f, int nt)
+{
+    const size_t need = ((size_t)nt / 2 + 2) * ENGINE_MBOX_DOUBLES;
+    if (f->dmbox_elems < need) {
+        HIPCHK(hipStreamSynchronize(f->stream));
+        if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
+        if (f->dmbox) { HIPCHK(hipFree(f->dmbox)); f->dmbox = nullptr; f->dmbox_elems = 0; }
+        HIPCHK(hipMalloc(&f->dmbox, need * sizeof(double)));
+        f->dmbox_elems = need;
+    }
+    HIPCHK(hipMemsetAsync(f->dmbox, 0xff, need * sizeof(double), f->stream));
     return 0;
 }
 
@@ -1365,18 +1385,8 @@ static int engine_start(cocons_fit *f, const FactorView &v)
         if (f->dag_nsteps < 2) f->dag_next = false;          // too small a problem for a head worth the launch: classic throughout
     }
     f->engine_pair_live = tun().engine_pair != 0 ? 1 : 0;
-    if (f->engine_pair_live) {
-        // the mailboxes of the blocks' first tiles, every byte 0xff (potrf_tile_body: mbox): 88 KB per block, 3.6 MB at n = 10^4
-        const size_t need = ((size_t)nt / 2 + 2) * ENGINE_MBOX_DOUBLES;
-        if (f->dmbox_elems < need) {
-            HIPCHK(hipStreamSynchronize(M));
-            if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
-            if (f->dmbox) { HIPCHK(hipFree(f->dmbox)); f->dmbox = nullptr; f->dmbox_elems = 0; }
-            HIPCHK(hipMalloc(&f->dmbox, need * sizeof(double)));
-            f->dmbox_elems = need;
-        }
-        HIPCHK(hipMemsetAsync(f->dmbox, 0xff, ((size_t)nt / 2 + 2) * ENGINE_MBOX_DOUBLES * sizeof(double), M));
-    }
+    if (f->engine_pair_live)
+        if (int rc = mbox_reset(f, nt)) return rc;
     HIPCHK(hipEventRecord(f->ev_eng, M));                    // (behind the resets of the flag and task words, and of W / P when new)
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
     unsigned *alive_w = f->dflags + 3 * (size_t)f->flags_cap;
@@ -1512,6 +1522,11 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         if (k >= k_first) {                          // (the update with the last DAG step's panel was that launch's)
             if (ev_upd) count_update_flops(f, 2, t);
             timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k));
+        }
+        if (two && hb < 0 && tun().panel_fused) {
+            launch_panel_pair(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048,
+                              f->dinv + (size_t)((t + 1) & 1) * 2048, out + t, xr + t, out + t + 1, abort_word, M);
+            continue;
         }
         launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048, M,
                          out + t, abort_word, br, er);
@@ -2843,8 +2858,11 @@ static int shard_begin(cocons_fit *f, const double *theta, const double *mean, i
     if (f->r < 1) return fail(-1, "sharded evaluation: fit has no z");
     if (int rc = shard_prepare(f, rank, world)) return rc;
     if (int rc = reset_info(f)) return rc;
-    if (engine_enabled())
+    if (engine_enabled()) {
         if (int rc = flags_reset(f, f->nt)) return rc;     // (the words shard_factor_diag's engine launches read and raise)
+        if (tun().engine_pair)
+            if (int rc = mbox_reset(f, f->nt)) return rc;  // (... and the mailboxes of their pair mode)
+    }
     ThetaVecs tv;
     make_theta_vecs(theta, f->p, tv);
     ModeSel ms = select_mode(theta, f->p, f->smooth_limits, 0);
@@ -2884,8 +2902,12 @@ static int shard_factor_diag(cocons_fit *f, int k)
         // input words are raised beforehand, so it never waits, and it leaves behind the block of its second tile
         unsigned *in = f->dflags, *out = f->dflags + f->flags_cap, *xr = f->dflags + 2 * (size_t)f->flags_cap;
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(in + t), 7, (size_t)w, s));
+        // (pair mode: its two workgroups side by side -- the second tile's factorisation starts ~6 us behind the first's end
+        // instead of behind the strip solve and the tile update: 78 -> ~56 us for the block)
+        const bool pair = w == 2 && tun().engine_pair && f->dmbox && f->dmbox_elems >= ((size_t)f->nt / 2 + 2) * ENGINE_MBOX_DOUBLES;
         launch_potrf_engine(A, f->lda, t, t + w, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
-                            f->dflags + 3 * (size_t)f->flags_cap, s);
+                            f->dflags + 3 * (size_t)f->flags_cap, s, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                            pair ? f->dmbox : nullptr);
     } else {
         launch_potrf_tile(A, f->lda, t * TILE, q0, f->dinfo, s);
         if (w == 2) {

@@ -1011,6 +1011,30 @@ engine_gate_kernel(unsigned *alive, unsigned *abort_word, unsigned code, unsigne
         (void)wait_ge<false>(alive + 2, nhelp, abort_word, code + 1u, ticks);
 }
 
+// The 36 lower blocks of the factored diagonal tile at (c0, c0) and its Q operands into LDS (256 threads): EVERY global load is
+// issued before the first LDS store -- one round trip.  (Until round 5 the panel kernels fetched block by block, a load and a
+// store at a time: 36 dependent round trips, ~10 of the 14.6 us a panel solve took whatever its number of rows; the kernel
+// trace of the tail at n = 4096, tools/r5_tail_timeline.sh.)
+__device__ __forceinline__ void fetch_factor_tile(const double *A, size_t lda, int c0, const double *qin, double *SL, double *QS, int tid)
+{
+    const int i = tid & 15, k = tid >> 4;
+    const double *src = A + (size_t)(c0 + i) + (size_t)(c0 + k) * lda;
+    double v[36], q[8];
+    {
+        int b = 0;
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib)
+#pragma unroll
+            for (int kb = 0; kb <= ib; ++kb, ++b) v[b] = src[(size_t)(16 * ib) + (size_t)(16 * kb) * lda];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = qin[tid + 256 * e];
+#pragma unroll
+    for (int b = 0; b < 36; ++b) SL[b * 256 + k * 16 + i] = v[b];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) QS[tid + 256 * e] = q[e];
+}
+
 // ---------------------------------------------------------------------------
 // Panel solve: rows [r0, r1) of block column c0:  X <- X * L(c0)^-T.
 // One workgroup = 64 rows; each wave owns a 16 x 128 strip held in registers (8 blocks).
@@ -1033,13 +1057,7 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsig
         __syncthreads();
         if (!ok) return;
     }
-    {
-        int i = tid & 15, k = tid >> 4, b = 0;
-        for (int ib = 0; ib < 8; ++ib)
-            for (int kb = 0; kb <= ib; ++kb, ++b)
-                SL[b * 256 + k * 16 + i] = A[(size_t)(c0 + 16 * ib + i) + (size_t)(c0 + 16 * kb + k) * lda];
-        for (int e = tid; e < 8 * 256; e += 256) QS[e] = qin[e];
-    }
+    fetch_factor_tile(A, lda, c0, qin, SL, QS, tid);
     // rows: workgroups 0 .. nb1-1 cover [r0, r0 + 64 nb1), the others a second range from e0 (the right-hand-side rows
     // under a band-limited factorisation; nb1 = all of them otherwise)
     const int bx = blockIdx.x;
@@ -1064,6 +1082,115 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsig
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c0 + 16 * j, lane, B[j]);
+}
+
+// ---------------------------------------------------------------------------
+// Panel of a two-tile block in ONE launch (engine schedule, round 5): for the rows below the diagonal block
+//     X0 = B0 L(t)^-T  |  B1 -= X0 X(t+1,t)^T  |  X1 = B1 L(t+1)^-T
+// -- until now three launches (trsm_tile_kernel, the in-panel update_kernel, trsm_tile_kernel), each of which read its strip
+// from memory and wrote it back, the second and third behind a drained chip.  A workgroup owns 64 rows (a wave 16) for the whole
+// sequence: both 16 x 128 strips stay in registers, the three waits -- out[t], xr[t], out[t+1] -- are met where the data is needed,
+// and the rows are done ~8 us after the engine's second tile instead of ~16 + a boundary.  Same operations on the same operands
+// in the same order as the three kernels (the product accumulated from zero over ascending k and subtracted once, as
+// update_kernel does): bit-identical.
+__global__ void __launch_bounds__(256)
+panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const double *q1, unsigned *out0, unsigned *xrw,
+                  unsigned *out1, unsigned *abort_word)
+{
+    // 136 KB: L of the current tile (36 blocks) and its Q operands (8) -- or, between the two solves, all 64 blocks of X(t+1,t)
+    __shared__ double SM[68 * 256];
+    __shared__ int ok;
+    double *SL = SM, *QS = SM + 36 * 256, *XS = SM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c1 = c0 + TILE;
+    const int rs = r0 + 64 * (int)blockIdx.x + 16 * wave;
+    d4 B0[8], B1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) B0[j] = glb_blk(A, lda, rs, c0 + 16 * j, lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) B1[j] = glb_blk(A, lda, rs, c1 + 16 * j, lane);
+    // ---- X0 = B0 L(t)^-T
+    if (tid == 0) ok = wait_ge(out0, 1u, abort_word, 0x300u + c0 / TILE) ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!ok) return;
+    fetch_factor_tile(A, lda, c0, q0, SL, QS, tid);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        d4 L = lds_blk(SL + (j * (j + 1) / 2 + j) * 256, lane);
+        double Q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Q[s] = QS[j * 256 + s * 64 + lane];
+        trsm16(B0[j], L, Q);
+        d4 NX = -B0[j];
+#pragma unroll
+        for (int jj = j + 1; jj < 8; ++jj) {
+            d4 Lb = lds_blk(SL + (jj * (jj + 1) / 2 + j) * 256, lane);
+            blk_mma(B0[jj], NX, Lb);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c0 + 16 * j, lane, B0[j]);
+    // ---- B1 -= X0 X(t+1,t)^T: all 64 blocks of X(t+1,t) into LDS (over the image of L(t), which is dead), four rounds of sixteen
+    // loads per thread with the next round in flight while one is stored
+    if (tid == 0) ok = wait_ge(xrw, 1u, abort_word, 0x500u + c0 / TILE) ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                 // (also: every wave is done with L(t))
+    if (!ok) return;
+    {
+        const int i = tid & 15, k = tid >> 4;
+        const double *Xg = A + (size_t)(c1 + i) + (size_t)(c0 + k) * lda;      // block (jj, kb) at + 16 jj + 16 kb lda
+        double st[2][16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) st[0][b] = Xg[(size_t)(16 * (b >> 3)) + (size_t)(16 * (b & 7)) * lda];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r + 1 < 4) {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int bb = 16 * (r + 1) + b;
+                    st[(r + 1) & 1][b] = Xg[(size_t)(16 * (bb >> 3)) + (size_t)(16 * (bb & 7)) * lda];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 16; ++b) XS[(16 * r + b) * 256 + k * 16 + i] = st[r & 1][b];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                d4 Xb = lds_blk(XS + (jj * 8 + kb) * 256, lane);
+                blk_mma(acc, B0[kb], Xb);
+            }
+            B1[jj] = B1[jj] - acc;
+        }
+    }
+    // ---- X1 = B1 L(t+1)^-T
+    if (tid == 0) ok = wait_ge(out1, 1u, abort_word, 0x300u + c1 / TILE) ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                 // (also: every wave is done with X(t+1,t))
+    if (!ok) return;
+    fetch_factor_tile(A, lda, c1, q1, SL, QS, tid);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        d4 L = lds_blk(SL + (j * (j + 1) / 2 + j) * 256, lane);
+        double Q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Q[s] = QS[j * 256 + s * 64 + lane];
+        trsm16(B1[j], L, Q);
+        d4 NX = -B1[j];
+#pragma unroll
+        for (int jj = j + 1; jj < 8; ++jj) {
+            d4 Lb = lds_blk(SL + (jj * (jj + 1) / 2 + j) * 256, lane);
+            blk_mma(B1[jj], NX, Lb);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c1 + 16 * j, lane, B1[j]);
 }
 
 // ---------------------------------------------------------------------------
@@ -2293,6 +2420,14 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
     if (nb1 + nb2 <= 0) return;
     hipLaunchKernelGGL(trsm_tile_kernel, dim3(nb1 + nb2), dim3(256), 0, s, A, lda, c0, r0, dinv, wait_word, abort_word,
                        nb1, ext_r0, own_world, own_rank, own_group < 1 ? 1 : own_group);
+}
+
+void launch_panel_pair(double *A, size_t lda, int c0, int r0, int r1, const double *q0, const double *q1, unsigned *out0,
+                       unsigned *xr, unsigned *out1, unsigned *abort_word, hipStream_t s)
+{
+    const int nb = (r1 - r0) / 64;
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(panel_pair_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, q0, q1, out0, xr, out1, abort_word);
 }
 
 // waves per workgroup of the trailing update (COCONS_UPD_WAVES: 4 or 8, see update_kernel's NW)

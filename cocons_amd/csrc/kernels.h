@@ -148,6 +148,11 @@ int streams_run_concurrently(hipStream_t first, hipStream_t second, unsigned *wo
 void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const double *dinv, hipStream_t s,
                       unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, int band_r1 = -1, int ext_r0 = 0,
                       int own_world = 0, int own_rank = 0, int own_group = 1);
+// The panel of a two-tile block of the engine schedule in one launch: rows [r0, r1) of the tile columns at c0 and c0 + 128,
+// X0 = B0 L(c0)^-T | B1 -= X0 X(t+1,t)^T | X1 = B1 L(c0+128)^-T, waiting for out0 / xr / out1 where each is needed (dense, unsharded;
+// q0, q1: the Q operands of the two diagonal tiles).  Bit-identical to launch_trsm_tile | launch_update (K = 128) | launch_trsm_tile.
+void launch_panel_pair(double *A, size_t lda, int c0, int r0, int r1, const double *q0, const double *q1, unsigned *out0,
+                       unsigned *xr, unsigned *out1, unsigned *abort_word, hipStream_t s);
 // C(i,j) -= sum_{k in [k0,k0+K)} A(i,k) A(j,k) for tiles with tile-row in [ti0,ti1),
 // tile-col in [tj0,tj1); lower_only keeps ti >= tj.  All tile indices in units of TILE.
 // sig / sig_tile: hand-off to the engine (sig = the in[] array, sig_tile = even tile of the diagonal block);

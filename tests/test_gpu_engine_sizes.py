@@ -327,3 +327,32 @@ def test_engine_pair_same_bits_as_one_workgroup(gx, gy):
         assert v1 == v0 and v1b == v1 and np.array_equal(p1, p0)
     finally:
         _lib.check(L.cocons_debug_tune(b"engine_pair", int(os.environ.get("COCONS_ENGINE_PAIR", "1"))), "tune")
+
+
+@pytest.mark.parametrize("gx,gy", [(33, 31), (45, 47), (64, 64), (72, 64)])
+def test_fused_panel_same_bits_as_three_launches(gx, gy):
+    """The panel of a two-tile block in one launch (COCONS_PANEL_FUSED, chol.hip panel_pair_kernel: solve | in-panel update | solve
+    with both strips in registers) against the three launches it replaces: same operations, same order -- identical bits."""
+    import cocons_amd as ca
+    from cocons_amd import _lib, workloads as wl
+    if ENGINE_OFF:
+        pytest.skip("COCONS_ENGINE=0")
+    L = _lib.load()
+    locs, sc = _grid(gx, gy)
+    n = locs.shape[0]
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.1, -0.2, 0.05])
+    rng = np.random.default_rng(n + 2)
+    z = rng.standard_normal((n, 2)) + (X @ np.array([0.2, 0.3, -0.1]))[:, None]
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    try:
+        _lib.check(L.cocons_debug_tune(b"panel_fused", 1), "tune")
+        v1, p1 = fit.neg2loglik_core(th)
+        assert fit.engine_state()["active"]
+        _lib.check(L.cocons_debug_tune(b"panel_fused", 0), "tune")
+        v0, p0 = fit.neg2loglik_core(th)
+        assert fit.engine_state()["active"]
+        assert v1 == v0 and np.array_equal(p1, p0)
+    finally:
+        _lib.check(L.cocons_debug_tune(b"panel_fused", int(os.environ.get("COCONS_PANEL_FUSED", "1"))), "tune")
