@@ -1015,6 +1015,9 @@ engine_gate_kernel(unsigned *alive, unsigned *abort_word, unsigned code, unsigne
 // issued before the first LDS store -- one round trip.  (Until round 5 the panel kernels fetched block by block, a load and a
 // store at a time: 36 dependent round trips, ~10 of the 14.6 us a panel solve took whatever its number of rows; the kernel
 // trace of the tail at n = 4096, tools/r5_tail_timeline.sh.)
+// WT: the tile comes from the engine inside this launch's lifetime (write-through stores there): L1-bypassing loads here, and the
+// wait in front needs no acquire (the hand-off protocol above potrf_engine_kernel; an acquire is ~1.7 us, three per panel launch)
+template <bool WT>
 __device__ __forceinline__ void fetch_factor_tile(const double *A, size_t lda, int c0, const double *qin, double *SL, double *QS, int tid)
 {
     const int i = tid & 15, k = tid >> 4;
@@ -1025,10 +1028,13 @@ __device__ __forceinline__ void fetch_factor_tile(const double *A, size_t lda, i
 #pragma unroll
         for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
-            for (int kb = 0; kb <= ib; ++kb, ++b) v[b] = src[(size_t)(16 * ib) + (size_t)(16 * kb) * lda];
+            for (int kb = 0; kb <= ib; ++kb, ++b) {
+                const double *sp = src + (size_t)(16 * ib) + (size_t)(16 * kb) * lda;
+                v[b] = WT ? load_wt(sp) : *sp;
+            }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) q[e] = qin[tid + 256 * e];
+    for (int e = 0; e < 8; ++e) q[e] = WT ? load_wt(qin + tid + 256 * e) : qin[tid + 256 * e];
 #pragma unroll
     for (int b = 0; b < 36; ++b) SL[b * 256 + k * 16 + i] = v[b];
 #pragma unroll
@@ -1052,12 +1058,13 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsig
         if (((row / (2 * TILE) / own_group) % own_world) != own_rank) return;
     }
     if (wait_word) {     // the diagonal tile comes from the engine, which may still be at work
-        if (tid == 0) ok = wait_ge(wait_word, 1u, abort_word, 0x300u + c0 / TILE) ? 1 : 0;
+        if (tid == 0) ok = wait_ge<false>(wait_word, 1u, abort_word, 0x300u + c0 / TILE) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (!ok) return;
-    }
-    fetch_factor_tile(A, lda, c0, qin, SL, QS, tid);
+        fetch_factor_tile<true>(A, lda, c0, qin, SL, QS, tid);
+    } else
+        fetch_factor_tile<false>(A, lda, c0, qin, SL, QS, tid);
     // rows: workgroups 0 .. nb1-1 cover [r0, r0 + 64 nb1), the others a second range from e0 (the right-hand-side rows
     // under a band-limited factorisation; nb1 = all of them otherwise)
     const int bx = blockIdx.x;
@@ -1110,11 +1117,11 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
 #pragma unroll
     for (int j = 0; j < 8; ++j) B1[j] = glb_blk(A, lda, rs, c1 + 16 * j, lane);
     // ---- X0 = B0 L(t)^-T
-    if (tid == 0) ok = wait_ge(out0, 1u, abort_word, 0x300u + c0 / TILE) ? 1 : 0;
+    if (tid == 0) ok = wait_ge<false>(out0, 1u, abort_word, 0x300u + c0 / TILE) ? 1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!ok) return;
-    fetch_factor_tile(A, lda, c0, q0, SL, QS, tid);
+    fetch_factor_tile<true>(A, lda, c0, q0, SL, QS, tid);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1134,7 +1141,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
     for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c0 + 16 * j, lane, B0[j]);
     // ---- B1 -= X0 X(t+1,t)^T: all 64 blocks of X(t+1,t) into LDS (over the image of L(t), which is dead), four rounds of sixteen
     // loads per thread with the next round in flight while one is stored
-    if (tid == 0) ok = wait_ge(xrw, 1u, abort_word, 0x500u + c0 / TILE) ? 1 : 0;
+    if (tid == 0) ok = wait_ge<false>(xrw, 1u, abort_word, 0x500u + c0 / TILE) ? 1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                 // (also: every wave is done with L(t))
     if (!ok) return;
@@ -1143,14 +1150,14 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
         const double *Xg = A + (size_t)(c1 + i) + (size_t)(c0 + k) * lda;      // block (jj, kb) at + 16 jj + 16 kb lda
         double st[2][16];
 #pragma unroll
-        for (int b = 0; b < 16; ++b) st[0][b] = Xg[(size_t)(16 * (b >> 3)) + (size_t)(16 * (b & 7)) * lda];
+        for (int b = 0; b < 16; ++b) st[0][b] = load_wt(Xg + (size_t)(16 * (b >> 3)) + (size_t)(16 * (b & 7)) * lda);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (r + 1 < 4) {
 #pragma unroll
                 for (int b = 0; b < 16; ++b) {
                     const int bb = 16 * (r + 1) + b;
-                    st[(r + 1) & 1][b] = Xg[(size_t)(16 * (bb >> 3)) + (size_t)(16 * (bb & 7)) * lda];
+                    st[(r + 1) & 1][b] = load_wt(Xg + (size_t)(16 * (bb >> 3)) + (size_t)(16 * (bb & 7)) * lda);
                 }
             }
 #pragma unroll
@@ -1169,11 +1176,11 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
         }
     }
     // ---- X1 = B1 L(t+1)^-T
-    if (tid == 0) ok = wait_ge(out1, 1u, abort_word, 0x300u + c1 / TILE) ? 1 : 0;
+    if (tid == 0) ok = wait_ge<false>(out1, 1u, abort_word, 0x300u + c1 / TILE) ? 1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                 // (also: every wave is done with X(t+1,t))
     if (!ok) return;
-    fetch_factor_tile(A, lda, c1, q1, SL, QS, tid);
+    fetch_factor_tile<true>(A, lda, c1, q1, SL, QS, tid);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

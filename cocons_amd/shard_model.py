@@ -13,9 +13,9 @@ The chain term holds no all-gather because the code issues the broadcast of L_(k
 a stream -- under RCCL also a communicator (ncclCommSplit) -- of its own (round 5; until round 4 it was queued behind the
 all-gather on the one communication stream, so the chain did wait for the bulk exchange and this model was optimistic).
 What forbids more: the chain's solve (three launches of latency-bound kernels, 45 us: a launch over 4 strips takes as long as one
-over 80 -- solving the next diagonal block's 256 rows first would not shorten it) and its diagonal factor (78 us: one launch of
-the engine kernel; the same two tile factorisations that bound the single-GPU tail); at N = 2 the rank term (one link, half the
-updates).
+over 80 -- solving the next diagonal block's 256 rows first would not shorten it) and its diagonal factor (59 us: one launch of
+the engine kernel, a pair of workgroups since round 5; the same two tile factorisations that bound the single-GPU tail); at
+N = 2 the rank term (one link, half the updates).
 """
 from __future__ import annotations
 
@@ -25,9 +25,10 @@ TILE = 128
 T_UNPACK = 5.0            # two device-to-device copies of 0.5 MB + 32 KB
 T_SOLVE = 45.0            # solve | in-panel update | solve over a rank's rows (three launches; strips run side by side)
 T_DIAG_UPDATE = 10.0      # 256 x 256 x 256 update of the next diagonal block (10 tiles)
-T_DIAG_FACTOR = 85.0      # ONE launch of the diagonal-block engine (tile | strip solve | tile update | tile: 78 us measured at
-                          # n = 10^4, profiles/r04_shard_one_rank_kernel_stats.csv) + the fill that raises its input words + one gap
-                          # (until the end of round 4: four launches, potrf 30 | solve 13 | update 10 | potrf 30 + gaps = 100)
+T_DIAG_FACTOR = 66.0      # ONE launch of the diagonal-block engine, its two workgroups side by side (round 5: the second tile's
+                          # factorisation starts ~6 us behind the first's end): 59 us measured at n = 10^4,
+                          # profiles/r05_shard_one_rank_kernel_stats.csv (one workgroup, round 4: 78) + the fill that raises its
+                          # input words + one gap (until the end of round 4: four launches, 30 | 13 | 10 | 30 + gaps = 100)
 T_PACK = 10.0
 T_ASSEMBLY_MS = 0.9       # covariance assembly of the whole lower triangle on one GPU (shards: / N)
 T_UPDATES_MS = 6.4        # all trailing updates of one evaluation on one GPU at n = 10^4 (scaled by (n / 10^4)^3)

@@ -17,7 +17,7 @@ def find(d, name):
 
 for src, dst in (("r5_bench_final.json", "r05_bench_n10000.json"), ("r5_dag_trace_n10000.txt", "r05_dag_trace_n10000.txt"),
                  ("r5_chain_trace_n10000.txt", "r05_chain_trace_n10000.txt"), ("r5_batch_trace_n4096.txt", "r05_batch_trace_n4096.txt"),
-                 ("r5_batch_probe_final.txt", "r05_batch_probe.txt"), ("switch_matrix.txt", "r05_switch_matrix.txt")):
+                 ("r5_batch_probe_final.txt", "r05_batch_probe.txt")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, dst))
         print("copied", dst)
