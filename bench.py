@@ -519,7 +519,7 @@ def main():
                 kernel = ("cocons::dag_kernel (persistent, dependency-driven: the trailing updates of the head of the factorisation "
                           "-- steps of >= %s update tiles, %.0f %% of the update flops -- and the panel tasks between them, "
                           "v_mfma_f64_16x16x4_f64); the remaining %d steps: cocons::update_kernel launches"
-                          % (os.environ.get("COCONS_DAG_MIN_TILES", "3000"), 100.0 * st["dag_flops"] / flops, launches - 1))
+                          % (os.environ.get("COCONS_DAG_MIN_TILES", "2000"), 100.0 * st["dag_flops"] / flops, launches - 1))
                 kflops, kms, klaunches = st["dag_flops"], st["dag_ms"], 1
             else:
                 achieved = flops / (st["update_sum_ms"] * 1e-3) / 1e12

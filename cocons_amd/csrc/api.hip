@@ -971,8 +971,10 @@ struct Tunables {
     // the workgroups that draw them neither wait with a slot in hand nor come late.  One block at 3600 (round 4's first
     // form): -1.4 %; at 2400: -0.9 %; everything between (800 .. 2000, 400 .. 900, 1800 .. 2400) measures alike.
     int dag_lead = 1600, dag_lead2 = 600, dag_lead3 = 1800;
-    int dag_min_tiles = 3000;  // COCONS_DAG_MIN_TILES: the DAG launch covers the leading steps of at least this many update tiles
-                             // (n = 10^4: 21 of the 39 steps, 87 % of the flops; below n ~ 5200 no step at all)
+    int dag_min_tiles = 2000;  // COCONS_DAG_MIN_TILES: the DAG launch covers the leading steps of at least this many update tiles
+                             // (n = 10^4: 24 of the 39 steps, 94 % of the flops; below n ~ 4200 no step at all).  3000 until the
+                             // engine became a pair (round 5): with the shorter chain the break-even moved back, 1400 .. 2200
+                             // measure alike, +0.4 % over 3000)
     int dag_split = 1;       // COCONS_DAG_SPLIT: the diagonal-block tiles of a DAG step in two halves, the first one off the chain
     int dag_xcc_quota = -1;  // workgroups of the DAG launch that take part on the engine's XCD (of the 255 that land there; 0: all;
                              // -1: derived from the device, dag_xcc_quota() -- 208 on MI355X)

@@ -26,7 +26,7 @@ def dag_on():
     _tune("dag_min_tiles", 0)
     yield
     _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
-    _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "3000")))
+    _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "2000")))
 
 
 def _grid(gx, gy):
@@ -127,7 +127,7 @@ def test_dag_changing_parameters_stay_reproducible(dag_on):
     fit.close()
 
 
-@pytest.mark.parametrize("g,min_tiles", [(64, 1000), (100, 3000)])
+@pytest.mark.parametrize("g,min_tiles", [(64, 1000), (100, 2000)])
 def test_dag_head_then_classic(g, min_tiles):
     """The shipped form: the DAG launch for the head of the factorisation (steps of at least `min_tiles` update tiles), the
     classic schedule behind it -- n = 4096 with a three-step head, and the benchmark size with the default threshold -- against
@@ -153,7 +153,7 @@ def test_dag_head_then_classic(g, min_tiles):
         assert es["retries"] == 0 and es["active"]
     finally:
         _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
-        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "3000")))
+        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "2000")))
         fit.close()
 
 
@@ -185,7 +185,7 @@ def test_dag_xcd_quota_changes_nothing_but_who_works():
     finally:
         _tune("dag_xcc_quota", default)
         _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
-        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "3000")))
+        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "2000")))
         fit.close()
 
 
@@ -232,4 +232,4 @@ def test_dag_chain_layout_vs_classic(gx, gy, min_tiles):
         _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
         _tune("dag_chain", int(os.environ.get("COCONS_DAG_CHAIN", "0")))
         _tune("dag_split", int(os.environ.get("COCONS_DAG_SPLIT", "1")))
-        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "3000")))
+        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "2000")))
