@@ -291,7 +291,9 @@ struct cocons_fit {
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
     int dag_helpers_live;         // chain helpers in the engine launch of the factorisation being enqueued (0: none)
     int engine_pair_live;         // 1: the engine launched for the next factorisation has a pair partner (counts itself like a helper)
-    double *dmbox; size_t dmbox_elems;   // the pair mode's mailboxes (engine_start)
+    double *dmbox; size_t dmbox_elems;   // mailboxes (mbox_reset): one per diagonal block for the engine's pair mode, then one per tile
+    size_t mbox_follow0;                 // for potrf_solve's followers (first of those, in doubles)
+    bool follow_used, follow_off;        // the operation being enqueued used launch_potrf_follow; it timed out once on this handle: off
     double enq_host_us; long long enq_calls;      // (diagnostics) host time spent enqueueing evaluations, calls: cocons_debug_host_enqueue
     bool dag_used;                // the factorisation enqueued last ran the DAG schedule: its factor is split over dA and dP
     double dag_flops; int dag_events;   // profile runs: update flops inside the DAG launch; 1 = the first event pair is that launch
@@ -935,8 +937,17 @@ static int band_hi(const FactorView &v, int k)
 // a word the factorising workgroup raises, take L and solve -- was built and measured in round 5: SLOWER, taper path 4.18 -> 4.57
 // ms, batch at n = 4096 1066 -> 1031 evaluations/s: the boundary between the two launches costs less than the write-through
 // factor and the serialised fetch of L behind the word; removed.)
+// (Round 5, later: ONE launch after all -- not behind a word but FOLLOWING the factorisation through the tile's mailbox, the way the
+// engine's partner does: potrf_follow_kernel.  The mailboxes are filled by mbox_reset at the start of the factorisation.)
+static bool follow_on(cocons_fit *f);
 static void potrf_solve(cocons_fit *f, double *A, size_t lda, int tile, int r0, int r1, double *q, hipStream_t s, int br, int er)
 {
+    if (follow_on(f) && f->mbox_follow0 + ((size_t)tile + 1) * ENGINE_MBOX_DOUBLES <= f->dmbox_elems) {
+        f->follow_used = true;
+        launch_potrf_follow(A, lda, tile * TILE, r0, r1, q, f->dinfo,
+                            f->dmbox + f->mbox_follow0 + (size_t)tile * ENGINE_MBOX_DOUBLES, (unsigned *)(f->dinfo + 1), s, br, er);
+        return;
+    }
     launch_potrf_tile(A, lda, tile * TILE, q, f->dinfo, s);
     launch_trsm_tile(A, lda, tile * TILE, r0, r1, q, s, nullptr, nullptr, br, er);
 }
@@ -989,6 +1000,9 @@ struct Tunables {
                              // (chol.hip: engine_partner_loop); 0 = one workgroup does the four passes one behind the other
     int panel_fused = 1;     // COCONS_PANEL_FUSED: 1 = the panel of a two-tile block of the engine schedule is ONE launch (chol.hip:
                              // panel_pair_kernel); 0 = solve | in-panel update | solve, three launches
+    int potrf_follow = 1;    // COCONS_POTRF_FOLLOW: 1 = a tile factorisation and the panel solve below it are ONE launch whose solve
+                             // workgroups follow the factorisation through a mailbox (chol.hip: potrf_follow_kernel; the plain and
+                             // the band-limited schedule); 0 = two launches
     int dag_trace = 0;       // (diagnostics) time stamps per task, cocons_debug_dag_trace
     int gate_sabotage = 0;   // (tests) the next N engine-schedule factorisations wait at the gate for a word nobody raises:
                              // a genuine 5 ms time-out, abort code 0x600, to exercise the fall-back and its book-keeping
@@ -1012,11 +1026,18 @@ static Tunables &tun()
         rd("COCONS_DAG_HELPERS", t.dag_helpers);
         rd("COCONS_ENGINE_PAIR", t.engine_pair);
         rd("COCONS_PANEL_FUSED", t.panel_fused);
+        rd("COCONS_POTRF_FOLLOW", t.potrf_follow);
         if (t.dag_helpers < 1) t.dag_helpers = 1;
         if (t.dag_helpers > 24) t.dag_helpers = 24;
         t.init = true;
     }
     return t;
+}
+
+static bool follow_on(cocons_fit *f)
+{
+    return tun().potrf_follow != 0 && !f->follow_off && f->dmbox != nullptr && f->mbox_follow0 != 0 &&
+           f->dmbox_elems >= f->mbox_follow0 + ((size_t)f->nt + 1) * ENGINE_MBOX_DOUBLES;
 }
 
 extern "C" int cocons_debug_tune(const char *name, int value)
@@ -1038,6 +1059,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "dag_helpers") t.dag_helpers = value < 1 ? 1 : (value > 24 ? 24 : value);
     else if (k == "engine_pair") t.engine_pair = value;
     else if (k == "panel_fused") t.panel_fused = value;
+    else if (k == "potrf_follow") t.potrf_follow = value;
     else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
@@ -1135,11 +1157,13 @@ static int flags_reset(cocons_fit *f, int nt)
     return 0;
 }
 
-// the mailboxes of the engine's pair mode -- one per diagonal block, for its first tile -- filled with the pattern that means
-// "not written yet" (every byte 0xff; potrf_tile_body: mbox) on the main stream: 88 KB per block, 3.6 MB at n = 10^4
+// the mailboxes of the engine's pair mode -- one per diagonal block, for its first tile -- and of potrf_solve's followers -- one per
+// tile -- filled with the pattern that means "not written yet" (every byte 0xff; potrf_tile_body: mbox) on the main stream:
+// 88 KB each, 10.7 MB at n = 10^4
 static int mbox_reset(cocons_fit *f, int nt)
 {
-    const size_t need = ((size_t)nt / 2 + 2) * ENGINE_MBOX_DOUBLES;
+    f->mbox_follow0 = ((size_t)nt / 2 + 2) * ENGINE_MBOX_DOUBLES;
+    const size_t need = f->mbox_follow0 + ((size_t)nt + 1) * ENGINE_MBOX_DOUBLES;
     if (f->dmbox_elems < need) {
         HIPCHK(hipStreamSynchronize(f->stream));
         if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
@@ -1387,8 +1411,8 @@ static int engine_start(cocons_fit *f, const FactorView &v)
         if (f->dag_nsteps < 2) f->dag_next = false;          // too small a problem for a head worth the launch: classic throughout
     }
     f->engine_pair_live = tun().engine_pair != 0 ? 1 : 0;
-    if (f->engine_pair_live)
-        if (int rc = mbox_reset(f, nt)) return rc;
+    if (f->engine_pair_live || (tun().potrf_follow && !f->follow_off))
+        if (int rc = mbox_reset(f, nt > f->nt ? nt : f->nt)) return rc;
     HIPCHK(hipEventRecord(f->ev_eng, M));                    // (behind the resets of the flag and task words, and of W / P when new)
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
     unsigned *alive_w = f->dflags + 3 * (size_t)f->flags_cap;
@@ -1438,10 +1462,13 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     // covariances, right-hand sides, cross-covariance rows -- is replaced by unit vectors, in every view whose first
     // indices are the handle's observations
     launch_front_identity(v.A, v.lda, f->pad0, mt * TILE, M);
+    f->follow_used = false;
     if (!engine_wanted(f, v)) {
         f->engine_used = false;
         f->dag_used = false;
         if (int rc = flags_reset(f, nt)) return rc;
+        if (tun().potrf_follow && !f->follow_off)
+            if (int rc = mbox_reset(f, nt > f->nt ? nt : f->nt)) return rc;
         if (v.hi) {
             // band-limited: one tile column per step (factor, solve, update with K = 128) -- inside a narrow envelope
             // the in-panel update of the two-tile block costs more than the second, cheaper trailing update
@@ -1719,9 +1746,10 @@ static int info_status(cocons_fit *f)
 // engine again.  Every time-out is counted (cocons_fit_engine_state).
 static bool engine_retry(cocons_fit *f, int st)
 {
-    if (st != ENGINE_ABORT || !f->engine_used) return false;
+    if (st != ENGINE_ABORT || !(f->engine_used || f->follow_used)) return false;
     f->engine_retries++;
     f->engine_last_abort = f->hinfo[1];
+    if (!f->engine_used || (f->hinfo[1] & 0xff0) == 0x7f0) f->follow_off = true;      // a follower of potrf_follow_kernel gave up: two launches from now on
     if (f->engine_fails < 6) f->engine_fails++;
     f->engine_skip = 1 << f->engine_fails;
     f->engine_live = false;

@@ -649,6 +649,50 @@ struct EngineArgs {
 struct DagArgs;
 __device__ __forceinline__ void chain_helper_loop(const DagArgs *ap);
 
+// Following a tile's factorisation through its mailbox (potrf_tile_body: mbox), shared by the engine's partner and the followers of
+// potrf_follow_kernel.  In scope: tid, lane, half = tid >> 8 (wave-uniform), mb = the tile's mailbox, double v[5], int *okp (LDS).
+// MBOX_FETCH(j): this thread's words of column block j -- blocks (j .. 7, j), then its Q operands: (9 - j) x 256 values, contiguous
+// -- into v (value tid + 512 i is element tid & 255 of block (tid >> 8) + 2 i: one 32-bit offset per thread, nothing that would live
+// across an unrolled loop).  MBOX_COMPLETE(j, abort word, code): fetch again until none of this WAVE's words is the fill pattern
+// (bounded; every eighth retry a read-modify-write: a reader's own refill can leave it a stale line, poll_word); on a time-out or
+// an abort *okp = 0 and the caller leaves behind its next barrier.
+#define MBOX_FETCH(jn)                                                                                                        \
+{                                                                                                                        \
+    unsigned mo = 8u * (unsigned)tid;                                                                                    \
+    asm volatile("" : "+v"(mo));                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                                      \
+        v[i] = 0.0;                                                                                                      \
+        if (half + 2 * i <= 8 - (jn))                                                                                    \
+            v[i] = load_wt((const double *)((const char *)(mb + MBOX_OFF(jn)) + (mo + 4096u * (unsigned)i)));            \
+    }                                                                                                                    \
+}
+#define MBOX_COMPLETE(jn, ABORTW, CODE)                                                                                                    \
+for (unsigned it = 0;; ++it) {                                                                                           \
+    bool missing = false;                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                                        \
+        if (half + 2 * i <= 8 - (jn)) missing = missing || __double_as_longlong(v[i]) == -1ll;                           \
+    if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;                                                             \
+    const bool late_ = it > (unsigned)(ENGINE_TIMEOUT_TICKS / 100ull);                                                   \
+    if (late_ || ((it & 7u) == 7u && __hip_atomic_load((ABORTW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { \
+        if (lane == 0) {                                                                                                 \
+            if (late_) __hip_atomic_store((ABORTW), (CODE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            *okp = 0;                                                                                                    \
+        }                                                                                                                \
+        break;                                                                                                           \
+    }                                                                                                                    \
+    __builtin_amdgcn_s_sleep(2);                                                                                         \
+    if ((it & 7u) == 7u) {      /* (a reader's own refill can leave it a stale line: poll_word -- a read-modify-write cannot) */ \
+        unsigned mo = 8u * (unsigned)tid;                                                                                \
+        asm volatile("" : "+v"(mo));                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                                    \
+            if (half + 2 * i <= 8 - (jn) && __double_as_longlong(v[i]) == -1ll)                                          \
+                v[i] = __longlong_as_double((long long)__hip_atomic_fetch_or(                                            \
+                    (unsigned long long *)((char *)const_cast<double *>(mb + MBOX_OFF(jn)) + (mo + 4096u * (unsigned)i)), 0ull, \
+                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));                                                        \
+    } else                                                                                                               \
+        MBOX_FETCH(jn)                                                                                                \
+}
+
 // The pair partner (round 5, COCONS_ENGINE_PAIR): a second workgroup of the engine's launch, on a CU of its own, that takes the
 // SECOND tile of every diagonal block -- and everything between the two tiles -- off the engine's hands, and does the part that
 // depends on the first tile's factor WHILE that factor is being formed.  Until now a block was four passes of one workgroup,
@@ -719,47 +763,11 @@ __device__ __forceinline__ void engine_partner_loop(const EngineArgs &e, double 
         const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
         const double *mb = e.mbox + (size_t)(t >> 1) * (44 * 256);
         double v[5];
-#define PARTNER_FETCH(jn)                                                                                                        \
-        {                                                                                                                        \
-            unsigned mo = 8u * (unsigned)tid;                                                                                    \
-            asm volatile("" : "+v"(mo));                                                                                        \
-            _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                                      \
-                v[i] = 0.0;                                                                                                      \
-                if (half + 2 * i <= 8 - (jn))                                                                                    \
-                    v[i] = load_wt((const double *)((const char *)(mb + MBOX_OFF(jn)) + (mo + 4096u * (unsigned)i)));            \
-            }                                                                                                                    \
-        }
-#define PARTNER_COMPLETE(jn)                                                                                                     \
-        for (unsigned it = 0;; ++it) {                                                                                           \
-            bool missing = false;                                                                                                \
-            _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                                        \
-                if (half + 2 * i <= 8 - (jn)) missing = missing || __double_as_longlong(v[i]) == -1ll;                           \
-            if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;                                                             \
-            const bool late_ = it > (unsigned)(ENGINE_TIMEOUT_TICKS / 100ull);                                                   \
-            if (late_ || ((it & 7u) == 7u && __hip_atomic_load(e.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { \
-                if (lane == 0) {                                                                                                 \
-                    if (late_) __hip_atomic_store(e.abort_word, 0x700u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-                    *okp = 0;                                                                                                    \
-                }                                                                                                                \
-                break;                                                                                                           \
-            }                                                                                                                    \
-            __builtin_amdgcn_s_sleep(2);                                                                                         \
-            if ((it & 7u) == 7u) {      /* (a reader's own refill can leave it a stale line: poll_word -- a read-modify-write cannot) */ \
-                unsigned mo = 8u * (unsigned)tid;                                                                                \
-                asm volatile("" : "+v"(mo));                                                                                    \
-                _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                                    \
-                    if (half + 2 * i <= 8 - (jn) && __double_as_longlong(v[i]) == -1ll)                                          \
-                        v[i] = __longlong_as_double((long long)__hip_atomic_fetch_or(                                            \
-                            (unsigned long long *)((char *)const_cast<double *>(mb + MBOX_OFF(jn)) + (mo + 4096u * (unsigned)i)), 0ull, \
-                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));                                                        \
-            } else                                                                                                               \
-                PARTNER_FETCH(jn)                                                                                                \
-        }
-        PARTNER_FETCH(0)
+        MBOX_FETCH(0)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             double *LS = LST + (j & 1) * (9 * 256);
-            PARTNER_COMPLETE(j)
+            MBOX_COMPLETE(j, e.abort_word, 0x700u + (unsigned)t)
 #pragma unroll
             for (int i = 0; i < 5; ++i)
                 if (half + 2 * i <= 8 - j) LS[tid + 512 * i] = v[i];
@@ -782,7 +790,7 @@ __device__ __forceinline__ void engine_partner_loop(const EngineArgs &e, double 
                 }
             }
             __syncthreads();
-            if (j < 7) PARTNER_FETCH(j + 1)
+            if (j < 7) MBOX_FETCH(j + 1)
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const int bb = wave + 8 * i;
@@ -795,8 +803,6 @@ __device__ __forceinline__ void engine_partner_loop(const EngineArgs &e, double 
                 }
             }
         }
-#undef PARTNER_FETCH
-#undef PARTNER_COMPLETE
         // X to memory (both buffers under the dependency-driven schedule), the updated tile into the image it is factored from
         asm volatile("" : "+v"(lo));
 #pragma unroll
@@ -995,6 +1001,73 @@ potrf_engine_kernel(EngineArgs e)
         __syncthreads();
         if (tid == 0) signal_add(e.out + t + 1);
         if (tr && tid == 0) tr[7] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Tile factorisation and the panel solve below it in ONE launch (round 5, COCONS_POTRF_FOLLOW; the plain and the band-limited
+// schedule): workgroup 0 factors the tile and publishes every finished block in the tile's mailbox (potrf_tile_body: mbox); the
+// other workgroups -- 128 rows each, a wave 16 -- hold their strips of the rows below in registers and FOLLOW the factorisation
+// column block by column block, like the engine's partner does: X(., j) = (B(., j) - sum_{k<j} X(., k) L(j,k)^T) L(j,j)^-T is
+// formed ~a round trip behind column block j of the factor, and the rows are solved ~6 us after the tile is factored.  Until now:
+// the tile's launch (25 us), a boundary, then a panel-solve launch that fetched the whole factor before it began (8 .. 13 us) --
+// per tile column of the taper path's 79, and twice per block of the plain schedule the batch slots run.  (A first attempt at ONE
+// launch -- solve workgroups that waited for a word behind the complete factor -- was slower than two launches and removed.)
+// Workgroup 0 is dispatched first and waits for nothing, so the followers' bounded waits never run out unless something else has.
+// Same operations in the same order as potrf_tile_kernel | trsm_tile_kernel: bit-identical.
+// rows: strips of 64 -- nb1 of them from r0, the others from e0 (launch_trsm_tile's two ranges); a follower takes two.
+__global__ void __launch_bounds__(512)
+potrf_follow_kernel(double *A, size_t lda, int c0, double *q_out, int *info, double *mbox, int r0, int nb1, int e0, int nstrips,
+                    unsigned *abort_word)
+{
+    extern __shared__ double smem[];
+    if (blockIdx.x == 0) {
+        potrf_tile_body<false>(A, lda, c0, q_out, info, smem, nullptr, nullptr, nullptr, mbox);
+        return;
+    }
+    double *LST = smem;                            // two stages of 9 blocks
+    int *okp = (int *)(smem + 18 * 256);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int strip = 2 * ((int)blockIdx.x - 1) + half;
+    const bool valid = strip < nstrips;
+    const int rs = (strip < nb1 ? r0 + 64 * strip : e0 + 64 * (strip - nb1)) + 16 * (wave & 3);
+    const double *mb = mbox;
+    d4 B[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) B[j] = valid ? glb_blk(A, lda, rs, c0 + 16 * j, lane) : (d4){0.0, 0.0, 0.0, 0.0};
+    if (tid == 0) *okp = 1;
+    __syncthreads();
+    double v[5];
+    MBOX_FETCH(0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double *LS = LST + (j & 1) * (9 * 256);
+        MBOX_COMPLETE(j, abort_word, 0x7f0u)
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (half + 2 * i <= 8 - j) LS[tid + 512 * i] = v[i];
+        __syncthreads();
+        if (*okp == 0) return;
+        if (j < 7) MBOX_FETCH(j + 1)               // (in flight during the solve with column block j)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        d4 L = lds_blk(LS, ln);
+        double Q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Q[s] = LS[(8 - j) * 256 + s * 64 + ln];
+        trsm16(B[j], L, Q);
+        d4 NX = -B[j];
+#pragma unroll
+        for (int jj = j + 1; jj < 8; ++jj) {
+            d4 Lb = lds_blk(LS + (jj - j) * 256, ln);
+            blk_mma(B[jj], NX, Lb);
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c0 + 16 * j, lane, B[j]);
     }
 }
 
@@ -2427,6 +2500,22 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
     if (nb1 + nb2 <= 0) return;
     hipLaunchKernelGGL(trsm_tile_kernel, dim3(nb1 + nb2), dim3(256), 0, s, A, lda, c0, r0, dinv, wait_word, abort_word,
                        nb1, ext_r0, own_world, own_rank, own_group < 1 ? 1 : own_group);
+}
+
+// rows like launch_trsm_tile: [r0, r1), or -- band-limited -- [r0, band_r1) and [ext_r0, r1); mbox: the tile's mailbox, filled
+// with the pattern ~0 by the caller
+void launch_potrf_follow(double *A, size_t lda, int c0, int r0, int r1, double *dinv, int *info, double *mbox,
+                         unsigned *abort_word, hipStream_t s, int band_r1, int ext_r0)
+{
+    int nb1 = ((band_r1 >= 0 ? band_r1 : r1) - r0) / 64, nb2 = band_r1 >= 0 ? (r1 - ext_r0) / 64 : 0;
+    if (nb1 < 0) nb1 = 0;
+    if (nb2 < 0) nb2 = 0;
+    const int nstrips = nb1 + nb2;
+    static std::atomic<unsigned long long> attr_done{0};
+    const size_t shm = 76 * 1024;               // the tile's image and its Q operands (74 KB); a follower's two stages: 36 KB
+    set_dynamic_lds_once((const void *)potrf_follow_kernel, shm, attr_done);
+    hipLaunchKernelGGL(potrf_follow_kernel, dim3(1 + (nstrips + 1) / 2), dim3(512), shm, s, A, lda, c0, dinv, info, mbox, r0, nb1,
+                       ext_r0, nstrips, abort_word);
 }
 
 void launch_panel_pair(double *A, size_t lda, int c0, int r0, int r1, const double *q0, const double *q1, unsigned *out0,

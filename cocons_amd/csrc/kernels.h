@@ -113,6 +113,10 @@ inline double *band_base(double *A, int c, int skew) { return skew ? A - (ptrdif
 // its eight 16x16 diagonal blocks to dinv (8*256 doubles).  info: atomicMin of the
 // 1-based failing column (initialise to INT_MAX).
 void launch_potrf_tile(double *A, size_t lda, int c0, double *dinv, int *info, hipStream_t s);
+// launch_potrf_tile and launch_trsm_tile (rows as there) in ONE launch: the solve workgroups follow the factorisation through
+// the tile's mailbox (ENGINE_MBOX_DOUBLES doubles, every byte 0xff beforehand); bit-identical to the two launches
+void launch_potrf_follow(double *A, size_t lda, int c0, int r0, int r1, double *dinv, int *info, double *mbox,
+                         unsigned *abort_word, hipStream_t s, int band_r1 = -1, int ext_r0 = 0);
 // Resident diagonal-BLOCK engine (one workgroup on a CU of its own) for the 256 x 256 diagonal blocks
 // starting at tile t0 (even): see potrf_engine_kernel.  Flag words, all zero at launch:
 //   in[t]    raised by the update kernels (launch_update's sig / sig_tile): 3 = tile (t,t) updated;

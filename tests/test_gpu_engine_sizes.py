@@ -356,3 +356,34 @@ def test_fused_panel_same_bits_as_three_launches(gx, gy):
         assert v1 == v0 and np.array_equal(p1, p0)
     finally:
         _lib.check(L.cocons_debug_tune(b"panel_fused", int(os.environ.get("COCONS_PANEL_FUSED", "1"))), "tune")
+
+
+@pytest.mark.parametrize("gx,gy,engine", [(20, 20, 1), (33, 31, 0), (45, 47, 0), (64, 64, 0)])
+def test_potrf_follow_same_bits_as_two_launches(gx, gy, engine):
+    """Tile factorisation and the panel solve below it in one launch whose solve workgroups follow the factorisation through the
+    tile's mailbox (COCONS_POTRF_FOLLOW, chol.hip potrf_follow_kernel) against the two launches: identical bits -- on the plain
+    schedule (engine off: every tile; an odd number of 64-row strips, right-hand sides in slots and under the matrix) and on a
+    small problem that never uses the engine."""
+    import cocons_amd as ca
+    from cocons_amd import _lib, workloads as wl
+    L = _lib.load()
+    locs, sc = _grid(gx, gy)
+    n = locs.shape[0]
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.1, -0.2, 0.05])
+    rng = np.random.default_rng(n + 3)
+    z = rng.standard_normal((n, 2)) + (X @ np.array([0.2, 0.3, -0.1]))[:, None]
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    try:
+        _lib.check(L.cocons_debug_tune(b"engine", engine), "tune")
+        _lib.check(L.cocons_debug_tune(b"potrf_follow", 1), "tune")
+        v1, p1 = fit.neg2loglik_core(th)
+        v1b = fit.neg2loglik_core(th)[0]
+        _lib.check(L.cocons_debug_tune(b"potrf_follow", 0), "tune")
+        v0, p0 = fit.neg2loglik_core(th)
+        assert v1 == v0 and v1b == v1 and np.array_equal(p1, p0)
+        assert fit.engine_state()["retries"] == 0
+    finally:
+        _lib.check(L.cocons_debug_tune(b"engine", int(os.environ.get("COCONS_ENGINE", "1"))), "tune")
+        _lib.check(L.cocons_debug_tune(b"potrf_follow", int(os.environ.get("COCONS_POTRF_FOLLOW", "1"))), "tune")
