@@ -291,8 +291,8 @@ struct cocons_fit {
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
     int dag_helpers_live;         // chain helpers in the engine launch of the factorisation being enqueued (0: none)
     int engine_pair_live;         // 1: the engine launched for the next factorisation has a pair partner (counts itself like a helper)
-    double *dmbox; size_t dmbox_elems;   // mailboxes (mbox_reset): one per diagonal block for the engine's pair mode, then one per tile
-    size_t mbox_follow0;                 // for potrf_solve's followers (first of those, in doubles)
+    double *dmbox; size_t dmbox_elems;   // one mailbox per tile (mbox_reset): the engine's pair mode, the panel kernel and potrf_solve's
+                                         // followers read a tile's factor from there while it is being formed
     bool follow_used, follow_off;        // the operation being enqueued used launch_potrf_follow; it timed out once on this handle: off
     double enq_host_us; long long enq_calls;      // (diagnostics) host time spent enqueueing evaluations, calls: cocons_debug_host_enqueue
     bool dag_used;                // the factorisation enqueued last ran the DAG schedule: its factor is split over dA and dP
@@ -942,10 +942,10 @@ static int band_hi(const FactorView &v, int k)
 static bool follow_on(cocons_fit *f);
 static void potrf_solve(cocons_fit *f, double *A, size_t lda, int tile, int r0, int r1, double *q, hipStream_t s, int br, int er)
 {
-    if (follow_on(f) && f->mbox_follow0 + ((size_t)tile + 1) * ENGINE_MBOX_DOUBLES <= f->dmbox_elems) {
+    if (follow_on(f) && ((size_t)tile + 1) * ENGINE_MBOX_DOUBLES <= f->dmbox_elems) {
         f->follow_used = true;
         launch_potrf_follow(A, lda, tile * TILE, r0, r1, q, f->dinfo,
-                            f->dmbox + f->mbox_follow0 + (size_t)tile * ENGINE_MBOX_DOUBLES, (unsigned *)(f->dinfo + 1), s, br, er);
+                            f->dmbox + (size_t)tile * ENGINE_MBOX_DOUBLES, (unsigned *)(f->dinfo + 1), s, br, er);
         return;
     }
     launch_potrf_tile(A, lda, tile * TILE, q, f->dinfo, s);
@@ -1000,6 +1000,8 @@ struct Tunables {
                              // (chol.hip: engine_partner_loop); 0 = one workgroup does the four passes one behind the other
     int panel_fused = 1;     // COCONS_PANEL_FUSED: 1 = the panel of a two-tile block of the engine schedule is ONE launch (chol.hip:
                              // panel_pair_kernel); 0 = solve | in-panel update | solve, three launches
+    int panel_follow = 1;    // COCONS_PANEL_FOLLOW: 1 = the one-launch panel's strips follow the engine's tiles through their mailboxes
+                             // (pair mode) instead of waiting for out[t] / out[t+1] and fetching the factor
     int potrf_follow = 1;    // COCONS_POTRF_FOLLOW: 1 = a tile factorisation and the panel solve below it are ONE launch whose solve
                              // workgroups follow the factorisation through a mailbox (chol.hip: potrf_follow_kernel; the plain and
                              // the band-limited schedule); 0 = two launches
@@ -1027,6 +1029,7 @@ static Tunables &tun()
         rd("COCONS_ENGINE_PAIR", t.engine_pair);
         rd("COCONS_PANEL_FUSED", t.panel_fused);
         rd("COCONS_POTRF_FOLLOW", t.potrf_follow);
+        rd("COCONS_PANEL_FOLLOW", t.panel_follow);
         if (t.dag_helpers < 1) t.dag_helpers = 1;
         if (t.dag_helpers > 24) t.dag_helpers = 24;
         t.init = true;
@@ -1036,8 +1039,8 @@ static Tunables &tun()
 
 static bool follow_on(cocons_fit *f)
 {
-    return tun().potrf_follow != 0 && !f->follow_off && f->dmbox != nullptr && f->mbox_follow0 != 0 &&
-           f->dmbox_elems >= f->mbox_follow0 + ((size_t)f->nt + 1) * ENGINE_MBOX_DOUBLES;
+    return tun().potrf_follow != 0 && !f->follow_off && f->dmbox != nullptr &&
+           f->dmbox_elems >= ((size_t)f->nt + 2) * ENGINE_MBOX_DOUBLES;
 }
 
 extern "C" int cocons_debug_tune(const char *name, int value)
@@ -1060,6 +1063,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "engine_pair") t.engine_pair = value;
     else if (k == "panel_fused") t.panel_fused = value;
     else if (k == "potrf_follow") t.potrf_follow = value;
+    else if (k == "panel_follow") t.panel_follow = value;
     else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
@@ -1157,13 +1161,11 @@ static int flags_reset(cocons_fit *f, int nt)
     return 0;
 }
 
-// the mailboxes of the engine's pair mode -- one per diagonal block, for its first tile -- and of potrf_solve's followers -- one per
-// tile -- filled with the pattern that means "not written yet" (every byte 0xff; potrf_tile_body: mbox) on the main stream:
-// 88 KB each, 10.7 MB at n = 10^4
+// the tiles' mailboxes (the engine's pair mode, the panel kernel, potrf_solve's followers) filled with the pattern that means "not
+// written yet" (every byte 0xff; potrf_tile_body: mbox) on the main stream: 88 KB each, 7.1 MB at n = 10^4
 static int mbox_reset(cocons_fit *f, int nt)
 {
-    f->mbox_follow0 = ((size_t)nt / 2 + 2) * ENGINE_MBOX_DOUBLES;
-    const size_t need = f->mbox_follow0 + ((size_t)nt + 1) * ENGINE_MBOX_DOUBLES;
+    const size_t need = ((size_t)nt + 2) * ENGINE_MBOX_DOUBLES;
     if (f->dmbox_elems < need) {
         HIPCHK(hipStreamSynchronize(f->stream));
         if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
@@ -1553,8 +1555,11 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
             timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k));
         }
         if (two && hb < 0 && tun().panel_fused) {
+            const bool fol = f->engine_pair_live && tun().panel_follow && f->dmbox != nullptr;
             launch_panel_pair(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048,
-                              f->dinv + (size_t)((t + 1) & 1) * 2048, out + t, xr + t, out + t + 1, abort_word, M);
+                              f->dinv + (size_t)((t + 1) & 1) * 2048, out + t, xr + t, out + t + 1, abort_word, M,
+                              fol ? f->dmbox + (size_t)t * ENGINE_MBOX_DOUBLES : nullptr,
+                              fol ? f->dmbox + (size_t)(t + 1) * ENGINE_MBOX_DOUBLES : nullptr);
             continue;
         }
         launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048, M,
@@ -2934,7 +2939,7 @@ static int shard_factor_diag(cocons_fit *f, int k)
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(in + t), 7, (size_t)w, s));
         // (pair mode: its two workgroups side by side -- the second tile's factorisation starts ~6 us behind the first's end
         // instead of behind the strip solve and the tile update: 78 -> ~56 us for the block)
-        const bool pair = w == 2 && tun().engine_pair && f->dmbox && f->dmbox_elems >= ((size_t)f->nt / 2 + 2) * ENGINE_MBOX_DOUBLES;
+        const bool pair = w == 2 && tun().engine_pair && f->dmbox && f->dmbox_elems >= ((size_t)f->nt + 2) * ENGINE_MBOX_DOUBLES;
         launch_potrf_engine(A, f->lda, t, t + w, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
                             f->dflags + 3 * (size_t)f->flags_cap, s, nullptr, nullptr, 0, nullptr, nullptr, 0,
                             pair ? f->dmbox : nullptr);

@@ -642,7 +642,7 @@ struct EngineArgs {
                              // tile t factored, out[t] raised, in[t+1] seen, xr[t] raised, tile t+1 updated, factored, out[t+1] raised
     const struct DagArgs *chain; // DAG schedule, chain layout (round 5): device copy of the launch's task words -- the workgroups
     int nhelp;                   // 8, 16, ... 8 nhelp of this launch are CHAIN HELPERS (chain_helper_loop); null / 0: none
-    double *mbox;                // pair mode: mailboxes of the first tiles, 44 x 256 doubles per block, filled with ~0 (potrf_tile_body)
+    double *mbox;                // pair mode: the tiles' mailboxes, 44 x 256 doubles each (index: tile), filled with ~0 (potrf_tile_body)
     int partner;                 // pair mode: index of the PAIR PARTNER's workgroup in this launch (engine_partner_loop); 0: none
 };
 
@@ -691,6 +691,43 @@ for (unsigned it = 0;; ++it) {                                                  
                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));                                                        \
     } else                                                                                                               \
         MBOX_FETCH(jn)                                                                                                \
+}
+
+// ... and for workgroups of 256 threads (the panel kernel): value tid + 256 i is element tid of block i; double v9[9].
+#define MBOX_FETCH256(jn)                                                                                                     \
+{                                                                                                                             \
+    unsigned mo = 8u * (unsigned)tid;                                                                                         \
+    asm volatile("" : "+v"(mo));                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 9; ++i) {                                                                           \
+        v9[i] = 0.0;                                                                                                          \
+        if (i <= 8 - (jn)) v9[i] = load_wt((const double *)((const char *)(mb + MBOX_OFF(jn)) + (mo + 2048u * (unsigned)i))); \
+    }                                                                                                                         \
+}
+#define MBOX_COMPLETE256(jn, ABORTW, CODE)                                                                                    \
+for (unsigned it = 0;; ++it) {                                                                                                \
+    bool missing = false;                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 9; ++i)                                                                             \
+        if (i <= 8 - (jn)) missing = missing || __double_as_longlong(v9[i]) == -1ll;                                          \
+    if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;                                                                  \
+    const bool late_ = it > (unsigned)(ENGINE_TIMEOUT_TICKS / 100ull);                                                        \
+    if (late_ || ((it & 7u) == 7u && __hip_atomic_load((ABORTW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {        \
+        if (lane == 0) {                                                                                                      \
+            if (late_) __hip_atomic_store((ABORTW), (CODE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                      \
+            *okp = 0;                                                                                                         \
+        }                                                                                                                     \
+        break;                                                                                                                \
+    }                                                                                                                         \
+    __builtin_amdgcn_s_sleep(2);                                                                                              \
+    if ((it & 7u) == 7u) {                                                                                                    \
+        unsigned mo = 8u * (unsigned)tid;                                                                                     \
+        asm volatile("" : "+v"(mo));                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 9; ++i)                                                                         \
+            if (i <= 8 - (jn) && __double_as_longlong(v9[i]) == -1ll)                                                         \
+                v9[i] = __longlong_as_double((long long)__hip_atomic_fetch_or(                                                \
+                    (unsigned long long *)((char *)const_cast<double *>(mb + MBOX_OFF(jn)) + (mo + 2048u * (unsigned)i)), 0ull, \
+                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));                                                             \
+    } else                                                                                                                    \
+        MBOX_FETCH256(jn)                                                                                                     \
 }
 
 // The pair partner (round 5, COCONS_ENGINE_PAIR): a second workgroup of the engine's launch, on a CU of its own, that takes the
@@ -761,7 +798,7 @@ __device__ __forceinline__ void engine_partner_loop(const EngineArgs &e, double 
         // other: 6.4 us per column block against the engine's 3 .. 4, and 19 us behind it at the end; with the fetch ahead of the
         // update, but still behind a drained flag: 12 us behind.)
         const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
-        const double *mb = e.mbox + (size_t)(t >> 1) * (44 * 256);
+        const double *mb = e.mbox + (size_t)t * (44 * 256);
         double v[5];
         MBOX_FETCH(0)
 #pragma unroll
@@ -841,8 +878,10 @@ __device__ __forceinline__ void engine_partner_loop(const EngineArgs &e, double 
         __syncthreads();
         // (xr[t] is raised from inside the tile factorisation, once the copies of X have drained: nothing on the chain needs them)
         if (tr && tid == 0) { tr[4] = __builtin_amdgcn_s_memrealtime(); tr[5] = tr[4]; }
+        // (the second tile goes into a mailbox too: the panel kernel's workgroups follow both tiles, panel_pair_kernel)
         potrf_tile_body<true, true>(A, lda, c1, e.dinv + (size_t)((t + 1) & 1) * 2048, e.info, smem, dag_blk ? QALL : nullptr,
-                                    dag_blk ? e.wbuf + (size_t)(t + 1) * TILE * TILE : nullptr, XI, nullptr, e.xr + t);
+                                    dag_blk ? e.wbuf + (size_t)(t + 1) * TILE * TILE : nullptr, XI,
+                                    e.mbox + (size_t)(t + 1) * (44 * 256), e.xr + t);
         if (tr && tid == 0) tr[6] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -900,7 +939,7 @@ potrf_engine_kernel(EngineArgs e)
         // (DAG blocks: W = L^-1 of the tile comes out of the factorisation itself, complete before out[t])
         potrf_tile_body<true>(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem, QALL,
                               dag_blk ? e.wbuf + (size_t)t * TILE * TILE : nullptr, XI,
-                              pair ? e.mbox + (size_t)(t >> 1) * (44 * 256) : nullptr);
+                              pair ? e.mbox + (size_t)t * (44 * 256) : nullptr);
         __syncthreads();
         if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1071,19 +1110,6 @@ potrf_follow_kernel(double *A, size_t lda, int c0, double *q_out, int *info, dou
     }
 }
 
-// The engine needs a CU to itself (its 8 waves take every VGPR of the four SIMDs): once a chip-filling launch
-// is running, a CU only empties when that launch drains -- and never while workgroups that WAIT for the
-// engine sit on every CU.  So the main stream does not start the factorisation's launches before the
-// engine is resident: this one-lane kernel waits for its alive word (bounded like every other wait).
-__global__ void __launch_bounds__(64)
-engine_gate_kernel(unsigned *alive, unsigned *abort_word, unsigned code, unsigned long long ticks, unsigned nhelp)
-{
-    // (nhelp > 0: the launch also holds chain helpers, which count themselves in alive[2] once resident: a chain task nobody
-    // resident can draw would stop the persistent launch as surely as a missing engine)
-    if (threadIdx.x == 0 && wait_ge<false>(alive, 1u, abort_word, code, ticks) && nhelp)
-        (void)wait_ge<false>(alive + 2, nhelp, abort_word, code + 1u, ticks);
-}
-
 // The 36 lower blocks of the factored diagonal tile at (c0, c0) and its Q operands into LDS (256 threads): EVERY global load is
 // issued before the first LDS store -- one round trip.  (Until round 5 the panel kernels fetched block by block, a load and a
 // store at a time: 36 dependent round trips, ~10 of the 14.6 us a panel solve took whatever its number of rows; the kernel
@@ -1112,6 +1138,191 @@ __device__ __forceinline__ void fetch_factor_tile(const double *A, size_t lda, i
     for (int b = 0; b < 36; ++b) SL[b * 256 + k * 16 + i] = v[b];
 #pragma unroll
     for (int e = 0; e < 8; ++e) QS[tid + 256 * e] = q[e];
+}
+
+// ---------------------------------------------------------------------------
+// Panel of a two-tile block in ONE launch (engine schedule, round 5): for the rows below the diagonal block
+//     X0 = B0 L(t)^-T  |  B1 -= X0 X(t+1,t)^T  |  X1 = B1 L(t+1)^-T
+// -- until now three launches (trsm_tile_kernel, the in-panel update_kernel, trsm_tile_kernel), each of which read its strip
+// from memory and wrote it back, the second and third behind a drained chip.  A workgroup owns 64 rows (a wave 16) for the whole
+// sequence: both 16 x 128 strips stay in registers, the three waits -- out[t], xr[t], out[t+1] -- are met where the data is needed,
+// and the rows are done ~8 us after the engine's second tile instead of ~16 + a boundary.  Same operations on the same operands
+// in the same order as the three kernels (the product accumulated from zero over ascending k and subtracted once, as
+// update_kernel does): bit-identical.
+__global__ void __launch_bounds__(256)
+panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const double *q1, unsigned *out0, unsigned *xrw,
+                  unsigned *out1, unsigned *abort_word, const double *mb0, const double *mb1)
+{
+    // 136 KB: L of the current tile (36 blocks) and its Q operands (8) -- or, between the two solves, all 64 blocks of X(t+1,t)
+    __shared__ double SM[68 * 256];
+    __shared__ int ok;
+    double *SL = SM, *QS = SM + 36 * 256, *XS = SM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c1 = c0 + TILE;
+    const int rs = r0 + 64 * (int)blockIdx.x + 16 * wave;
+    d4 B0[8], B1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) B0[j] = glb_blk(A, lda, rs, c0 + 16 * j, lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) B1[j] = glb_blk(A, lda, rs, c1 + 16 * j, lane);
+    // ---- X0 = B0 L(t)^-T
+    int *okp = &ok;
+    if (mb0) {
+        // the engine's pair mode: both tiles are published in mailboxes while they are formed -- the strip FOLLOWS the tile column
+        // block by column block (like potrf_follow_kernel's workgroups) and is solved a round trip behind the tile's last block,
+        // where waiting for out[t], fetching the factor and solving took ~8 us behind it
+        const double *mb = mb0;
+        double v9[9];
+        if (tid == 0) ok = 1;
+        __syncthreads();
+        MBOX_FETCH256(0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double *LS = SM + (j & 1) * (9 * 256);
+            MBOX_COMPLETE256(j, abort_word, 0x300u + c0 / TILE)
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i <= 8 - j) LS[tid + 256 * i] = v9[i];
+            __syncthreads();
+            if (!ok) return;
+            if (j < 7) MBOX_FETCH256(j + 1)
+            d4 L = lds_blk(LS, lane);
+            double Q[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Q[s] = LS[(8 - j) * 256 + s * 64 + lane];
+            trsm16(B0[j], L, Q);
+            d4 NX = -B0[j];
+#pragma unroll
+            for (int jj = j + 1; jj < 8; ++jj) {
+                d4 Lb = lds_blk(LS + (jj - j) * 256, lane);
+                blk_mma(B0[jj], NX, Lb);
+            }
+        }
+    } else {
+    if (tid == 0) ok = wait_ge<false>(out0, 1u, abort_word, 0x300u + c0 / TILE) ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!ok) return;
+    fetch_factor_tile<true>(A, lda, c0, q0, SL, QS, tid);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        d4 L = lds_blk(SL + (j * (j + 1) / 2 + j) * 256, lane);
+        double Q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Q[s] = QS[j * 256 + s * 64 + lane];
+        trsm16(B0[j], L, Q);
+        d4 NX = -B0[j];
+#pragma unroll
+        for (int jj = j + 1; jj < 8; ++jj) {
+            d4 Lb = lds_blk(SL + (jj * (jj + 1) / 2 + j) * 256, lane);
+            blk_mma(B0[jj], NX, Lb);
+        }
+    }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c0 + 16 * j, lane, B0[j]);
+    // ---- B1 -= X0 X(t+1,t)^T: all 64 blocks of X(t+1,t) into LDS (over the image of L(t), which is dead), four rounds of sixteen
+    // loads per thread with the next round in flight while one is stored
+    if (tid == 0) ok = wait_ge<false>(xrw, 1u, abort_word, 0x500u + c0 / TILE) ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                 // (also: every wave is done with L(t))
+    if (!ok) return;
+    {
+        const int i = tid & 15, k = tid >> 4;
+        const double *Xg = A + (size_t)(c1 + i) + (size_t)(c0 + k) * lda;      // block (jj, kb) at + 16 jj + 16 kb lda
+        double st[2][16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) st[0][b] = load_wt(Xg + (size_t)(16 * (b >> 3)) + (size_t)(16 * (b & 7)) * lda);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r + 1 < 4) {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int bb = 16 * (r + 1) + b;
+                    st[(r + 1) & 1][b] = load_wt(Xg + (size_t)(16 * (bb >> 3)) + (size_t)(16 * (bb & 7)) * lda);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 16; ++b) XS[(16 * r + b) * 256 + k * 16 + i] = st[r & 1][b];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                d4 Xb = lds_blk(XS + (jj * 8 + kb) * 256, lane);
+                blk_mma(acc, B0[kb], Xb);
+            }
+            B1[jj] = B1[jj] - acc;
+        }
+    }
+    // ---- X1 = B1 L(t+1)^-T
+    if (mb1) {
+        const double *mb = mb1;
+        double v9[9];
+        __syncthreads();             // (every wave is done with X(t+1,t): the stages overlay it)
+        MBOX_FETCH256(0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double *LS = SM + (j & 1) * (9 * 256);
+            MBOX_COMPLETE256(j, abort_word, 0x300u + c1 / TILE)
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i <= 8 - j) LS[tid + 256 * i] = v9[i];
+            __syncthreads();
+            if (!ok) return;
+            if (j < 7) MBOX_FETCH256(j + 1)
+            d4 L = lds_blk(LS, lane);
+            double Q[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Q[s] = LS[(8 - j) * 256 + s * 64 + lane];
+            trsm16(B1[j], L, Q);
+            d4 NX = -B1[j];
+#pragma unroll
+            for (int jj = j + 1; jj < 8; ++jj) {
+                d4 Lb = lds_blk(LS + (jj - j) * 256, lane);
+                blk_mma(B1[jj], NX, Lb);
+            }
+        }
+    } else {
+    if (tid == 0) ok = wait_ge<false>(out1, 1u, abort_word, 0x300u + c1 / TILE) ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                 // (also: every wave is done with X(t+1,t))
+    if (!ok) return;
+    fetch_factor_tile<true>(A, lda, c1, q1, SL, QS, tid);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        d4 L = lds_blk(SL + (j * (j + 1) / 2 + j) * 256, lane);
+        double Q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Q[s] = QS[j * 256 + s * 64 + lane];
+        trsm16(B1[j], L, Q);
+        d4 NX = -B1[j];
+#pragma unroll
+        for (int jj = j + 1; jj < 8; ++jj) {
+            d4 Lb = lds_blk(SL + (jj * (jj + 1) / 2 + j) * 256, lane);
+            blk_mma(B1[jj], NX, Lb);
+        }
+    }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c1 + 16 * j, lane, B1[j]);
+}
+
+// The engine needs a CU to itself (its 8 waves take every VGPR of the four SIMDs): once a chip-filling launch
+// is running, a CU only empties when that launch drains -- and never while workgroups that WAIT for the
+// engine sit on every CU.  So the main stream does not start the factorisation's launches before the
+// engine is resident: this one-lane kernel waits for its alive word (bounded like every other wait).
+__global__ void __launch_bounds__(64)
+engine_gate_kernel(unsigned *alive, unsigned *abort_word, unsigned code, unsigned long long ticks, unsigned nhelp)
+{
+    // (nhelp > 0: the launch also holds chain helpers, which count themselves in alive[2] once resident: a chain task nobody
+    // resident can draw would stop the persistent launch as surely as a missing engine)
+    if (threadIdx.x == 0 && wait_ge<false>(alive, 1u, abort_word, code, ticks) && nhelp)
+        (void)wait_ge<false>(alive + 2, nhelp, abort_word, code + 1u, ticks);
 }
 
 // ---------------------------------------------------------------------------
@@ -1162,115 +1373,6 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsig
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c0 + 16 * j, lane, B[j]);
-}
-
-// ---------------------------------------------------------------------------
-// Panel of a two-tile block in ONE launch (engine schedule, round 5): for the rows below the diagonal block
-//     X0 = B0 L(t)^-T  |  B1 -= X0 X(t+1,t)^T  |  X1 = B1 L(t+1)^-T
-// -- until now three launches (trsm_tile_kernel, the in-panel update_kernel, trsm_tile_kernel), each of which read its strip
-// from memory and wrote it back, the second and third behind a drained chip.  A workgroup owns 64 rows (a wave 16) for the whole
-// sequence: both 16 x 128 strips stay in registers, the three waits -- out[t], xr[t], out[t+1] -- are met where the data is needed,
-// and the rows are done ~8 us after the engine's second tile instead of ~16 + a boundary.  Same operations on the same operands
-// in the same order as the three kernels (the product accumulated from zero over ascending k and subtracted once, as
-// update_kernel does): bit-identical.
-__global__ void __launch_bounds__(256)
-panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const double *q1, unsigned *out0, unsigned *xrw,
-                  unsigned *out1, unsigned *abort_word)
-{
-    // 136 KB: L of the current tile (36 blocks) and its Q operands (8) -- or, between the two solves, all 64 blocks of X(t+1,t)
-    __shared__ double SM[68 * 256];
-    __shared__ int ok;
-    double *SL = SM, *QS = SM + 36 * 256, *XS = SM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c1 = c0 + TILE;
-    const int rs = r0 + 64 * (int)blockIdx.x + 16 * wave;
-    d4 B0[8], B1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) B0[j] = glb_blk(A, lda, rs, c0 + 16 * j, lane);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) B1[j] = glb_blk(A, lda, rs, c1 + 16 * j, lane);
-    // ---- X0 = B0 L(t)^-T
-    if (tid == 0) ok = wait_ge<false>(out0, 1u, abort_word, 0x300u + c0 / TILE) ? 1 : 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (!ok) return;
-    fetch_factor_tile<true>(A, lda, c0, q0, SL, QS, tid);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        d4 L = lds_blk(SL + (j * (j + 1) / 2 + j) * 256, lane);
-        double Q[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) Q[s] = QS[j * 256 + s * 64 + lane];
-        trsm16(B0[j], L, Q);
-        d4 NX = -B0[j];
-#pragma unroll
-        for (int jj = j + 1; jj < 8; ++jj) {
-            d4 Lb = lds_blk(SL + (jj * (jj + 1) / 2 + j) * 256, lane);
-            blk_mma(B0[jj], NX, Lb);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c0 + 16 * j, lane, B0[j]);
-    // ---- B1 -= X0 X(t+1,t)^T: all 64 blocks of X(t+1,t) into LDS (over the image of L(t), which is dead), four rounds of sixteen
-    // loads per thread with the next round in flight while one is stored
-    if (tid == 0) ok = wait_ge<false>(xrw, 1u, abort_word, 0x500u + c0 / TILE) ? 1 : 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                 // (also: every wave is done with L(t))
-    if (!ok) return;
-    {
-        const int i = tid & 15, k = tid >> 4;
-        const double *Xg = A + (size_t)(c1 + i) + (size_t)(c0 + k) * lda;      // block (jj, kb) at + 16 jj + 16 kb lda
-        double st[2][16];
-#pragma unroll
-        for (int b = 0; b < 16; ++b) st[0][b] = load_wt(Xg + (size_t)(16 * (b >> 3)) + (size_t)(16 * (b & 7)) * lda);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (r + 1 < 4) {
-#pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    const int bb = 16 * (r + 1) + b;
-                    st[(r + 1) & 1][b] = load_wt(Xg + (size_t)(16 * (bb >> 3)) + (size_t)(16 * (bb & 7)) * lda);
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < 16; ++b) XS[(16 * r + b) * 256 + k * 16 + i] = st[r & 1][b];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                d4 Xb = lds_blk(XS + (jj * 8 + kb) * 256, lane);
-                blk_mma(acc, B0[kb], Xb);
-            }
-            B1[jj] = B1[jj] - acc;
-        }
-    }
-    // ---- X1 = B1 L(t+1)^-T
-    if (tid == 0) ok = wait_ge<false>(out1, 1u, abort_word, 0x300u + c1 / TILE) ? 1 : 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                 // (also: every wave is done with X(t+1,t))
-    if (!ok) return;
-    fetch_factor_tile<true>(A, lda, c1, q1, SL, QS, tid);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        d4 L = lds_blk(SL + (j * (j + 1) / 2 + j) * 256, lane);
-        double Q[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) Q[s] = QS[j * 256 + s * 64 + lane];
-        trsm16(B1[j], L, Q);
-        d4 NX = -B1[j];
-#pragma unroll
-        for (int jj = j + 1; jj < 8; ++jj) {
-            d4 Lb = lds_blk(SL + (jj * (jj + 1) / 2 + j) * 256, lane);
-            blk_mma(B1[jj], NX, Lb);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c1 + 16 * j, lane, B1[j]);
 }
 
 // ---------------------------------------------------------------------------
@@ -2519,11 +2621,11 @@ void launch_potrf_follow(double *A, size_t lda, int c0, int r0, int r1, double *
 }
 
 void launch_panel_pair(double *A, size_t lda, int c0, int r0, int r1, const double *q0, const double *q1, unsigned *out0,
-                       unsigned *xr, unsigned *out1, unsigned *abort_word, hipStream_t s)
+                       unsigned *xr, unsigned *out1, unsigned *abort_word, hipStream_t s, const double *mb0, const double *mb1)
 {
     const int nb = (r1 - r0) / 64;
     if (nb <= 0) return;
-    hipLaunchKernelGGL(panel_pair_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, q0, q1, out0, xr, out1, abort_word);
+    hipLaunchKernelGGL(panel_pair_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, q0, q1, out0, xr, out1, abort_word, mb0, mb1);
 }
 
 // waves per workgroup of the trailing update (COCONS_UPD_WAVES: 4 or 8, see update_kernel's NW)

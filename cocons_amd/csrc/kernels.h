@@ -135,8 +135,8 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
                          unsigned long long *trace = nullptr,
                          const void *chain = nullptr, int nhelp = 0,    // chain helpers of the DAG schedule (chol.hip: chain_helper_loop):
                                                                          // device copy of the task words (launch_chain_args), workgroups
-                         double *mbox = nullptr);                        // pair mode (engine_partner_loop): mailboxes of the blocks' first
-                                                                         // tiles (ENGINE_MBOX_DOUBLES each, index t / 2), every byte 0xff at
+                         double *mbox = nullptr);                        // pair mode (engine_partner_loop): the tiles' mailboxes
+                                                                         // (ENGINE_MBOX_DOUBLES each, index = tile), every byte 0xff at
                                                                          // launch; a second workgroup takes the second tile of every block
 constexpr size_t ENGINE_MBOX_DOUBLES = 44 * 256;
 // nhelp > 0: also waits until that many chain helpers of the engine's launch are resident
@@ -155,8 +155,10 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
 // The panel of a two-tile block of the engine schedule in one launch: rows [r0, r1) of the tile columns at c0 and c0 + 128,
 // X0 = B0 L(c0)^-T | B1 -= X0 X(t+1,t)^T | X1 = B1 L(c0+128)^-T, waiting for out0 / xr / out1 where each is needed (dense, unsharded;
 // q0, q1: the Q operands of the two diagonal tiles).  Bit-identical to launch_trsm_tile | launch_update (K = 128) | launch_trsm_tile.
+// mb0, mb1 (both or neither): the two tiles' mailboxes (the engine's pair mode): the strips follow the tiles while they are formed
 void launch_panel_pair(double *A, size_t lda, int c0, int r0, int r1, const double *q0, const double *q1, unsigned *out0,
-                       unsigned *xr, unsigned *out1, unsigned *abort_word, hipStream_t s);
+                       unsigned *xr, unsigned *out1, unsigned *abort_word, hipStream_t s, const double *mb0 = nullptr,
+                       const double *mb1 = nullptr);
 // C(i,j) -= sum_{k in [k0,k0+K)} A(i,k) A(j,k) for tiles with tile-row in [ti0,ti1),
 // tile-col in [tj0,tj1); lower_only keeps ti >= tj.  All tile indices in units of TILE.
 // sig / sig_tile: hand-off to the engine (sig = the in[] array, sig_tile = even tile of the diagonal block);
