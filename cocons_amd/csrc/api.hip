@@ -291,6 +291,7 @@ struct cocons_fit {
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
     int dag_helpers_live;         // chain helpers in the engine launch of the factorisation being enqueued (0: none)
     int engine_pair_live;         // 1: the engine launched for the next factorisation has a pair partner (counts itself like a helper)
+    double *dsmbox; size_t dsmbox_elems; // strip mailboxes, one per diagonal block (panel_pair_kernel's next-diagonal-block update)
     double *dmbox; size_t dmbox_elems;   // one mailbox per tile (mbox_reset): the engine's pair mode, the panel kernel and potrf_solve's
                                          // followers read a tile's factor from there while it is being formed
     bool follow_used, follow_off;        // the operation being enqueued used launch_potrf_follow; it timed out once on this handle: off
@@ -392,6 +393,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->ev_eng) hipEventDestroy(f->ev_eng);
         hipFree(f->dflags);
         if (f->dmbox) hipFree(f->dmbox);
+        if (f->dsmbox) hipFree(f->dsmbox);
         hipFree(f->dP); hipFree(f->dWt); hipFree(f->ddag); hipFree(f->ddag_steps); hipFree(f->ddag_trace); hipFree(f->dpart);
         hipFree(f->ddag_chain);
         hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_thi);
@@ -1002,6 +1004,8 @@ struct Tunables {
                              // panel_pair_kernel); 0 = solve | in-panel update | solve, three launches
     int panel_follow = 1;    // COCONS_PANEL_FOLLOW: 1 = the one-launch panel's strips follow the engine's tiles through their mailboxes
                              // (pair mode) instead of waiting for out[t] / out[t+1] and fetching the factor
+    int panel_diag = 1;      // COCONS_PANEL_DIAG: 1 = the one-launch panel also updates the NEXT diagonal block (extra workgroups that
+                             // follow its first strips through a strip mailbox) and the update launch behind it leaves those tiles alone
     int potrf_follow = 1;    // COCONS_POTRF_FOLLOW: 1 = a tile factorisation and the panel solve below it are ONE launch whose solve
                              // workgroups follow the factorisation through a mailbox (chol.hip: potrf_follow_kernel; the plain and
                              // the band-limited schedule); 0 = two launches
@@ -1030,6 +1034,7 @@ static Tunables &tun()
         rd("COCONS_PANEL_FUSED", t.panel_fused);
         rd("COCONS_POTRF_FOLLOW", t.potrf_follow);
         rd("COCONS_PANEL_FOLLOW", t.panel_follow);
+        rd("COCONS_PANEL_DIAG", t.panel_diag);
         if (t.dag_helpers < 1) t.dag_helpers = 1;
         if (t.dag_helpers > 24) t.dag_helpers = 24;
         t.init = true;
@@ -1064,6 +1069,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "panel_fused") t.panel_fused = value;
     else if (k == "potrf_follow") t.potrf_follow = value;
     else if (k == "panel_follow") t.panel_follow = value;
+    else if (k == "panel_diag") t.panel_diag = value;
     else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
@@ -1101,7 +1107,8 @@ static bool engine_enabled() { return tun().engine != 0; }
 // one trailing-update launch (tile columns [t0, t1) of the trapezoid below (t0, t0)), optionally
 // bracketed by timing events (profile runs): appended as (start, stop)
 static void timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int t0, int t1, hipStream_t s,
-                         std::vector<hipEvent_t> *ev_upd, unsigned *sig, int sig_tile, unsigned *queue = nullptr)
+                         std::vector<hipEvent_t> *ev_upd, unsigned *sig, int sig_tile, unsigned *queue = nullptr,
+                         int skip_tiles = 0)      // > 0: the diagonal block at t0 (that many tiles) was updated by the panel's launch
 {
     const int mt = v.mt;
     if (t1 <= t0) return;
@@ -1118,7 +1125,7 @@ static void timed_update(cocons_fit *f, const FactorView &v, int k, int kw, int 
     // nothing to the trailing matrix, so the update starts behind them (whole 16-column chunks; bit-identical)
     const int kskip = (k == 0 && !v.hi) ? (f->pad0 / 16) * 16 : 0;
     launch_update(v.A, v.lda, k * TILE + kskip, kw * TILE - kskip, t0, mt, t0, t1, true, s, sig, sig_tile, nullptr,
-                  abort_word, queue, hb, v.nt, 0, v.trim);
+                  abort_word, queue, hb, v.nt, 0, v.trim, skip_tiles > 0 ? 2 * t0 : 0, skip_tiles > 0 ? 2 * (t0 + skip_tiles) : 0);
     if (ev_upd) {
         hipEventRecord(b, s);
         ev_upd->push_back(a); ev_upd->push_back(b);
@@ -1174,6 +1181,18 @@ static int mbox_reset(cocons_fit *f, int nt)
         f->dmbox_elems = need;
     }
     HIPCHK(hipMemsetAsync(f->dmbox, 0xff, need * sizeof(double), f->stream));
+    if (tun().panel_diag && tun().panel_follow && tun().panel_fused && tun().engine_pair) {
+        // ... and the strip mailboxes of the panel launches (0.5 MB per diagonal block)
+        const size_t sneed = ((size_t)nt / 2 + 2) * PANEL_SMBOX_DOUBLES;
+        if (f->dsmbox_elems < sneed) {
+            HIPCHK(hipStreamSynchronize(f->stream));
+            if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
+            if (f->dsmbox) { HIPCHK(hipFree(f->dsmbox)); f->dsmbox = nullptr; f->dsmbox_elems = 0; }
+            HIPCHK(hipMalloc(&f->dsmbox, sneed * sizeof(double)));
+            f->dsmbox_elems = sneed;
+        }
+        HIPCHK(hipMemsetAsync(f->dsmbox, 0xff, sneed * sizeof(double), f->stream));
+    }
     return 0;
 }
 
@@ -1544,6 +1563,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     // panel as products with explicit inverses published by the engine (round 3's COCONS_PANEL_MODE 1-3: +-1 %, deleted
     // in round 4))
     const int rend = mt * TILE - 64 * v.trim;         // one past the last row any panel kernel touches
+    int diag_done = 0;                                // tiles of the diagonal block at t that the previous panel's launch has updated
     for (int k = k_first > 0 ? k_first - 2 : 0; k + 2 < nt; k += 2) {
         const int t = k + 2;
         const bool two = t + 1 < nt;                 // the block has a second tile
@@ -1552,14 +1572,23 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         const int br = hb >= 0 ? hb * TILE : -1, er = nt * TILE;
         if (k >= k_first) {                          // (the update with the last DAG step's panel was that launch's)
             if (ev_upd) count_update_flops(f, 2, t);
-            timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k));
+            timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), diag_done);
         }
+        diag_done = 0;
         if (two && hb < 0 && tun().panel_fused) {
             const bool fol = f->engine_pair_live && tun().panel_follow && f->dmbox != nullptr;
+            // the next diagonal block (tiles t + 2, t + 3), when there is one, is updated inside this launch; the update launch of
+            // the next round leaves it alone
+            const int next_tiles = t + 2 < nt ? (t + 3 < nt ? 2 : 1) : 0;
+            const bool dg = fol && tun().panel_diag && next_tiles > 0 && f->dsmbox != nullptr && k + 4 < nt &&
+                            ((size_t)(t >> 1) + 1) * PANEL_SMBOX_DOUBLES <= f->dsmbox_elems;
             launch_panel_pair(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048,
                               f->dinv + (size_t)((t + 1) & 1) * 2048, out + t, xr + t, out + t + 1, abort_word, M,
                               fol ? f->dmbox + (size_t)t * ENGINE_MBOX_DOUBLES : nullptr,
-                              fol ? f->dmbox + (size_t)(t + 1) * ENGINE_MBOX_DOUBLES : nullptr);
+                              fol ? f->dmbox + (size_t)(t + 1) * ENGINE_MBOX_DOUBLES : nullptr,
+                              dg ? f->dsmbox + (size_t)(t >> 1) * PANEL_SMBOX_DOUBLES : nullptr, dg ? (next_tiles == 2 ? 10 : 3) : 0,
+                              in, t + 2);
+            if (dg && (rend - r0 * TILE) / 64 >= (next_tiles == 2 ? 4 : 2)) diag_done = next_tiles;
             continue;
         }
         launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048, M,

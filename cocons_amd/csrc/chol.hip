@@ -1151,7 +1151,8 @@ __device__ __forceinline__ void fetch_factor_tile(const double *A, size_t lda, i
 // update_kernel does): bit-identical.
 __global__ void __launch_bounds__(256)
 panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const double *q1, unsigned *out0, unsigned *xrw,
-                  unsigned *out1, unsigned *abort_word, const double *mb0, const double *mb1)
+                  unsigned *out1, unsigned *abort_word, const double *mb0, const double *mb1,
+                  double *smb, int nstrip, int npub, unsigned *sig, int sig_tile)
 {
     // 136 KB: L of the current tile (36 blocks) and its Q operands (8) -- or, between the two solves, all 64 blocks of X(t+1,t)
     __shared__ double SM[68 * 256];
@@ -1159,7 +1160,88 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
     double *SL = SM, *QS = SM + 36 * 256, *XS = SM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c1 = c0 + TILE;
+    if ((int)blockIdx.x >= nstrip) {
+        // ---- the NEXT diagonal block's update, inside this launch (COCONS_PANEL_DIAG): workgroup nstrip + dd takes the dd-th of its
+        // ten (three) 64 x 64 tiles, C(ta, tb) -= sum_k X(ta, k) X(tb, k)^T over the sixteen 16-column blocks of this panel -- and
+        // FOLLOWS the strips that form them: the first npub strip workgroups publish every finished 16 x 16 block of X in a strip
+        // mailbox (smb: strip, column block, wave; filled with ~0 like the tiles' mailboxes), and a wave here reads its five blocks
+        // of a column block until none of their words is the fill pattern.  No barrier, no LDS: a wave owns 16 rows of the tile.
+        // The tile is complete ~2 round trips behind the second diagonal tile's last block and raises the engine's input word
+        // itself; the trailing update that follows leaves these tiles alone (its first tiles, ~10 us of latency-bound products
+        // behind a kernel boundary, were what the engine's next block waited for).  Accumulated from zero over ascending k and
+        // subtracted once, like update_kernel: bit-identical.
+        const int dd = (int)blockIdx.x - nstrip;
+        const int ta = c_tri_ib[dd], tb = dd - ta * (ta + 1) / 2;
+        const int rI = r0 + 64 * ta + 16 * wave, cJ = r0 + 64 * tb;
+        d4 C[4], acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            C[c] = glb_blk(A, lda, rI, cJ + 16 * c, lane);
+            acc[c] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+        const double *pi = smb + ((size_t)ta * 16 * 4 + wave) * 256 + lane;      // + k * 1024: block (ta, k, wave)
+        const double *pj = smb + ((size_t)tb * 16 * 4) * 256 + lane;             // + k * 1024 + c * 256
+        double x[2][20];
+#define DIAG_FETCH(kk, buf)                                                                                    \
+        {                                                                                                      \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) x[buf][r] = load_wt(pi + (size_t)(kk) * 1024 + 64 * r); \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                       \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                   \
+                    x[buf][4 + 4 * c + r] = load_wt(pj + (size_t)(kk) * 1024 + 256 * c + 64 * r);                \
+        }
+        DIAG_FETCH(0, 0)
+        bool good = true;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int cur = k & 1;
+            for (unsigned it = 0; good; ++it) {
+                bool missing = false;
+#pragma unroll
+                for (int e = 0; e < 20; ++e) missing = missing || __double_as_longlong(x[cur][e]) == -1ll;
+                if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
+                const bool late_ = it > (unsigned)(ENGINE_TIMEOUT_TICKS / 100ull);
+                if (late_ || ((it & 7u) == 7u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    if (late_ && lane == 0) __hip_atomic_store(abort_word, 0x7e0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    good = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                if ((it & 7u) == 7u) {
+#pragma unroll
+                    for (int e = 0; e < 20; ++e)
+                        if (__double_as_longlong(x[cur][e]) == -1ll) {
+                            const double *ad = e < 4 ? pi + (size_t)k * 1024 + 64 * e
+                                                     : pj + (size_t)k * 1024 + 256 * ((e - 4) >> 2) + 64 * ((e - 4) & 3);
+                            x[cur][e] = __longlong_as_double((long long)__hip_atomic_fetch_or(
+                                (unsigned long long *)const_cast<double *>(ad), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        }
+                } else
+                    DIAG_FETCH(k, cur)
+            }
+            if (k + 1 < 16) DIAG_FETCH(k + 1, cur ^ 1)
+            d4 Xi = {x[cur][0], x[cur][1], x[cur][2], x[cur][3]};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                d4 Xj = {x[cur][4 + 4 * c], x[cur][5 + 4 * c], x[cur][6 + 4 * c], x[cur][7 + 4 * c]};
+                blk_mma(acc[c], Xi, Xj);
+            }
+        }
+#undef DIAG_FETCH
+        if (tid == 0) ok = 1;
+        __syncthreads();
+        if (!good && lane == 0) ok = 0;
+        __syncthreads();
+        if (!ok) return;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) glb_blk_store_wt(A, lda, rI, cJ + 16 * c, lane, C[c] - acc[c]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) signal_add(sig + sig_tile + (ta >> 1));
+        return;
+    }
     const int rs = r0 + 64 * (int)blockIdx.x + 16 * wave;
+    const bool pub = smb != nullptr && (int)blockIdx.x < npub;
+    double *sp = smb + ((size_t)blockIdx.x * 16 * 4 + wave) * 256;      // + k * 1024: this wave's block of column block k
     d4 B0[8], B1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) B0[j] = glb_blk(A, lda, rs, c0 + 16 * j, lane);
@@ -1191,6 +1273,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
 #pragma unroll
             for (int s = 0; s < 4; ++s) Q[s] = LS[(8 - j) * 256 + s * 64 + lane];
             trsm16(B0[j], L, Q);
+            if (pub) mbox_store(sp + (size_t)j * 1024, lane, B0[j]);
             d4 NX = -B0[j];
 #pragma unroll
             for (int jj = j + 1; jj < 8; ++jj) {
@@ -1279,6 +1362,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
 #pragma unroll
             for (int s = 0; s < 4; ++s) Q[s] = LS[(8 - j) * 256 + s * 64 + lane];
             trsm16(B1[j], L, Q);
+            if (pub) mbox_store(sp + (size_t)(8 + j) * 1024, lane, B1[j]);
             d4 NX = -B1[j];
 #pragma unroll
             for (int jj = j + 1; jj < 8; ++jj) {
@@ -1487,7 +1571,17 @@ update_kernel(UpdArgs a)
         }
         // sharded path (static launches only): the rows of this rank's 256-row blocks, minus a diagonal block done ahead
         if (a.world > 1 && ((ti * TM / (2 * TILE) / a.ptiles) % a.world) != a.rank) return;
-        if (ti >= a.skip_lo && ti < a.skip_hi && tj >= a.skip_lo && tj < a.skip_hi) return;
+        if (ti >= a.skip_lo && ti < a.skip_hi && tj >= a.skip_lo && tj < a.skip_hi) {
+            // (a tile somebody else takes care of -- sharded path: a diagonal block done ahead; engine schedule, round 5: the next
+            // diagonal block, updated inside the panel's launch, panel_pair_kernel)
+            if (!a.queue) return;
+            if (t2 == 0) *share = gridDim.x + __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            L = (unsigned)__builtin_amdgcn_readfirstlane((int)*share);
+            __syncthreads();
+            if (L >= a.ntiles) break;
+            continue;
+        }
         // does this tile lie inside the diagonal block the engine is waiting for?
         const int sig_Ti = (ti * TM) / TILE - a.sig_tile, sig_Tj = (tj * TM) / TILE - a.sig_tile;
         const bool sig_wg = a.sig != nullptr && sig_Ti >= 0 && sig_Ti <= 1 && sig_Tj >= 0 && sig_Tj <= sig_Ti;
@@ -2621,11 +2715,16 @@ void launch_potrf_follow(double *A, size_t lda, int c0, int r0, int r1, double *
 }
 
 void launch_panel_pair(double *A, size_t lda, int c0, int r0, int r1, const double *q0, const double *q1, unsigned *out0,
-                       unsigned *xr, unsigned *out1, unsigned *abort_word, hipStream_t s, const double *mb0, const double *mb1)
+                       unsigned *xr, unsigned *out1, unsigned *abort_word, hipStream_t s, const double *mb0, const double *mb1,
+                       double *smb, int ndiag, unsigned *sig, int sig_tile)
 {
     const int nb = (r1 - r0) / 64;
     if (nb <= 0) return;
-    hipLaunchKernelGGL(panel_pair_kernel, dim3(nb), dim3(256), 0, s, A, lda, c0, r0, q0, q1, out0, xr, out1, abort_word, mb0, mb1);
+    // (ndiag = 10 or 3: the next diagonal block -- two tiles or one -- is updated by as many extra workgroups, which follow the
+    // first 4 or 2 strips through the strip mailbox smb; needs the tiles' mailboxes)
+    const bool diag = smb && mb0 && mb1 && ndiag > 0 && nb >= (ndiag == 10 ? 4 : 2);
+    hipLaunchKernelGGL(panel_pair_kernel, dim3(nb + (diag ? ndiag : 0)), dim3(256), 0, s, A, lda, c0, r0, q0, q1, out0, xr, out1,
+                       abort_word, mb0, mb1, diag ? smb : nullptr, nb, diag ? (ndiag == 10 ? 4 : 2) : 0, sig, sig_tile);
 }
 
 // waves per workgroup of the trailing update (COCONS_UPD_WAVES: 4 or 8, see update_kernel's NW)
@@ -2841,10 +2940,10 @@ void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagSte
 void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int tj0, int tj1,
                    bool lower_only, hipStream_t s, unsigned *sig, int sig_tile,
                    unsigned *wait_word, unsigned *abort_word, unsigned *queue, int band_hi, int ext0,
-                   int skew, int trim64)
+                   int skew, int trim64, int skip_lo, int skip_hi)
 {
     launch_update_from(A, lda, A + (size_t)k0 * lda, lda, K, ti0, ti1, tj0, tj1, lower_only, s, 1, 1, 0, sig, sig_tile,
-                       wait_word, abort_word, queue, band_hi, ext0, skew, k0 / TILE, trim64);
+                       wait_word, abort_word, queue, band_hi, ext0, skew, k0 / TILE, trim64, nullptr, skip_lo, skip_hi);
 }
 
 void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, int row0, int nr,

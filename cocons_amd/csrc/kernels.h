@@ -158,7 +158,12 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
 // mb0, mb1 (both or neither): the two tiles' mailboxes (the engine's pair mode): the strips follow the tiles while they are formed
 void launch_panel_pair(double *A, size_t lda, int c0, int r0, int r1, const double *q0, const double *q1, unsigned *out0,
                        unsigned *xr, unsigned *out1, unsigned *abort_word, hipStream_t s, const double *mb0 = nullptr,
-                       const double *mb1 = nullptr);
+                       const double *mb1 = nullptr,
+                       double *smb = nullptr, int ndiag = 0, unsigned *sig = nullptr, int sig_tile = 0);
+// smb (PANEL_SMBOX_DOUBLES doubles, every byte 0xff beforehand) + ndiag = 10 or 3: the launch also updates the NEXT diagonal
+// block (two tiles or one) with this panel and raises sig[sig_tile] (+3) / sig[sig_tile + 1] (+7) like launch_update's tiles
+// inside the diagonal block do; the update launch that follows must leave those tiles alone (skip_lo / skip_hi)
+constexpr size_t PANEL_SMBOX_DOUBLES = 4 * 16 * 4 * 256;
 // C(i,j) -= sum_{k in [k0,k0+K)} A(i,k) A(j,k) for tiles with tile-row in [ti0,ti1),
 // tile-col in [tj0,tj1); lower_only keeps ti >= tj.  All tile indices in units of TILE.
 // sig / sig_tile: hand-off to the engine (sig = the in[] array, sig_tile = even tile of the diagonal block);
@@ -170,8 +175,10 @@ void launch_update(double *A, size_t lda, int k0, int K, int ti0, int ti1, int t
                    unsigned *wait_word = nullptr, unsigned *abort_word = nullptr, unsigned *queue = nullptr,
                    int band_hi = -1, int ext0 = 0,       // band_hi >= 0: tile rows [ti0, band_hi) and [ext0, ti1)
                    int skew = 0,           // packed band buffer (band_index; with band_hi / ext0): A is its unshifted base
-                   int trim64 = 0);        // 1: the last 64 rows of the row range hold nothing (a 128-row tile of right-hand
+                   int trim64 = 0,         // 1: the last 64 rows of the row range hold nothing (a 128-row tile of right-hand
                                            // sides of which at most 64 rows are used): they are not updated
+                   int skip_lo = 0, int skip_hi = 0);   // tiles with both 64-row and 64-column index in [skip_lo, skip_hi) are left
+                                                        // alone (the next diagonal block, when the panel's launch has updated it)
 // waves per workgroup of the trailing-update kernel: 4 or 8 (512 threads, KC = 16: half the tile latency; default for
 // launches of at most set_update_w8_max_tiles tiles, 0 = every launch)
 void set_update_waves(int nw);
