@@ -291,7 +291,9 @@ struct cocons_fit {
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
     int dag_helpers_live;         // chain helpers in the engine launch of the factorisation being enqueued (0: none)
     int engine_pair_live;         // 1: the engine launched for the next factorisation has a pair partner (counts itself like a helper)
-    double *dsmbox; size_t dsmbox_elems; // strip mailboxes, one per diagonal block (panel_pair_kernel's next-diagonal-block update)
+    size_t smb_off, smb_elems;           // inside dmbox: strip mailboxes, one per diagonal block (the panel launch's next-diagonal-block
+                                         // update), and xmb_off: the panel launch's exchange mailboxes, one per 64-row strip (split panel)
+    size_t xmb_off, xmb_elems;
     double *dmbox; size_t dmbox_elems;   // one mailbox per tile (mbox_reset): the engine's pair mode, the panel kernel and potrf_solve's
                                          // followers read a tile's factor from there while it is being formed
     bool follow_used, follow_off;        // the operation being enqueued used launch_potrf_follow; it timed out once on this handle: off
@@ -393,7 +395,6 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         if (f->ev_eng) hipEventDestroy(f->ev_eng);
         hipFree(f->dflags);
         if (f->dmbox) hipFree(f->dmbox);
-        if (f->dsmbox) hipFree(f->dsmbox);
         hipFree(f->dP); hipFree(f->dWt); hipFree(f->ddag); hipFree(f->ddag_steps); hipFree(f->ddag_trace); hipFree(f->dpart);
         hipFree(f->ddag_chain);
         hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_thi);
@@ -944,7 +945,7 @@ static int band_hi(const FactorView &v, int k)
 static bool follow_on(cocons_fit *f);
 static void potrf_solve(cocons_fit *f, double *A, size_t lda, int tile, int r0, int r1, double *q, hipStream_t s, int br, int er)
 {
-    if (follow_on(f) && ((size_t)tile + 1) * ENGINE_MBOX_DOUBLES <= f->dmbox_elems) {
+    if (follow_on(f) && ((size_t)tile + 1) * ENGINE_MBOX_DOUBLES <= f->smb_off) {
         f->follow_used = true;
         launch_potrf_follow(A, lda, tile * TILE, r0, r1, q, f->dinfo,
                             f->dmbox + (size_t)tile * ENGINE_MBOX_DOUBLES, (unsigned *)(f->dinfo + 1), s, br, er);
@@ -1004,6 +1005,8 @@ struct Tunables {
                              // panel_pair_kernel); 0 = solve | in-panel update | solve, three launches
     int panel_follow = 1;    // COCONS_PANEL_FOLLOW: 1 = the one-launch panel's strips follow the engine's tiles through their mailboxes
                              // (pair mode) instead of waiting for out[t] / out[t+1] and fetching the factor
+    int panel_split = 1;     // COCONS_PANEL_SPLIT: 1 = a strip of the one-launch panel is TWO workgroups -- the first follows tile t (X0), the second
+                             // follows the first through an exchange mailbox (the in-panel product while X0 is being formed), then tile t+1
     int panel_diag = 1;      // COCONS_PANEL_DIAG: 1 = the one-launch panel also updates the NEXT diagonal block (extra workgroups that
                              // follow its first strips through a strip mailbox) and the update launch behind it leaves those tiles alone
     int potrf_follow = 1;    // COCONS_POTRF_FOLLOW: 1 = a tile factorisation and the panel solve below it are ONE launch whose solve
@@ -1035,6 +1038,7 @@ static Tunables &tun()
         rd("COCONS_POTRF_FOLLOW", t.potrf_follow);
         rd("COCONS_PANEL_FOLLOW", t.panel_follow);
         rd("COCONS_PANEL_DIAG", t.panel_diag);
+        rd("COCONS_PANEL_SPLIT", t.panel_split);
         if (t.dag_helpers < 1) t.dag_helpers = 1;
         if (t.dag_helpers > 24) t.dag_helpers = 24;
         t.init = true;
@@ -1045,7 +1049,7 @@ static Tunables &tun()
 static bool follow_on(cocons_fit *f)
 {
     return tun().potrf_follow != 0 && !f->follow_off && f->dmbox != nullptr &&
-           f->dmbox_elems >= ((size_t)f->nt + 2) * ENGINE_MBOX_DOUBLES;
+           f->smb_off >= ((size_t)f->nt + 2) * ENGINE_MBOX_DOUBLES;
 }
 
 extern "C" int cocons_debug_tune(const char *name, int value)
@@ -1070,6 +1074,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "potrf_follow") t.potrf_follow = value;
     else if (k == "panel_follow") t.panel_follow = value;
     else if (k == "panel_diag") t.panel_diag = value;
+    else if (k == "panel_split") t.panel_split = value;
     else if (k == "gate_sabotage") t.gate_sabotage = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
@@ -1172,7 +1177,13 @@ static int flags_reset(cocons_fit *f, int nt)
 // written yet" (every byte 0xff; potrf_tile_body: mbox) on the main stream: 88 KB each, 7.1 MB at n = 10^4
 static int mbox_reset(cocons_fit *f, int nt)
 {
-    const size_t need = ((size_t)nt + 2) * ENGINE_MBOX_DOUBLES;
+    // one allocation, one fill: the tiles' mailboxes | the strip mailboxes (0.5 MB per diagonal block) | the exchange mailboxes of
+    // the split panel (64 KB per 64-row strip of the matrix and the rows under it)
+    const size_t tiles = ((size_t)nt + 2) * ENGINE_MBOX_DOUBLES;
+    const bool panel = tun().panel_follow && tun().panel_fused && tun().engine_pair;
+    const size_t smb = panel && tun().panel_diag ? ((size_t)nt / 2 + 2) * PANEL_SMBOX_DOUBLES : 0;
+    const size_t xmb = panel && tun().panel_split ? (2 * ((size_t)nt + 2) + 4) * PANEL_XMBOX_DOUBLES : 0;
+    const size_t need = tiles + smb + xmb;
     if (f->dmbox_elems < need) {
         HIPCHK(hipStreamSynchronize(f->stream));
         if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
@@ -1180,19 +1191,9 @@ static int mbox_reset(cocons_fit *f, int nt)
         HIPCHK(hipMalloc(&f->dmbox, need * sizeof(double)));
         f->dmbox_elems = need;
     }
+    f->smb_off = tiles; f->smb_elems = smb;
+    f->xmb_off = tiles + smb; f->xmb_elems = xmb;
     HIPCHK(hipMemsetAsync(f->dmbox, 0xff, need * sizeof(double), f->stream));
-    if (tun().panel_diag && tun().panel_follow && tun().panel_fused && tun().engine_pair) {
-        // ... and the strip mailboxes of the panel launches (0.5 MB per diagonal block)
-        const size_t sneed = ((size_t)nt / 2 + 2) * PANEL_SMBOX_DOUBLES;
-        if (f->dsmbox_elems < sneed) {
-            HIPCHK(hipStreamSynchronize(f->stream));
-            if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
-            if (f->dsmbox) { HIPCHK(hipFree(f->dsmbox)); f->dsmbox = nullptr; f->dsmbox_elems = 0; }
-            HIPCHK(hipMalloc(&f->dsmbox, sneed * sizeof(double)));
-            f->dsmbox_elems = sneed;
-        }
-        HIPCHK(hipMemsetAsync(f->dsmbox, 0xff, sneed * sizeof(double), f->stream));
-    }
     return 0;
 }
 
@@ -1580,14 +1581,16 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
             // the next diagonal block (tiles t + 2, t + 3), when there is one, is updated inside this launch; the update launch of
             // the next round leaves it alone
             const int next_tiles = t + 2 < nt ? (t + 3 < nt ? 2 : 1) : 0;
-            const bool dg = fol && tun().panel_diag && next_tiles > 0 && f->dsmbox != nullptr && k + 4 < nt &&
-                            ((size_t)(t >> 1) + 1) * PANEL_SMBOX_DOUBLES <= f->dsmbox_elems;
+            const bool dg = fol && tun().panel_diag && next_tiles > 0 && k + 4 < nt &&
+                            ((size_t)(t >> 1) + 1) * PANEL_SMBOX_DOUBLES <= f->smb_elems;
+            const int nstrips = (rend - r0 * TILE) / 64;
+            const bool sp = fol && tun().panel_split && nstrips > 0 && (size_t)nstrips * PANEL_XMBOX_DOUBLES <= f->xmb_elems;
             launch_panel_pair(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048,
                               f->dinv + (size_t)((t + 1) & 1) * 2048, out + t, xr + t, out + t + 1, abort_word, M,
                               fol ? f->dmbox + (size_t)t * ENGINE_MBOX_DOUBLES : nullptr,
                               fol ? f->dmbox + (size_t)(t + 1) * ENGINE_MBOX_DOUBLES : nullptr,
-                              dg ? f->dsmbox + (size_t)(t >> 1) * PANEL_SMBOX_DOUBLES : nullptr, dg ? (next_tiles == 2 ? 10 : 3) : 0,
-                              in, t + 2);
+                              dg ? f->dmbox + f->smb_off + (size_t)(t >> 1) * PANEL_SMBOX_DOUBLES : nullptr,
+                              dg ? (next_tiles == 2 ? 10 : 3) : 0, in, t + 2, sp ? f->dmbox + f->xmb_off : nullptr);
             if (dg && (rend - r0 * TILE) / 64 >= (next_tiles == 2 ? 4 : 2)) diag_done = next_tiles;
             continue;
         }
@@ -2968,7 +2971,7 @@ static int shard_factor_diag(cocons_fit *f, int k)
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(in + t), 7, (size_t)w, s));
         // (pair mode: its two workgroups side by side -- the second tile's factorisation starts ~6 us behind the first's end
         // instead of behind the strip solve and the tile update: 78 -> ~56 us for the block)
-        const bool pair = w == 2 && tun().engine_pair && f->dmbox && f->dmbox_elems >= ((size_t)f->nt + 2) * ENGINE_MBOX_DOUBLES;
+        const bool pair = w == 2 && tun().engine_pair && f->dmbox && f->smb_off >= ((size_t)f->nt + 2) * ENGINE_MBOX_DOUBLES;
         launch_potrf_engine(A, f->lda, t, t + w, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
                             f->dflags + 3 * (size_t)f->flags_cap, s, nullptr, nullptr, 0, nullptr, nullptr, 0,
                             pair ? f->dmbox : nullptr);

@@ -694,20 +694,20 @@ for (unsigned it = 0;; ++it) {                                                  
 }
 
 // ... and for workgroups of 256 threads (the panel kernel): value tid + 256 i is element tid of block i; double v9[9].
-#define MBOX_FETCH256(jn)                                                                                                     \
+#define MBOX_FETCH256V(jn, VV)                                                                                                    \
 {                                                                                                                             \
     unsigned mo = 8u * (unsigned)tid;                                                                                         \
     asm volatile("" : "+v"(mo));                                                                                             \
     _Pragma("unroll") for (int i = 0; i < 9; ++i) {                                                                           \
-        v9[i] = 0.0;                                                                                                          \
-        if (i <= 8 - (jn)) v9[i] = load_wt((const double *)((const char *)(mb + MBOX_OFF(jn)) + (mo + 2048u * (unsigned)i))); \
+        VV[i] = 0.0;                                                                                                          \
+        if (i <= 8 - (jn)) VV[i] = load_wt((const double *)((const char *)(mb + MBOX_OFF(jn)) + (mo + 2048u * (unsigned)i))); \
     }                                                                                                                         \
 }
-#define MBOX_COMPLETE256(jn, ABORTW, CODE)                                                                                    \
+#define MBOX_COMPLETE256V(jn, VV, ABORTW, CODE)                                                                                   \
 for (unsigned it = 0;; ++it) {                                                                                                \
     bool missing = false;                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < 9; ++i)                                                                             \
-        if (i <= 8 - (jn)) missing = missing || __double_as_longlong(v9[i]) == -1ll;                                          \
+        if (i <= 8 - (jn)) missing = missing || __double_as_longlong(VV[i]) == -1ll;                                          \
     if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;                                                                  \
     const bool late_ = it > (unsigned)(ENGINE_TIMEOUT_TICKS / 100ull);                                                        \
     if (late_ || ((it & 7u) == 7u && __hip_atomic_load((ABORTW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {        \
@@ -722,13 +722,16 @@ for (unsigned it = 0;; ++it) {                                                  
         unsigned mo = 8u * (unsigned)tid;                                                                                     \
         asm volatile("" : "+v"(mo));                                                                                         \
         _Pragma("unroll") for (int i = 0; i < 9; ++i)                                                                         \
-            if (i <= 8 - (jn) && __double_as_longlong(v9[i]) == -1ll)                                                         \
-                v9[i] = __longlong_as_double((long long)__hip_atomic_fetch_or(                                                \
+            if (i <= 8 - (jn) && __double_as_longlong(VV[i]) == -1ll)                                                         \
+                VV[i] = __longlong_as_double((long long)__hip_atomic_fetch_or(                                                \
                     (unsigned long long *)((char *)const_cast<double *>(mb + MBOX_OFF(jn)) + (mo + 2048u * (unsigned)i)), 0ull, \
                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));                                                             \
     } else                                                                                                                    \
-        MBOX_FETCH256(jn)                                                                                                     \
+        MBOX_FETCH256V(jn, VV)                                                                                                     \
 }
+
+#define MBOX_FETCH256(jn) MBOX_FETCH256V(jn, v9)
+#define MBOX_COMPLETE256(jn, ABORTW, CODE) MBOX_COMPLETE256V(jn, v9, ABORTW, CODE)
 
 // The pair partner (round 5, COCONS_ENGINE_PAIR): a second workgroup of the engine's launch, on a CU of its own, that takes the
 // SECOND tile of every diagonal block -- and everything between the two tiles -- off the engine's hands, and does the part that
@@ -1152,7 +1155,7 @@ __device__ __forceinline__ void fetch_factor_tile(const double *A, size_t lda, i
 __global__ void __launch_bounds__(256)
 panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const double *q1, unsigned *out0, unsigned *xrw,
                   unsigned *out1, unsigned *abort_word, const double *mb0, const double *mb1,
-                  double *smb, int nstrip, int npub, unsigned *sig, int sig_tile)
+                  double *smb, int nstrip, int npub, unsigned *sig, int sig_tile, double *xmb)
 {
     // 136 KB: L of the current tile (36 blocks) and its Q operands (8) -- or, between the two solves, all 64 blocks of X(t+1,t)
     __shared__ double SM[68 * 256];
@@ -1160,8 +1163,17 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
     double *SL = SM, *QS = SM + 36 * 256, *XS = SM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c1 = c0 + TILE;
-    if ((int)blockIdx.x >= nstrip) {
-        // ---- the NEXT diagonal block's update, inside this launch (COCONS_PANEL_DIAG): workgroup nstrip + dd takes the dd-th of its
+    // Split panel (COCONS_PANEL_SPLIT, xmb != null): a strip is TWO workgroups.  The first (role A, block index = strip) follows tile
+    // t and forms X0 -- and publishes every finished 16 x 16 block of it in the strip's exchange mailbox; the second (role B, block
+    // index nstrip + strip) holds B1, brings X(t+1,t) into LDS and follows the first: the in-panel product advances one column
+    // block of X0 behind its formation (accumulated from zero over ascending k and subtracted once, as ever), then it follows tile
+    // t+1 for X1.  With everything there to be read a strip takes solve + 1.5 us + solve instead of solve | fetch | product |
+    // solve on one wave per SIMD: ~27 us instead of 41.  The second workgroup puts the fill pattern back into every block it has
+    // read (its only reader), the whole region is filled again with the others before the next factorisation.
+    const bool split = xmb != nullptr;
+    const int nfirst = split ? 2 * nstrip : nstrip;        // workgroups in front of the diagonal-tile ones
+    if ((int)blockIdx.x >= nfirst) {
+        // ---- the NEXT diagonal block's update, inside this launch (COCONS_PANEL_DIAG): workgroup nfirst + dd takes the dd-th of its
         // ten (three) 64 x 64 tiles, C(ta, tb) -= sum_k X(ta, k) X(tb, k)^T over the sixteen 16-column blocks of this panel -- and
         // FOLLOWS the strips that form them: the first npub strip workgroups publish every finished 16 x 16 block of X in a strip
         // mailbox (smb: strip, column block, wave; filled with ~0 like the tiles' mailboxes), and a wave here reads its five blocks
@@ -1170,7 +1182,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
         // itself; the trailing update that follows leaves these tiles alone (its first tiles, ~10 us of latency-bound products
         // behind a kernel boundary, were what the engine's next block waited for).  Accumulated from zero over ascending k and
         // subtracted once, like update_kernel: bit-identical.
-        const int dd = (int)blockIdx.x - nstrip;
+        const int dd = (int)blockIdx.x - nfirst;
         const int ta = c_tri_ib[dd], tb = dd - ta * (ta + 1) / 2;
         const int rI = r0 + 64 * ta + 16 * wave, cJ = r0 + 64 * tb;
         d4 C[4], acc[4];
@@ -1239,14 +1251,139 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
         if (tid == 0) signal_add(sig + sig_tile + (ta >> 1));
         return;
     }
-    const int rs = r0 + 64 * (int)blockIdx.x + 16 * wave;
-    const bool pub = smb != nullptr && (int)blockIdx.x < npub;
-    double *sp = smb + ((size_t)blockIdx.x * 16 * 4 + wave) * 256;      // + k * 1024: this wave's block of column block k
+    const bool roleB = split && (int)blockIdx.x >= nstrip;
+    const int strip = (int)blockIdx.x - (roleB ? nstrip : 0);
+    const int rs = r0 + 64 * strip + 16 * wave;
+    const bool pub = smb != nullptr && strip < npub;
+    double *sp = smb + ((size_t)strip * 16 * 4 + wave) * 256;          // + k * 1024: this wave's block of column block k
+    double *xp = split ? xmb + ((size_t)strip * 8 * 4 + wave) * 256 : nullptr;      // + k * 1024: the exchange mailbox, likewise
+    if (roleB) {
+        // ---- role B: B1 -= X0 X(t+1,t)^T behind role A's X0, then X1 = B1 L(t+1)^-T behind tile t+1
+        int *okp = &ok;
+        d4 B1[8], acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            B1[j] = glb_blk(A, lda, rs, c1 + 16 * j, lane);
+            acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+        if (tid == 0) ok = wait_ge<false>(xrw, 1u, abort_word, 0x500u + c0 / TILE) ? 1 : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!ok) return;
+        {
+            const int i = tid & 15, k = tid >> 4;
+            const double *Xg = A + (size_t)(c1 + i) + (size_t)(c0 + k) * lda;
+            double st[2][16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) st[0][b] = load_wt(Xg + (size_t)(16 * (b >> 3)) + (size_t)(16 * (b & 7)) * lda);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r + 1 < 4) {
+#pragma unroll
+                    for (int b = 0; b < 16; ++b) {
+                        const int bb = 16 * (r + 1) + b;
+                        st[(r + 1) & 1][b] = load_wt(Xg + (size_t)(16 * (bb >> 3)) + (size_t)(16 * (bb & 7)) * lda);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 16; ++b) XS[(16 * r + b) * 256 + k * 16 + i] = st[r & 1][b];
+            }
+        }
+        __syncthreads();
+        {
+            // (a wave follows its own 16 rows of X0: no barrier; the block is put back to the fill pattern once it is in registers)
+            const double *xq = xp + lane;
+            double x[2][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[0][r] = load_wt(xq + 64 * r);
+            bool good = true;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int cur = kb & 1;
+                for (unsigned it = 0; good; ++it) {
+                    bool missing = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) missing = missing || __double_as_longlong(x[cur][r]) == -1ll;
+                    if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
+                    const bool late_ = it > (unsigned)(ENGINE_TIMEOUT_TICKS / 100ull);
+                    if (late_ || ((it & 7u) == 7u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        if (late_ && lane == 0) __hip_atomic_store(abort_word, 0x7d0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        good = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double *ad = xq + (size_t)kb * 1024 + 64 * r;
+                        if ((it & 7u) == 7u) {
+                            if (__double_as_longlong(x[cur][r]) == -1ll)
+                                x[cur][r] = __longlong_as_double((long long)__hip_atomic_fetch_or(
+                                    (unsigned long long *)const_cast<double *>(ad), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        } else
+                            x[cur][r] = load_wt(ad);
+                    }
+                }
+                if (kb + 1 < 8) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[cur ^ 1][r] = load_wt(xq + (size_t)(kb + 1) * 1024 + 64 * r);
+                }
+                if (good) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) store_wt(const_cast<double *>(xq) + (size_t)kb * 1024 + 64 * r, __longlong_as_double(-1ll));
+                }
+                d4 Xk = {x[cur][0], x[cur][1], x[cur][2], x[cur][3]};
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    d4 Xb = lds_blk(XS + (jj * 8 + kb) * 256, lane);
+                    blk_mma(acc[jj], Xk, Xb);
+                }
+            }
+            if (!good && lane == 0) ok = 0;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) B1[jj] = B1[jj] - acc[jj];
+        {
+            const double *mb = mb1;
+            double v9[3][9];
+            __syncthreads();             // (every wave is done with X(t+1,t): the stages overlay it; and the product's verdict is in)
+            if (!ok) return;
+            MBOX_FETCH256V(0, v9[0])
+            MBOX_FETCH256V(1, v9[1])
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                double *LS = SM + (j & 1) * (9 * 256);
+                MBOX_COMPLETE256V(j, v9[j % 3], abort_word, 0x300u + c1 / TILE)
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+                    if (i <= 8 - j) LS[tid + 256 * i] = v9[j % 3][i];
+                __syncthreads();
+                if (!ok) return;
+                if (j + 2 < 8) MBOX_FETCH256V(j + 2, v9[(j + 2) % 3])
+                d4 L = lds_blk(LS, lane);
+                double Q[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Q[s] = LS[(8 - j) * 256 + s * 64 + lane];
+                trsm16(B1[j], L, Q);
+                if (pub) mbox_store(sp + (size_t)(8 + j) * 1024, lane, B1[j]);
+                d4 NX = -B1[j];
+#pragma unroll
+                for (int jj = j + 1; jj < 8; ++jj) {
+                    d4 Lb = lds_blk(LS + (jj - j) * 256, lane);
+                    blk_mma(B1[jj], NX, Lb);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c1 + 16 * j, lane, B1[j]);
+        return;
+    }
     d4 B0[8], B1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) B0[j] = glb_blk(A, lda, rs, c0 + 16 * j, lane);
+    if (!split) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) B1[j] = glb_blk(A, lda, rs, c1 + 16 * j, lane);
+        for (int j = 0; j < 8; ++j) B1[j] = glb_blk(A, lda, rs, c1 + 16 * j, lane);
+    }
     // ---- X0 = B0 L(t)^-T
     int *okp = &ok;
     if (mb0) {
@@ -1254,26 +1391,28 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
         // block by column block (like potrf_follow_kernel's workgroups) and is solved a round trip behind the tile's last block,
         // where waiting for out[t], fetching the factor and solving took ~8 us behind it
         const double *mb = mb0;
-        double v9[9];
-        if (tid == 0) ok = 1;
+        double v9[3][9];             // (TWO column blocks in flight: with the tile already there a column block costs its solve,
+        if (tid == 0) ok = 1;        // not a round trip)
         __syncthreads();
-        MBOX_FETCH256(0)
+        MBOX_FETCH256V(0, v9[0])
+        MBOX_FETCH256V(1, v9[1])
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             double *LS = SM + (j & 1) * (9 * 256);
-            MBOX_COMPLETE256(j, abort_word, 0x300u + c0 / TILE)
+            MBOX_COMPLETE256V(j, v9[j % 3], abort_word, 0x300u + c0 / TILE)
 #pragma unroll
             for (int i = 0; i < 9; ++i)
-                if (i <= 8 - j) LS[tid + 256 * i] = v9[i];
+                if (i <= 8 - j) LS[tid + 256 * i] = v9[j % 3][i];
             __syncthreads();
             if (!ok) return;
-            if (j < 7) MBOX_FETCH256(j + 1)
+            if (j + 2 < 8) MBOX_FETCH256V(j + 2, v9[(j + 2) % 3])
             d4 L = lds_blk(LS, lane);
             double Q[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) Q[s] = LS[(8 - j) * 256 + s * 64 + lane];
             trsm16(B0[j], L, Q);
             if (pub) mbox_store(sp + (size_t)j * 1024, lane, B0[j]);
+            if (split) mbox_store(xp + (size_t)j * 1024, lane, B0[j]);
             d4 NX = -B0[j];
 #pragma unroll
             for (int jj = j + 1; jj < 8; ++jj) {
@@ -1305,6 +1444,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) glb_blk_store(A, lda, rs, c0 + 16 * j, lane, B0[j]);
+    if (split) return;               // (role A: the rest of the strip is role B's)
     // ---- B1 -= X0 X(t+1,t)^T: all 64 blocks of X(t+1,t) into LDS (over the image of L(t), which is dead), four rounds of sixteen
     // loads per thread with the next round in flight while one is stored
     if (tid == 0) ok = wait_ge<false>(xrw, 1u, abort_word, 0x500u + c0 / TILE) ? 1 : 0;
@@ -1344,19 +1484,20 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
     // ---- X1 = B1 L(t+1)^-T
     if (mb1) {
         const double *mb = mb1;
-        double v9[9];
+        double v9[3][9];
         __syncthreads();             // (every wave is done with X(t+1,t): the stages overlay it)
-        MBOX_FETCH256(0)
+        MBOX_FETCH256V(0, v9[0])
+        MBOX_FETCH256V(1, v9[1])
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             double *LS = SM + (j & 1) * (9 * 256);
-            MBOX_COMPLETE256(j, abort_word, 0x300u + c1 / TILE)
+            MBOX_COMPLETE256V(j, v9[j % 3], abort_word, 0x300u + c1 / TILE)
 #pragma unroll
             for (int i = 0; i < 9; ++i)
-                if (i <= 8 - j) LS[tid + 256 * i] = v9[i];
+                if (i <= 8 - j) LS[tid + 256 * i] = v9[j % 3][i];
             __syncthreads();
             if (!ok) return;
-            if (j < 7) MBOX_FETCH256(j + 1)
+            if (j + 2 < 8) MBOX_FETCH256V(j + 2, v9[(j + 2) % 3])
             d4 L = lds_blk(LS, lane);
             double Q[4];
 #pragma unroll
@@ -2716,15 +2857,17 @@ void launch_potrf_follow(double *A, size_t lda, int c0, int r0, int r1, double *
 
 void launch_panel_pair(double *A, size_t lda, int c0, int r0, int r1, const double *q0, const double *q1, unsigned *out0,
                        unsigned *xr, unsigned *out1, unsigned *abort_word, hipStream_t s, const double *mb0, const double *mb1,
-                       double *smb, int ndiag, unsigned *sig, int sig_tile)
+                       double *smb, int ndiag, unsigned *sig, int sig_tile, double *xmb)
 {
     const int nb = (r1 - r0) / 64;
     if (nb <= 0) return;
+    const bool split = xmb && mb0 && mb1;         // (two workgroups per strip: see the kernel)
     // (ndiag = 10 or 3: the next diagonal block -- two tiles or one -- is updated by as many extra workgroups, which follow the
     // first 4 or 2 strips through the strip mailbox smb; needs the tiles' mailboxes)
     const bool diag = smb && mb0 && mb1 && ndiag > 0 && nb >= (ndiag == 10 ? 4 : 2);
-    hipLaunchKernelGGL(panel_pair_kernel, dim3(nb + (diag ? ndiag : 0)), dim3(256), 0, s, A, lda, c0, r0, q0, q1, out0, xr, out1,
-                       abort_word, mb0, mb1, diag ? smb : nullptr, nb, diag ? (ndiag == 10 ? 4 : 2) : 0, sig, sig_tile);
+    hipLaunchKernelGGL(panel_pair_kernel, dim3((split ? 2 * nb : nb) + (diag ? ndiag : 0)), dim3(256), 0, s, A, lda, c0, r0, q0, q1,
+                       out0, xr, out1, abort_word, mb0, mb1, diag ? smb : nullptr, nb, diag ? (ndiag == 10 ? 4 : 2) : 0, sig, sig_tile,
+                       split ? xmb : nullptr);
 }
 
 // waves per workgroup of the trailing update (COCONS_UPD_WAVES: 4 or 8, see update_kernel's NW)

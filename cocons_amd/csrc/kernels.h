@@ -159,7 +159,10 @@ void launch_trsm_tile(double *A, size_t lda, int c0, int r0, int r1, const doubl
 void launch_panel_pair(double *A, size_t lda, int c0, int r0, int r1, const double *q0, const double *q1, unsigned *out0,
                        unsigned *xr, unsigned *out1, unsigned *abort_word, hipStream_t s, const double *mb0 = nullptr,
                        const double *mb1 = nullptr,
-                       double *smb = nullptr, int ndiag = 0, unsigned *sig = nullptr, int sig_tile = 0);
+                       double *smb = nullptr, int ndiag = 0, unsigned *sig = nullptr, int sig_tile = 0,
+                       double *xmb = nullptr);   // split panel: exchange mailboxes, PANEL_XMBOX_DOUBLES per 64-row strip, every byte
+                                                 // 0xff (the second workgroup of a strip puts the pattern back as it reads)
+constexpr size_t PANEL_XMBOX_DOUBLES = 8 * 4 * 256;
 // smb (PANEL_SMBOX_DOUBLES doubles, every byte 0xff beforehand) + ndiag = 10 or 3: the launch also updates the NEXT diagonal
 // block (two tiles or one) with this panel and raises sig[sig_tile] (+3) / sig[sig_tile + 1] (+7) like launch_update's tiles
 // inside the diagonal block do; the update launch that follows must leave those tiles alone (skip_lo / skip_hi)

@@ -350,6 +350,9 @@ def test_fused_panel_same_bits_as_three_launches(gx, gy):
         _lib.check(L.cocons_debug_tune(b"panel_fused", 1), "tune")
         v1, p1 = fit.neg2loglik_core(th)
         assert fit.engine_state()["active"]
+        _lib.check(L.cocons_debug_tune(b"panel_split", 0), "tune")       # (one workgroup per strip instead of two)
+        v4, p4 = fit.neg2loglik_core(th)
+        assert v4 == v1 and np.array_equal(p4, p1)
         _lib.check(L.cocons_debug_tune(b"panel_diag", 0), "tune")        # (the next diagonal block by the update launch again)
         v3, p3 = fit.neg2loglik_core(th)
         assert v3 == v1 and np.array_equal(p3, p1)
@@ -364,6 +367,7 @@ def test_fused_panel_same_bits_as_three_launches(gx, gy):
         _lib.check(L.cocons_debug_tune(b"panel_fused", int(os.environ.get("COCONS_PANEL_FUSED", "1"))), "tune")
         _lib.check(L.cocons_debug_tune(b"panel_follow", int(os.environ.get("COCONS_PANEL_FOLLOW", "1"))), "tune")
         _lib.check(L.cocons_debug_tune(b"panel_diag", int(os.environ.get("COCONS_PANEL_DIAG", "1"))), "tune")
+        _lib.check(L.cocons_debug_tune(b"panel_split", int(os.environ.get("COCONS_PANEL_SPLIT", "1"))), "tune")
 
 
 @pytest.mark.parametrize("gx,gy,engine", [(20, 20, 1), (33, 31, 0), (45, 47, 0), (64, 64, 0)])
