@@ -1005,8 +1005,11 @@ struct Tunables {
                              // panel_pair_kernel); 0 = solve | in-panel update | solve, three launches
     int panel_follow = 1;    // COCONS_PANEL_FOLLOW: 1 = the one-launch panel's strips follow the engine's tiles through their mailboxes
                              // (pair mode) instead of waiting for out[t] / out[t+1] and fetching the factor
-    int panel_split = 1;     // COCONS_PANEL_SPLIT: 1 = a strip of the one-launch panel is TWO workgroups -- the first follows tile t (X0), the second
-                             // follows the first through an exchange mailbox (the in-panel product while X0 is being formed), then tile t+1
+    int panel_split = 32;    // COCONS_PANEL_SPLIT: a strip of the one-launch panel is TWO workgroups -- the first follows tile t (X0), the second
+                             // follows the first through an exchange mailbox (the in-panel product while X0 is being formed), then tile
+                             // t+1 -- in panels of at least this many 64-row strips (0: never, 1: always).  It pays where the panel stands
+                             // exposed behind a long update launch (n = 4096: +1.9 %, 6400: +1.5 %, 10^4: +0.6 %) and costs where the engine
+                             // is the bound anyway (always on: n = 2116 -4.3 %, n = 1024 -2.2 %); an update of 32 strips' trapezoid is ~30 us
     int panel_diag = 1;      // COCONS_PANEL_DIAG: 1 = the one-launch panel also updates the NEXT diagonal block (extra workgroups that
                              // follow its first strips through a strip mailbox) and the update launch behind it leaves those tiles alone
     int potrf_follow = 1;    // COCONS_POTRF_FOLLOW: 1 = a tile factorisation and the panel solve below it are ONE launch whose solve
@@ -1175,7 +1178,7 @@ static int flags_reset(cocons_fit *f, int nt)
 
 // the tiles' mailboxes (the engine's pair mode, the panel kernel, potrf_solve's followers) filled with the pattern that means "not
 // written yet" (every byte 0xff; potrf_tile_body: mbox) on the main stream: 88 KB each, 7.1 MB at n = 10^4
-static int mbox_reset(cocons_fit *f, int nt)
+static int mbox_reset(cocons_fit *f, int nt, bool engine_schedule = true)
 {
     // one allocation, one fill: the tiles' mailboxes | the strip mailboxes (0.5 MB per diagonal block) | the exchange mailboxes of
     // the split panel (64 KB per 64-row strip of the matrix and the rows under it)
@@ -1193,7 +1196,8 @@ static int mbox_reset(cocons_fit *f, int nt)
     }
     f->smb_off = tiles; f->smb_elems = smb;
     f->xmb_off = tiles + smb; f->xmb_elems = xmb;
-    HIPCHK(hipMemsetAsync(f->dmbox, 0xff, need * sizeof(double), f->stream));
+    // (the plain schedule uses the tiles' mailboxes only)
+    HIPCHK(hipMemsetAsync(f->dmbox, 0xff, (engine_schedule ? need : tiles) * sizeof(double), f->stream));
     return 0;
 }
 
@@ -1490,7 +1494,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         f->dag_used = false;
         if (int rc = flags_reset(f, nt)) return rc;
         if (tun().potrf_follow && !f->follow_off)
-            if (int rc = mbox_reset(f, nt > f->nt ? nt : f->nt)) return rc;
+            if (int rc = mbox_reset(f, nt > f->nt ? nt : f->nt, false)) return rc;
         if (v.hi) {
             // band-limited: one tile column per step (factor, solve, update with K = 128) -- inside a narrow envelope
             // the in-panel update of the two-tile block costs more than the second, cheaper trailing update
@@ -1584,7 +1588,8 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
             const bool dg = fol && tun().panel_diag && next_tiles > 0 && k + 4 < nt &&
                             ((size_t)(t >> 1) + 1) * PANEL_SMBOX_DOUBLES <= f->smb_elems;
             const int nstrips = (rend - r0 * TILE) / 64;
-            const bool sp = fol && tun().panel_split && nstrips > 0 && (size_t)nstrips * PANEL_XMBOX_DOUBLES <= f->xmb_elems;
+            const bool sp = fol && tun().panel_split > 0 && nstrips >= tun().panel_split &&
+                            (size_t)nstrips * PANEL_XMBOX_DOUBLES <= f->xmb_elems;
             launch_panel_pair(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048,
                               f->dinv + (size_t)((t + 1) & 1) * 2048, out + t, xr + t, out + t + 1, abort_word, M,
                               fol ? f->dmbox + (size_t)t * ENGINE_MBOX_DOUBLES : nullptr,

@@ -348,6 +348,7 @@ def test_fused_panel_same_bits_as_three_launches(gx, gy):
     fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
     try:
         _lib.check(L.cocons_debug_tune(b"panel_fused", 1), "tune")
+        _lib.check(L.cocons_debug_tune(b"panel_split", 1), "tune")       # (two workgroups per strip in EVERY panel: the default asks for 32 strips)
         v1, p1 = fit.neg2loglik_core(th)
         assert fit.engine_state()["active"]
         _lib.check(L.cocons_debug_tune(b"panel_split", 0), "tune")       # (one workgroup per strip instead of two)
@@ -367,7 +368,7 @@ def test_fused_panel_same_bits_as_three_launches(gx, gy):
         _lib.check(L.cocons_debug_tune(b"panel_fused", int(os.environ.get("COCONS_PANEL_FUSED", "1"))), "tune")
         _lib.check(L.cocons_debug_tune(b"panel_follow", int(os.environ.get("COCONS_PANEL_FOLLOW", "1"))), "tune")
         _lib.check(L.cocons_debug_tune(b"panel_diag", int(os.environ.get("COCONS_PANEL_DIAG", "1"))), "tune")
-        _lib.check(L.cocons_debug_tune(b"panel_split", int(os.environ.get("COCONS_PANEL_SPLIT", "1"))), "tune")
+        _lib.check(L.cocons_debug_tune(b"panel_split", int(os.environ.get("COCONS_PANEL_SPLIT", "32"))), "tune")
 
 
 @pytest.mark.parametrize("gx,gy,engine", [(20, 20, 1), (33, 31, 0), (45, 47, 0), (64, 64, 0)])
