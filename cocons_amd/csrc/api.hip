@@ -291,6 +291,7 @@ struct cocons_fit {
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
     int dag_helpers_live;         // chain helpers in the engine launch of the factorisation being enqueued (0: none)
     int engine_pair_live;         // 1: the engine launched for the next factorisation has a pair partner (counts itself like a helper)
+    int engine_t0;                // first tile of the engine launched for the next factorisation: 0 (it factors the first diagonal block too) or 2
     size_t smb_off, smb_elems;           // inside dmbox: strip mailboxes, one per diagonal block (the panel launch's next-diagonal-block
                                          // update), and xmb_off: the panel launch's exchange mailboxes, one per 64-row strip (split panel)
     size_t xmb_off, xmb_elems;
@@ -998,6 +999,9 @@ struct Tunables {
                              // the classic schedule's 125, and the eleven CUs it holds cost the chip-bound head as much again:
                              // +0.1 .. +0.4 % at n = 10^4 (alternated in one process) -- not the default.
     int dag_helpers = 10;    // COCONS_DAG_HELPERS: that many of them (one round of the ten tiles of a diagonal block)
+    int engine_block0 = 1;   // COCONS_ENGINE_BLOCK0: 1 = the engine factors the FIRST diagonal block too (its input words raised by the gate
+                             // kernel) and that block's panel is the one-launch panel of every other block; 0 = the first block on the
+                             // plain schedule (tile | solve | in-panel update | tile | solve on the main stream), the engine from block 1
     int engine_pair = 1;     // COCONS_ENGINE_PAIR: 1 = the engine is a PAIR of workgroups -- the second one follows the first tile's
                              // factorisation column block by column block (strip solve, tile update) and factors the second tile
                              // (chol.hip: engine_partner_loop); 0 = one workgroup does the four passes one behind the other
@@ -1037,6 +1041,7 @@ static Tunables &tun()
         rd("COCONS_DAG_CHAIN", t.dag_chain);
         rd("COCONS_DAG_HELPERS", t.dag_helpers);
         rd("COCONS_ENGINE_PAIR", t.engine_pair);
+        rd("COCONS_ENGINE_BLOCK0", t.engine_block0);
         rd("COCONS_PANEL_FUSED", t.panel_fused);
         rd("COCONS_POTRF_FOLLOW", t.potrf_follow);
         rd("COCONS_PANEL_FOLLOW", t.panel_follow);
@@ -1073,6 +1078,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "dag_chain") t.dag_chain = value;
     else if (k == "dag_helpers") t.dag_helpers = value < 1 ? 1 : (value > 24 ? 24 : value);
     else if (k == "engine_pair") t.engine_pair = value;
+    else if (k == "engine_block0") t.engine_block0 = value;
     else if (k == "panel_fused") t.panel_fused = value;
     else if (k == "potrf_follow") t.potrf_follow = value;
     else if (k == "panel_follow") t.panel_follow = value;
@@ -1453,7 +1459,8 @@ static int engine_start(cocons_fit *f, const FactorView &v)
                           f->stream2, f->dag_trace_tasks ? f->ddag_trace + 5 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2) : nullptr);
     }
     f->dag_helpers_live = helpers ? tun().dag_helpers : 0;
-    launch_potrf_engine(v.A, v.lda, 2, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
+    f->engine_t0 = (tun().engine_block0 && !v.hi) ? 0 : 2;
+    launch_potrf_engine(v.A, v.lda, f->engine_t0, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
                         alive_w, f->stream2, f->dag_next ? f->dWt : nullptr,
                         f->dag_next ? f->dP : nullptr, f->dag_next ? 2 * f->dag_nsteps : 0,
                         (f->dag_next && f->dag_trace_tasks) ? f->ddag_trace + 4 * (size_t)f->dag_ntasks : nullptr,
@@ -1531,9 +1538,48 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     unsigned *abort_word = (unsigned *)(f->dinfo + 1);
     unsigned *alive = f->dflags + 3 * (size_t)f->flags_cap;
     if (tun().gate_sabotage > 0) { --tun().gate_sabotage; alive += 1; }      // (tests: a word that stays zero)
+    const bool block0 = f->engine_t0 == 0;           // the engine factors the first diagonal block too: the gate raises its input words
     launch_engine_gate(alive, abort_word, M, false, f->engine_ops++ == 0,
-                       (f->dag_next ? f->dag_helpers_live : 0) + f->engine_pair_live);      // (chain helpers and the pair partner count themselves)
-    panel_ops(f, v, 0, M);
+                       (f->dag_next ? f->dag_helpers_live : 0) + f->engine_pair_live,       // (chain helpers and the pair partner count themselves)
+                       (block0 && tun().gate_sabotage == 0 && alive == f->dflags + 3 * (size_t)f->flags_cap) ? in : nullptr);
+    const int rend = mt * TILE - 64 * v.trim;         // one past the last row any panel kernel touches
+    // the panel of the block at tile t (behind the engine's factorisation of it): one launch or three; returns the tiles of the NEXT
+    // diagonal block that the launch has updated (the update launch behind it then leaves them alone)
+    auto panel_for = [&](int t, bool allow_diag) -> int {
+        const bool two = t + 1 < nt;                 // the block has a second tile
+        const int r0 = two ? t + 2 : t + 1;          // first tile row below the diagonal block
+        const int hb = band_hi(v, t);                // rows of block t's panel: [r0, hb) and the rows under the matrix
+        const int br = hb >= 0 ? hb * TILE : -1, er = nt * TILE;
+        if (two && hb < 0 && tun().panel_fused) {
+            const bool fol = f->engine_pair_live && tun().panel_follow && f->dmbox != nullptr;
+            // the next diagonal block (tiles t + 2, t + 3), when there is one, is updated inside this launch
+            const int next_tiles = t + 2 < nt ? (t + 3 < nt ? 2 : 1) : 0;
+            const bool dg = allow_diag && fol && tun().panel_diag && next_tiles > 0 &&
+                            ((size_t)(t >> 1) + 1) * PANEL_SMBOX_DOUBLES <= f->smb_elems;
+            const int nstrips = (rend - r0 * TILE) / 64;
+            const bool sp = fol && tun().panel_split > 0 && nstrips >= tun().panel_split &&
+                            (size_t)nstrips * PANEL_XMBOX_DOUBLES <= f->xmb_elems;
+            launch_panel_pair(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048,
+                              f->dinv + (size_t)((t + 1) & 1) * 2048, out + t, xr + t, out + t + 1, abort_word, M,
+                              fol ? f->dmbox + (size_t)t * ENGINE_MBOX_DOUBLES : nullptr,
+                              fol ? f->dmbox + (size_t)(t + 1) * ENGINE_MBOX_DOUBLES : nullptr,
+                              dg ? f->dmbox + f->smb_off + (size_t)(t >> 1) * PANEL_SMBOX_DOUBLES : nullptr,
+                              dg ? (next_tiles == 2 ? 10 : 3) : 0, in, t + 2, sp ? f->dmbox + f->xmb_off : nullptr);
+            return (dg && nstrips >= (next_tiles == 2 ? 4 : 2)) ? next_tiles : 0;
+        }
+        launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048, M,
+                         out + t, abort_word, br, er);
+        if (two) {
+            launch_update(v.A, v.lda, t * TILE, TILE, r0, mt, t + 1, t + 2, false, M, nullptr, -1, xr + t, abort_word,
+                          nullptr, hb, nt, 0, v.trim);
+            launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, r0 * TILE, rend,
+                             f->dinv + (size_t)((t + 1) & 1) * 2048, M, out + t + 1, abort_word, br, er);
+        }
+        return 0;
+    };
+    int diag_done = 0;                                // tiles of the diagonal block at t that the previous panel's launch has updated
+    if (block0) diag_done = panel_for(0, !f->dag_next);          // (the persistent launch updates its first diagonal block itself)
+    else panel_ops(f, v, 0, M);
     if (f->dag_next && f->dag_helpers_live > 0) launch_raise_word(alive + 3, M);      // the chain helpers may touch the matrix now
     f->dag_used = f->dag_next;
     int k_first = 0;                 // first block step the classic loop below runs in full
@@ -1567,46 +1613,13 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     // update workgroups per CU, the event back to the main stream costs 12 us -- and removed; so were three forms of the
     // panel as products with explicit inverses published by the engine (round 3's COCONS_PANEL_MODE 1-3: +-1 %, deleted
     // in round 4))
-    const int rend = mt * TILE - 64 * v.trim;         // one past the last row any panel kernel touches
-    int diag_done = 0;                                // tiles of the diagonal block at t that the previous panel's launch has updated
     for (int k = k_first > 0 ? k_first - 2 : 0; k + 2 < nt; k += 2) {
         const int t = k + 2;
-        const bool two = t + 1 < nt;                 // the block has a second tile
-        const int r0 = two ? t + 2 : t + 1;          // first tile row below the diagonal block
-        const int hb = band_hi(v, t);                // rows of block t's panel: [r0, hb) and the rows under the matrix
-        const int br = hb >= 0 ? hb * TILE : -1, er = nt * TILE;
         if (k >= k_first) {                          // (the update with the last DAG step's panel was that launch's)
             if (ev_upd) count_update_flops(f, 2, t);
             timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), diag_done);
         }
-        diag_done = 0;
-        if (two && hb < 0 && tun().panel_fused) {
-            const bool fol = f->engine_pair_live && tun().panel_follow && f->dmbox != nullptr;
-            // the next diagonal block (tiles t + 2, t + 3), when there is one, is updated inside this launch; the update launch of
-            // the next round leaves it alone
-            const int next_tiles = t + 2 < nt ? (t + 3 < nt ? 2 : 1) : 0;
-            const bool dg = fol && tun().panel_diag && next_tiles > 0 && k + 4 < nt &&
-                            ((size_t)(t >> 1) + 1) * PANEL_SMBOX_DOUBLES <= f->smb_elems;
-            const int nstrips = (rend - r0 * TILE) / 64;
-            const bool sp = fol && tun().panel_split > 0 && nstrips >= tun().panel_split &&
-                            (size_t)nstrips * PANEL_XMBOX_DOUBLES <= f->xmb_elems;
-            launch_panel_pair(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048,
-                              f->dinv + (size_t)((t + 1) & 1) * 2048, out + t, xr + t, out + t + 1, abort_word, M,
-                              fol ? f->dmbox + (size_t)t * ENGINE_MBOX_DOUBLES : nullptr,
-                              fol ? f->dmbox + (size_t)(t + 1) * ENGINE_MBOX_DOUBLES : nullptr,
-                              dg ? f->dmbox + f->smb_off + (size_t)(t >> 1) * PANEL_SMBOX_DOUBLES : nullptr,
-                              dg ? (next_tiles == 2 ? 10 : 3) : 0, in, t + 2, sp ? f->dmbox + f->xmb_off : nullptr);
-            if (dg && (rend - r0 * TILE) / 64 >= (next_tiles == 2 ? 4 : 2)) diag_done = next_tiles;
-            continue;
-        }
-        launch_trsm_tile(v.A, v.lda, t * TILE, r0 * TILE, rend, f->dinv + (size_t)(t & 1) * 2048, M,
-                         out + t, abort_word, br, er);
-        if (two) {
-            launch_update(v.A, v.lda, t * TILE, TILE, r0, mt, t + 1, t + 2, false, M, nullptr, -1, xr + t, abort_word,
-                          nullptr, hb, nt, 0, v.trim);
-            launch_trsm_tile(v.A, v.lda, (t + 1) * TILE, r0 * TILE, rend,
-                             f->dinv + (size_t)((t + 1) & 1) * 2048, M, out + t + 1, abort_word, br, er);
-        }
+        diag_done = panel_for(t, k + 4 < nt);
     }
     // no rows under the matrix (right-hand sides in the slots of the last tile): nothing on the main stream has waited for
     // the engine's last tile yet -- what follows (the reductions) must

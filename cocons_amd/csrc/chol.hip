@@ -767,9 +767,9 @@ __device__ __forceinline__ void engine_partner_loop(const EngineArgs &e, double 
         __syncthreads();
         if (*okp == 0) return;
         __syncthreads();
-        unsigned long long *tr = (DAG && e.trace) ? e.trace + 8 * (size_t)(t >> 1) : nullptr;
+        unsigned long long *tr = (DAG && e.trace && t >= 2) ? e.trace + 8 * (size_t)(t >> 1) : nullptr;
         if (tr && tid == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
-        const bool dag_blk = DAG && t < e.dag_until;
+        const bool dag_blk = DAG && t >= 2 && t < e.dag_until;      // (the first block's panel is formed by classic kernels: no inverses)
         const int c0 = t * TILE, c1 = (t + 1) * TILE;
         // this wave's 16 x 128 strip of A(t+1,t) and its 4 or 5 lower blocks of A(t+1,t+1)  (addresses: see the strip solve below)
         const double *Sb = A + (size_t)(c1 + 16 * wave) + (size_t)c0 * lda;
@@ -930,7 +930,7 @@ potrf_engine_kernel(EngineArgs e)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
-        unsigned long long *tr = (DAG && e.trace) ? e.trace + 8 * (size_t)(t >> 1) : nullptr;
+        unsigned long long *tr = (DAG && e.trace && t >= 2) ? e.trace + 8 * (size_t)(t >> 1) : nullptr;
         if (tr && tid == 0) {
             tr[0] = __builtin_amdgcn_s_memrealtime();
             // (the unused record of pair 0: where the engine ran first, where it runs now, the pair at which that changed)
@@ -938,7 +938,7 @@ potrf_engine_kernel(EngineArgs e)
             if (e.trace[0] == 0) e.trace[0] = w;
             if (e.trace[1] != w) { e.trace[1] = w; e.trace[2] = (unsigned long long)(t >> 1); }
         }
-        const bool dag_blk = DAG && t < e.dag_until;
+        const bool dag_blk = DAG && t >= 2 && t < e.dag_until;      // (the first block's panel is formed by classic kernels: no inverses)
         // (DAG blocks: W = L^-1 of the tile comes out of the factorisation itself, complete before out[t])
         potrf_tile_body<true>(A, lda, t * TILE, e.dinv + (size_t)(t & 1) * 2048, e.info, smem, QALL,
                               dag_blk ? e.wbuf + (size_t)t * TILE * TILE : nullptr, XI,
@@ -1542,12 +1542,21 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
 // engine sit on every CU.  So the main stream does not start the factorisation's launches before the
 // engine is resident: this one-lane kernel waits for its alive word (bounded like every other wait).
 __global__ void __launch_bounds__(64)
-engine_gate_kernel(unsigned *alive, unsigned *abort_word, unsigned code, unsigned long long ticks, unsigned nhelp)
+engine_gate_kernel(unsigned *alive, unsigned *abort_word, unsigned code, unsigned long long ticks, unsigned nhelp,
+                   unsigned *raise_in)
 {
     // (nhelp > 0: the launch also holds chain helpers, which count themselves in alive[2] once resident: a chain task nobody
     // resident can draw would stop the persistent launch as surely as a missing engine)
-    if (threadIdx.x == 0 && wait_ge<false>(alive, 1u, abort_word, code, ticks) && nhelp)
-        (void)wait_ge<false>(alive + 2, nhelp, abort_word, code + 1u, ticks);
+    // (raise_in: the engine also factors the FIRST diagonal block -- nobody updates it, so its input words are raised here, behind
+    // everything the main stream did to the matrix before the factorisation: in[0] = 3, in[1] = 7)
+    if (threadIdx.x == 0) {
+        bool ok = wait_ge<false>(alive, 1u, abort_word, code, ticks);
+        if (ok && nhelp) ok = wait_ge<false>(alive + 2, nhelp, abort_word, code + 1u, ticks);
+        if (ok && raise_in) {
+            __hip_atomic_store(raise_in, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(raise_in + 1, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2735,7 +2744,7 @@ int streams_run_concurrently(hipStream_t first, hipStream_t second, unsigned *wo
 {
     if (hipMemsetAsync(words, 0, 2 * sizeof(unsigned), second) != hipSuccess) return -1;
     if (hipStreamSynchronize(second) != hipSuccess) return -1;
-    hipLaunchKernelGGL(engine_gate_kernel, dim3(1), dim3(64), 0, first, words, words + 1, 1u, 200000ull, 0u);
+    hipLaunchKernelGGL(engine_gate_kernel, dim3(1), dim3(64), 0, first, words, words + 1, 1u, 200000ull, 0u, (unsigned *)nullptr);
     hipLaunchKernelGGL(raise_word_kernel, dim3(1), dim3(64), 0, second, words);
     unsigned h[2] = {0, 0};
     if (hipStreamSynchronize(first) != hipSuccess || hipStreamSynchronize(second) != hipSuccess) return -1;
@@ -2744,7 +2753,8 @@ int streams_run_concurrently(hipStream_t first, hipStream_t second, unsigned *wo
     return h[1] == 0 ? 1 : 0;
 }
 
-void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile, bool patient, int nhelp)
+void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile, bool patient, int nhelp,
+                        unsigned *raise_in)
 {
     // last_tile: not the start-up gate (is the engine resident? 5 ms, code 0x600) but the wait of the reductions for the
     // engine's LAST diagonal tile when no panel kernel has waited for it (code 0x900, the hand-offs' 100 ms bound)
@@ -2753,7 +2763,7 @@ void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bo
     // not be mistaken for "every CU is taken by someone else"
     hipLaunchKernelGGL(engine_gate_kernel, dim3(1), dim3(64), 0, s, alive, abort_word, last_tile ? 0x900u : 0x600u,
                        last_tile ? ENGINE_TIMEOUT_TICKS : (patient ? 10 * GATE_TIMEOUT_TICKS : GATE_TIMEOUT_TICKS),
-                       (unsigned)(last_tile || nhelp < 0 ? 0 : nhelp));
+                       (unsigned)(last_tile || nhelp < 0 ? 0 : nhelp), last_tile ? nullptr : raise_in);
 }
 
 // Dynamic LDS of the engine.  136 KB: the 128 KB LDS copy of X plus the flag word; leaves room for ONE update workgroup

@@ -140,7 +140,9 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
                                                                          // launch; a second workgroup takes the second tile of every block
 constexpr size_t ENGINE_MBOX_DOUBLES = 44 * 256;
 // nhelp > 0: also waits until that many chain helpers of the engine's launch are resident
-void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false, bool patient = false, int nhelp = 0);
+// raise_in != NULL: the gate also raises in[0] = 3, in[1] = 7 (the engine factors the first diagonal block too: launch_potrf_engine t0 = 0)
+void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false, bool patient = false, int nhelp = 0,
+                        unsigned *raise_in = nullptr);
 void launch_raise_word(unsigned *word, hipStream_t s);      // *word = 1 (agent scope) by a one-lane kernel: "everything in front of me on this stream is done"
 // 1: a kernel on `first` and a kernel launched behind it on `second` overlap (the streams sit on different hardware queues);
 // 0: they run one after the other; -1: HIP error.  words: two device words; both streams idle.

@@ -21,8 +21,8 @@ extern "C" {
 int cocons_debug_matern(int n, const double *nu, const double *u, double *out);
 
 /* Schedule switches of the factorisation, settable at run time (the library reads the COCONS_* environment variables
- * of the same meaning once per process; DESIGN.md section 6 lists them): "engine", "engine_pair", "panel_fused", "panel_follow",
- * "panel_diag", "potrf_follow", "upd_dynamic", "upd_waves", "w8_max_tiles", "dag", "dag_min_tiles", "dag_split", "dag_chain",
+ * of the same meaning once per process; DESIGN.md section 6 lists them): "engine", "engine_block0", "engine_pair", "panel_fused", "panel_follow",
+ * "panel_diag", "panel_split", "potrf_follow", "upd_dynamic", "upd_waves", "w8_max_tiles", "dag", "dag_min_tiles", "dag_split", "dag_chain",
  * "dag_helpers", "dag_lead" / "dag_lead2" / "dag_lead3", "dag_xcc_quota", "dag_trace" (and, for the tests, "gate_sabotage").
  * For timing variants in alternation inside one process (tools/ab_modes.py); results do not depend on them beyond the
  * rounding of a different summation order.                                                                        */

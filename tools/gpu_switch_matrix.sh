@@ -10,7 +10,8 @@ part2=("COCONS_RHS_SLOTS=0" "COCONS_TAPER_PACKED=0" "COCONS_SPATIAL_SORT=0" "COC
        "COCONS_BATCH_SLOTS=1" "COCONS_BATCH_SLOTS=4" "COCONS_DAG_CHAIN=1" "COCONS_DAG_CHAIN=1 COCONS_DAG_MIN_TILES=0"
        "COCONS_ENGINE_PAIR=0" "COCONS_PANEL_FUSED=0" "COCONS_ENGINE_PAIR=0 COCONS_PANEL_FUSED=0 COCONS_DAG_MIN_TILES=0"
        "COCONS_POTRF_FOLLOW=0" "COCONS_POTRF_FOLLOW=0 COCONS_ENGINE=0" "COCONS_PANEL_FOLLOW=0"
-       "COCONS_PANEL_DIAG=0" "COCONS_PANEL_SPLIT=0" "COCONS_PANEL_SPLIT=1")
+       "COCONS_PANEL_DIAG=0" "COCONS_PANEL_SPLIT=0" "COCONS_PANEL_SPLIT=1"
+       "COCONS_ENGINE_BLOCK0=0")
 shard=()
 case "$PART" in
   1) cfgs=("${part1[@]}"); : > gpurun_out/switch_matrix.txt ;;
