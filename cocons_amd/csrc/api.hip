@@ -292,7 +292,6 @@ struct cocons_fit {
     int dag_helpers_live;         // chain helpers in the engine launch of the factorisation being enqueued (0: none)
     int engine_pair_live;         // 1: the engine launched for the next factorisation has a pair partner (counts itself like a helper)
     int engine_t0;                // first tile of the engine launched for the next factorisation: 0 (it factors the first diagonal block too) or 2
-    bool dag_follow;              // the factorisation being enqueued uses the follow layout of the DAG schedule (COCONS_DAG_CHAIN=2)
     size_t smb_off, smb_elems;           // inside dmbox: strip mailboxes, one per diagonal block (the panel launch's next-diagonal-block
                                          // update), and xmb_off: the panel launch's exchange mailboxes, one per 64-row strip (split panel)
     size_t xmb_off, xmb_elems;
@@ -1459,19 +1458,14 @@ static int engine_start(cocons_fit *f, const FactorView &v)
                           queue, tdone, pdone, (int)T64, pall, f->dpart, dcount, in, out, xr, (unsigned *)(f->dinfo + 1), alive_w,
                           f->stream2, f->dag_trace_tasks ? f->ddag_trace + 5 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2) : nullptr);
     }
+    f->dag_helpers_live = helpers ? tun().dag_helpers : 0;
     f->engine_t0 = (tun().engine_block0 && !v.hi) ? 0 : 2;
-    // follow layout (COCONS_DAG_CHAIN=2): the chain layout's table, its helpers' workgroups as FOLLOWERS (two of strips, five of
-    // diagonal tiles: chol.hip dag_follow_loop) -- needs the pair's mailboxes, the strip mailboxes and the engine on the first block
-    f->dag_follow = helpers && tun().dag_chain == 2 && tun().engine_pair != 0 && f->engine_t0 == 0 && tun().panel_fused &&
-                    tun().panel_follow && tun().panel_diag && f->dmbox != nullptr &&
-                    ((size_t)nt / 2 + 2) * PANEL_SMBOX_DOUBLES <= f->smb_elems;
-    f->dag_helpers_live = helpers ? (f->dag_follow ? 7 : tun().dag_helpers) : 0;
     launch_potrf_engine(v.A, v.lda, f->engine_t0, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
                         alive_w, f->stream2, f->dag_next ? f->dWt : nullptr,
                         f->dag_next ? f->dP : nullptr, f->dag_next ? 2 * f->dag_nsteps : 0,
                         (f->dag_next && f->dag_trace_tasks) ? f->ddag_trace + 4 * (size_t)f->dag_ntasks : nullptr,
                         helpers ? f->ddag_chain : nullptr, f->dag_helpers_live,
-                        f->engine_pair_live ? f->dmbox : nullptr, f->dag_follow ? f->dmbox + f->smb_off : nullptr);
+                        f->engine_pair_live ? f->dmbox : nullptr);
     f->engine_live = true;
     return 0;
 }
@@ -1584,9 +1578,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         return 0;
     };
     int diag_done = 0;                                // tiles of the diagonal block at t that the previous panel's launch has updated
-    // (the persistent launch updates its first diagonal block itself -- except in the follow layout, whose list has no diagonal
-    // tiles at all: there the first panel's launch does it, like every panel's behind the head)
-    if (block0) diag_done = panel_for(0, !f->dag_next || f->dag_follow);
+    if (block0) diag_done = panel_for(0, !f->dag_next);          // (the persistent launch updates its first diagonal block itself)
     else panel_ops(f, v, 0, M);
     if (f->dag_next && f->dag_helpers_live > 0) launch_raise_word(alive + 3, M);      // the chain helpers may touch the matrix now
     f->dag_used = f->dag_next;

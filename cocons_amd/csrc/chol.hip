@@ -643,16 +643,11 @@ struct EngineArgs {
     const struct DagArgs *chain; // DAG schedule, chain layout (round 5): device copy of the launch's task words -- the workgroups
     int nhelp;                   // 8, 16, ... 8 nhelp of this launch are CHAIN HELPERS (chain_helper_loop); null / 0: none
     double *mbox;                // pair mode: the tiles' mailboxes, 44 x 256 doubles each (index: tile), filled with ~0 (potrf_tile_body)
-    double *smb;                 // follow layout of the DAG schedule (COCONS_DAG_CHAIN=2): the strip mailboxes, PANEL_SMBOX_DOUBLES per
-                                 // diagonal block; the workgroups 8, 16 (strips) and 24 .. 56 (diagonal tiles) of the launch are FOLLOWERS
-                                 // (dag_follow_loop) instead of chain helpers; null: chain helpers
     int partner;                 // pair mode: index of the PAIR PARTNER's workgroup in this launch (engine_partner_loop); 0: none
 };
 
 struct DagArgs;
 __device__ __forceinline__ void chain_helper_loop(const DagArgs *ap);
-struct EngineArgs;
-__device__ __forceinline__ void dag_follow_loop(const DagArgs *ap, const EngineArgs &e, double *smem);
 
 // Following a tile's factorisation through its mailbox (potrf_tile_body: mbox), shared by the engine's partner and the followers of
 // potrf_follow_kernel.  In scope: tid, lane, half = tid >> 8 (wave-uniform), mb = the tile's mailbox, double v[5], int *okp (LDS).
@@ -919,9 +914,7 @@ potrf_engine_kernel(EngineArgs e)
         // on a CU of its own like the engine (the launch's LDS request keeps everything else off it); behind them the pair
         // partner.  The others leave at once.
         if (e.partner != 0 && (int)blockIdx.x == e.partner) engine_partner_loop<DAG>(e, smem);
-        else if (DAG && e.chain && (blockIdx.x & 7u) == 0u && (int)(blockIdx.x >> 3) <= e.nhelp) {
-            if (e.smb) dag_follow_loop(e.chain, e, smem); else chain_helper_loop(e.chain);
-        }
+        else if (DAG && e.chain && (blockIdx.x & 7u) == 0u && (int)(blockIdx.x >> 3) <= e.nhelp) chain_helper_loop(e.chain);
         return;
     }
     const bool pair = e.partner != 0;
@@ -2571,273 +2564,6 @@ __device__ __forceinline__ void chain_helper_loop(const DagArgs *ap)
 }
 
 // ---------------------------------------------------------------------------
-// ---------------------------------------------------------------------------
-// Follow layout of the dependency-driven schedule (COCONS_DAG_CHAIN=2, end of round 5).  The bulk list is the chain layout's; what
-// that layout gave to chain helpers as tile TASKS -- the next diagonal block's ten tiles, the panel tasks of the four strips below
-// it -- is done here by FOLLOWERS, the way the classic steps behind the head do it (panel_pair_kernel): workgroups 8 and 16 of the
-// engine's launch hold two 64-row strips each (a wave 16 rows: both 16 x 128 strips in registers), follow the engine's tile t
-// through its mailbox (X0), form the in-panel product, follow the partner's tile t+1 (X1), publish every finished block of X in
-// the strip mailbox, and store X into P with the launch's words (pdone = complete, pall + 1); workgroups 24 .. 56 hold two tiles
-// of the NEXT diagonal block each (a wave 16 rows of a tile), follow the strips, and raise tdone and the engine's input words.
-// A step's chain is then engine | ~4 us | ~3 us instead of three tile tasks that share their CUs with seven others.
-// Per step s < nsteps - 1 (the last step of the launch forms no panel); every wait bounded like the helpers'.
-__device__ __forceinline__ void dag_follow_loop(const DagArgs *ap, const EngineArgs &e, double *smem)
-{
-    const DagArgs a = *ap;
-    const int tid0 = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    const int half = __builtin_amdgcn_readfirstlane(tid0 >> 8);
-    const int role = (int)(blockIdx.x >> 3);          // 1, 2: strips (2 role - 2 + half); 3 .. 7: diagonal tiles (2 role - 6 + half)
-    int *okp = (int *)(smem + 73 * 256);
-    unsigned *alive = const_cast<unsigned *>(a.alive);
-    double *A = a.A;
-    const size_t lda = a.lda;
-    if (tid0 == 0) {
-        __hip_atomic_fetch_add(alive + 16 + ((hw_where() >> 28) & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(alive + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *okp = wait_ge<false>(alive + 3, 1u, a.abort_word, 0xf00u, HOST_PACED_TICKS) ? 1 : 0;      // (the first panel is there)
-    }
-    __syncthreads();
-    if (*okp == 0) return;
-    __syncthreads();
-    for (int s = 0; s + 1 < a.nsteps; ++s) {
-        // (the thread index is taken afresh in every step: what the compiler derives from it -- LDS and mailbox offsets -- would
-        // otherwise be formed once at the kernel's entry for every role of the launch and live, or spill, through all of them)
-        int tid_ = threadIdx.x;
-        asm volatile("" : "+v"(tid_));
-        const int tid = tid_, lane = tid & 63;
-        const DagStep st = a.steps[s];
-        if (!st.two) return;                              // (never: only the launch's last step may be a block of one tile)
-        const int ncs = st.cs;                            // strips of this panel that are the followers' (4; fewer at the matrix's end)
-        const int ncn = a.steps[s + 1].nc;                // 64-tiles across the NEXT diagonal block: 4, or 2 for a last block of one tile
-        const int ndn = ncn * (ncn + 1) / 2;
-        const int t = st.tj0 >> 1;                        // the block being factored: tiles t, t + 1
-        const int c0 = t * TILE, c1 = c0 + TILE;
-        double *smb = e.smb + (size_t)(t >> 1) * (4 * 16 * 4 * 256);
-        if (role <= 2) {
-            // ---------------- two strips of the panel of block t: rows of the block behind it
-            const int strip = 2 * (role - 1) + half;
-            if (2 * (role - 1) >= ncs) continue;               // (neither of this workgroup's strips exists in this panel)
-            const bool valid = strip < ncs;                   // (the second one may not)
-            const int row64 = st.tj0 + 4 + strip;
-            const int rs = 64 * row64 + 16 * (wave & 3);
-            if (tid == 0) {
-                bool o = true;
-                const int r0s = st.tj0 + 4 + 2 * (role - 1);
-                for (int q = 0; q < 8 && o; ++q) {        // the strips' eight tiles in the block's columns, updated through step s
-                    const int rr = r0s + (q >> 2), cc = st.tj0 + (q & 3);
-                    if (2 * (role - 1) + (q >> 2) < ncs)
-                        o = wait_ge<false>(a.tdone + (rr * (rr + 1) / 2 + cc), (unsigned)s + 1u, a.abort_word, 0xf00u + (unsigned)(s & 0xff));
-                }
-                *okp = o ? 1 : 0;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (*okp == 0) return;
-            d4 B0[8], B1[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) B0[j] = valid ? glb_blk_wt(A, lda, rs, c0 + 16 * j, lane) : (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) B1[j] = valid ? glb_blk_wt(A, lda, rs, c1 + 16 * j, lane) : (d4){0.0, 0.0, 0.0, 0.0};
-            double *sp = smb + ((size_t)strip * 16 * 4 + (wave & 3)) * 256;
-            double v[5];
-            double *LST = smem;                                // two stages of 9 blocks (overlaid by X(t+1,t) in between)
-            __syncthreads();
-            {   // X0: follow tile t
-                const double *mb = e.mbox + (size_t)t * (44 * 256);
-                MBOX_FETCH(0)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    double *LS = LST + (j & 1) * (9 * 256);
-                    MBOX_COMPLETE(j, a.abort_word, 0xf00u + (unsigned)(s & 0xff))
-#pragma unroll
-                    for (int i = 0; i < 5; ++i)
-                        if (half + 2 * i <= 8 - j) LS[tid + 512 * i] = v[i];
-                    __syncthreads();
-                    if (*okp == 0) return;
-                    if (j < 7) MBOX_FETCH(j + 1)
-                    d4 L = lds_blk(LS, lane);
-                    double Q[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Q[q] = LS[(8 - j) * 256 + q * 64 + lane];
-                    trsm16(B0[j], L, Q);
-                    if (valid) mbox_store(sp + (size_t)j * 1024, lane, B0[j]);
-                    d4 NX = -B0[j];
-#pragma unroll
-                    for (int jj = j + 1; jj < 8; ++jj) {
-                        d4 Lb = lds_blk(LS + (jj - j) * 256, lane);
-                        blk_mma(B0[jj], NX, Lb);
-                    }
-                }
-            }
-            if (valid) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) glb_blk_store_wt(a.P, lda, rs, c0 + 16 * j, lane, B0[j]);
-            }
-            // B1 -= X0 X(t+1,t)^T
-            if (tid == 0) *okp = wait_ge<false>(a.xr + t, 1u, a.abort_word, 0xf00u + (unsigned)(s & 0xff)) ? 1 : 0;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (*okp == 0) return;
-            {
-                const int i = tid & 15, k = (tid >> 4) & 15, hb = tid >> 8;       // 512 threads: 32 blocks per round, two rounds
-                const double *Xg = A + (size_t)(c1 + i) + (size_t)(c0 + k) * lda;
-                double stx[2][8];                                               // four rounds of eight, the next one in flight
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const int bb = 2 * b + hb;                                   // block (jj, kb) = (bb >> 3, bb & 7)
-                    stx[0][b] = load_wt(Xg + (size_t)(16 * (bb >> 3)) + (size_t)(16 * (bb & 7)) * lda);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (r + 1 < 4) {
-#pragma unroll
-                        for (int b = 0; b < 8; ++b) {
-                            const int bb = 2 * (8 * (r + 1) + b) + hb;
-                            stx[(r + 1) & 1][b] = load_wt(Xg + (size_t)(16 * (bb >> 3)) + (size_t)(16 * (bb & 7)) * lda);
-                        }
-                    }
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) smem[(2 * (8 * r + b) + hb) * 256 + k * 16 + i] = stx[r & 1][b];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kb = 0; kb < 8; ++kb) {
-                    d4 Xb = lds_blk(smem + (jj * 8 + kb) * 256, lane);
-                    blk_mma(acc, B0[kb], Xb);
-                }
-                B1[jj] = B1[jj] - acc;
-            }
-            __syncthreads();
-            {   // X1: follow tile t + 1
-                const double *mb = e.mbox + (size_t)(t + 1) * (44 * 256);
-                MBOX_FETCH(0)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    double *LS = LST + (j & 1) * (9 * 256);
-                    MBOX_COMPLETE(j, a.abort_word, 0xf00u + (unsigned)(s & 0xff))
-#pragma unroll
-                    for (int i = 0; i < 5; ++i)
-                        if (half + 2 * i <= 8 - j) LS[tid + 512 * i] = v[i];
-                    __syncthreads();
-                    if (*okp == 0) return;
-                    if (j < 7) MBOX_FETCH(j + 1)
-                    d4 L = lds_blk(LS, lane);
-                    double Q[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Q[q] = LS[(8 - j) * 256 + q * 64 + lane];
-                    trsm16(B1[j], L, Q);
-                    if (valid) mbox_store(sp + (size_t)(8 + j) * 1024, lane, B1[j]);
-                    d4 NX = -B1[j];
-#pragma unroll
-                    for (int jj = j + 1; jj < 8; ++jj) {
-                        d4 Lb = lds_blk(LS + (jj - j) * 256, lane);
-                        blk_mma(B1[jj], NX, Lb);
-                    }
-                }
-            }
-            if (valid) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) glb_blk_store_wt(a.P, lda, rs, c1 + 16 * j, lane, B1[j]);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if ((tid & 255) == 0 && valid) {                   // one lane per strip: the strip of panel s + 1 is complete
-                __hip_atomic_fetch_max(a.pdone + (size_t)(s + 1) * a.pstride + strip, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(a.pall + s + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-        } else {
-            // ---------------- two tiles of the NEXT diagonal block (tiles t + 2, t + 3), updated with the panel of block t
-            const int dd = 2 * (role - 3) + half;
-            if (2 * (role - 3) >= ndn) continue;               // (neither of this workgroup's tiles exists in the next diagonal block)
-            const bool valid = dd < ndn;
-            const int ta = c_tri_ib[valid ? dd : 0], tb = (valid ? dd : 0) - ta * (ta + 1) / 2;
-            const int tj0n = st.tj0 + 4, ti = tj0n + ta, tj = tj0n + tb;
-            unsigned *tw = a.tdone + (ti * (ti + 1) / 2 + tj);
-            if ((tid & 255) == 0 && valid) {
-                if (!wait_ge<false>(tw, (unsigned)s + 1u, a.abort_word, 0xf00u + (unsigned)(s & 0xff))) *okp = 0;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (*okp == 0) return;
-            const int rI = 64 * ti + 16 * (wave & 3), cJ = 64 * tj;
-            d4 C[4], acc[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                C[c] = valid ? glb_blk_wt(A, lda, rI, cJ + 16 * c, lane) : (d4){0.0, 0.0, 0.0, 0.0};
-                acc[c] = (d4){0.0, 0.0, 0.0, 0.0};
-            }
-            const double *pi = smb + ((size_t)ta * 16 * 4 + (wave & 3)) * 256 + lane;
-            const double *pj = smb + ((size_t)tb * 16 * 4) * 256 + lane;
-            double x[2][20];
-#define DIAG_FETCH(kk, buf)                                                                                    \
-            {                                                                                                  \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) x[buf][r] = load_wt(pi + (size_t)(kk) * 1024 + 64 * r); \
-                _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                   \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                               \
-                        x[buf][4 + 4 * c + r] = load_wt(pj + (size_t)(kk) * 1024 + 256 * c + 64 * r);            \
-            }
-            DIAG_FETCH(0, 0)
-            bool good = true;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int cur = k & 1;
-                for (unsigned it = 0; good && valid; ++it) {
-                    bool missing = false;
-#pragma unroll
-                    for (int q = 0; q < 20; ++q) missing = missing || __double_as_longlong(x[cur][q]) == -1ll;
-                    if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
-                    const bool late_ = it > (unsigned)(ENGINE_TIMEOUT_TICKS / 100ull);
-                    if (late_ || ((it & 7u) == 7u && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                        if (late_ && lane == 0) __hip_atomic_store(a.abort_word, 0xfe0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        good = false;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                    if ((it & 7u) == 7u) {
-#pragma unroll
-                        for (int q = 0; q < 20; ++q)
-                            if (__double_as_longlong(x[cur][q]) == -1ll) {
-                                const double *ad = q < 4 ? pi + (size_t)k * 1024 + 64 * q
-                                                         : pj + (size_t)k * 1024 + 256 * ((q - 4) >> 2) + 64 * ((q - 4) & 3);
-                                x[cur][q] = __longlong_as_double((long long)__hip_atomic_fetch_or(
-                                    (unsigned long long *)const_cast<double *>(ad), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                            }
-                    } else
-                        DIAG_FETCH(k, cur)
-                }
-                if (k + 1 < 16) DIAG_FETCH(k + 1, cur ^ 1)
-                d4 Xi = {x[cur][0], x[cur][1], x[cur][2], x[cur][3]};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    d4 Xj = {x[cur][4 + 4 * c], x[cur][5 + 4 * c], x[cur][6 + 4 * c], x[cur][7 + 4 * c]};
-                    blk_mma(acc[c], Xi, Xj);
-                }
-            }
-#undef DIAG_FETCH
-            if (!good && lane == 0) *okp = 0;
-            __syncthreads();
-            if (*okp == 0) return;
-            if (valid) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) glb_blk_store_wt(A, lda, rI, cJ + 16 * c, lane, C[c] - acc[c]);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if ((tid & 255) == 0 && valid) {
-                __hip_atomic_fetch_max(tw, (unsigned)s + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                signal_add(a.sig + (t + 2) + (ta >> 1));
-            }
-            __syncthreads();
-        }
-    }
-}
-
 __device__ __forceinline__ double block_sum(double v, double *red)
 {
 #pragma unroll
@@ -3085,7 +2811,7 @@ void launch_chain_args(void *dev, double *A, size_t lda, double *P, const double
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
                          double *wbuf, double *pbuf, int dag_until, unsigned long long *trace, const void *chain, int nhelp,
-                         double *mbox, double *smb)
+                         double *mbox)
 {
     EngineArgs e;
     e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
@@ -3095,7 +2821,6 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
     e.nhelp = e.chain ? nhelp : 0;
     // (mbox: pair mode -- the partner is the workgroup behind the helpers' on workgroup 0's XCD: 8 (nhelp + 1))
     e.mbox = mbox;
-    e.smb = (e.chain && mbox) ? smb : nullptr;        // (follow layout: needs the chain layout's table and the pair's mailboxes)
     e.partner = mbox ? 8 * (e.nhelp + 1) : 0;
     const int grid = e.partner ? e.partner + 1 : (e.nhelp > 0 ? 8 * e.nhelp + 1 : 1);
     const size_t shm = engine_lds_bytes();

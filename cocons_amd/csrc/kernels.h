@@ -135,11 +135,9 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
                          unsigned long long *trace = nullptr,
                          const void *chain = nullptr, int nhelp = 0,    // chain helpers of the DAG schedule (chol.hip: chain_helper_loop):
                                                                          // device copy of the task words (launch_chain_args), workgroups
-                         double *mbox = nullptr,                         // pair mode (engine_partner_loop): the tiles' mailboxes
+                         double *mbox = nullptr);                        // pair mode (engine_partner_loop): the tiles' mailboxes
                                                                          // (ENGINE_MBOX_DOUBLES each, index = tile), every byte 0xff at
                                                                          // launch; a second workgroup takes the second tile of every block
-                         double *smb = nullptr);                         // follow layout of the DAG schedule (with chain, nhelp = 7 and mbox):
-                                                                         // the strip mailboxes; the helpers' workgroups are followers
 constexpr size_t ENGINE_MBOX_DOUBLES = 44 * 256;
 // nhelp > 0: also waits until that many chain helpers of the engine's launch are resident
 // raise_in != NULL: the gate also raises in[0] = 3, in[1] = 7 (the engine factors the first diagonal block too: launch_potrf_engine t0 = 0)

@@ -233,42 +233,3 @@ def test_dag_chain_layout_vs_classic(gx, gy, min_tiles):
         _tune("dag_chain", int(os.environ.get("COCONS_DAG_CHAIN", "0")))
         _tune("dag_split", int(os.environ.get("COCONS_DAG_SPLIT", "1")))
         _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "2000")))
-
-
-@pytest.mark.parametrize("gx,gy,min_tiles", [(45, 47, 0), (64, 64, 0), (72, 64, 0), (100, 100, 800), (100, 100, 0)])
-def test_dag_follow_layout_vs_classic(gx, gy, min_tiles):
-    """The follow layout of the dependency-driven schedule (COCONS_DAG_CHAIN=2, end of round 5): the chain layout's list, and
-    what that layout gives to chain helpers as tile tasks done by followers of the engine's launch -- strips that follow the
-    engine's two tiles through their mailboxes, diagonal tiles that follow the strips (chol.hip dag_follow_loop).  The panel of
-    the chain's rows is formed by substitution instead of products with the tile inverses, so the value equals the other
-    layouts' to rounding (1e-11), not bit for bit; reproducible run to run; no hand-off timed out."""
-    import cocons_amd as ca
-    from cocons_amd import workloads as wl
-    locs, sc = _grid(gx, gy)
-    n = locs.shape[0]
-    X = sc["std.covs"]
-    th = wl.theta_full()
-    th["mean"] = np.array([0.1, -0.2, 0.05])
-    rng = np.random.default_rng(n + 7)
-    z = rng.standard_normal((n, 2)) + (X @ np.array([0.2, 0.3, -0.1]))[:, None]
-    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
-    try:
-        _tune("dag", 1)
-        _tune("dag_min_tiles", min_tiles)
-        _tune("dag_chain", 0)
-        v_list = fit.neg2loglik_core(th)[0]
-        _tune("dag_chain", 2)
-        v_f, p_f = fit.neg2loglik_core(th)
-        v_f2, p_f2 = fit.neg2loglik_core(th)
-        st = fit.engine_state()
-        assert st["retries"] == 0 and st["active"]
-        assert abs(v_f - v_list) <= 1e-11 * abs(v_list)
-        assert v_f2 == v_f and np.array_equal(p_f2, p_f)
-        _tune("dag", 0)
-        v_cl = fit.neg2loglik_core(th)[0]
-        assert abs(v_f - v_cl) <= 1e-11 * abs(v_cl)
-        assert fit.engine_state()["retries"] == 0
-    finally:
-        _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
-        _tune("dag_chain", int(os.environ.get("COCONS_DAG_CHAIN", "0")))
-        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "2000")))
