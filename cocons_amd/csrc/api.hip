@@ -336,6 +336,10 @@ struct cocons_fit {
     std::vector<cocons_fit *> *slots;
     bool sorted;                  // observations are stored in Morton order (see fit_create_impl)
     cocons_fit *unsorted;         // lazily created clone in the ORIGINAL order (marginal simulation)
+    std::recursive_mutex *op_mu;  // held by every entry point for as long as it works on this handle (FIT_ENTER), and by another
+                                  // handle's stream self-test while it launches probe kernels on this handle's streams
+                                  // (engine_warm: try_lock under the registry's lock -- a busy handle is not probed, a probed one
+                                  // can neither be used nor destroyed until the probe is over).  A pointer: the struct is memset
 };
 
 static void shard_state_free(struct ShardState *S);
@@ -362,6 +366,13 @@ static int fit_check(cocons_fit *f)
     return 0;
 }
 
+// Every public entry point that works on a handle: validate it, then hold its operation lock until the call returns.
+// THREADING CONTRACT (include/cocons_hip.h): one handle serves one call at a time -- a second thread that enters with the
+// same handle waits here --; different handles may be used, created and destroyed from different threads concurrently.
+#define FIT_ENTER(f)                                                   \
+    if (int rc__ = fit_check(f)) return rc__;                          \
+    std::lock_guard<std::recursive_mutex> op_guard__(*(f)->op_mu)
+
 static int fit_alloc_matrix(cocons_fit *f, int rhs_rows)
 {
     int cap = round_up(rhs_rows > 0 ? rhs_rows : 1, TILE);
@@ -382,7 +393,10 @@ static int fit_alloc_matrix(cocons_fit *f, int rhs_rows)
 extern "C" void cocons_fit_destroy(cocons_fit *f)
 {
     if (!f) return;
+    // out of the registry first (no stream self-test of another thread can find the handle any more), then wait for one that
+    // found it earlier and is still launching probe kernels on its streams (engine_warm holds op_mu for that long)
     registry_remove(f);
+    if (f->op_mu) { f->op_mu->lock(); f->op_mu->unlock(); }
     if (f->pid == getpid()) {
         hipSetDevice(f->device);
         if (f->stream) hipStreamSynchronize(f->stream);
@@ -412,6 +426,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
     }
     delete f->h_locs; delete f->h_X; delete f->h_z; delete f->h_xb;
     delete f->taper_hi; delete f->taper_inv;
+    delete f->op_mu;
     delete f;
 }
 
@@ -420,7 +435,7 @@ static int engine_warm(cocons_fit *f);
 static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *locs,
                                    const double *X, const double *z, const double *x_betas,
                                    const double *smooth_limits, int device, bool allow_sort, bool defer_matrix = false,
-                                   bool want_engine = true)
+                                   bool want_engine = true, bool return_locked = false)
 {
     if (n <= 0 || p <= 0 || p > COCONS_P_MAX || r < 0 || q < 0 || !locs || !X || !smooth_limits ||
         (r > 0 && !z) || (q > 0 && !x_betas)) {
@@ -429,6 +444,7 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     }
     cocons_fit *f = new cocons_fit();
     memset(f, 0, sizeof *f);
+    f->op_mu = new std::recursive_mutex();
     f->n = n; f->p = p; f->r = r; f->q = q;
     f->device = device < 0 ? 0 : device;
     f->pid = getpid();
@@ -587,6 +603,9 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     if (!defer_matrix && fit_alloc_matrix(f, nr_max) != 0) { cocons_fit_destroy(f); return nullptr; }
 #undef CK
     if (engine_warm(f) != 0) { cocons_fit_destroy(f); return nullptr; }
+    // (return_locked: the caller goes on building the handle -- a batch slot, whose main stream may still be redrawn --, so it
+    // enters the registry with its operation lock held and no other thread's stream self-test can touch it before it is done)
+    if (return_locked) f->op_mu->lock();
     registry_add(f);
     return f;
 }
@@ -694,7 +713,8 @@ extern "C" cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double
         }
         prp[i + 1] = w2 + 1;
     }
-    cocons_fit *f = fit_create_impl(n, p, r, 0, pl.data(), pX.data(), pz.data(), nullptr, smooth_limits, device, false, true);
+    cocons_fit *f = fit_create_impl(n, p, r, 0, pl.data(), pX.data(), pz.data(), nullptr, smooth_limits, device, false, true,
+                                    true, true);       // (registered with its operation lock held: it is still being built)
     if (!f) return nullptr;
     // envelope per tile column: row i of the factor is non-zero from its first stored column on
     f->taper_hi = new std::vector<int>(f->nt, 0);
@@ -734,7 +754,7 @@ extern "C" cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double
             if (!(pk && atoi(pk) == 0) && f->taper_maxband < f->nt) f->skew = f->taper_maxband;
         }
     }
-    if (fit_alloc_matrix(f, r + p) != 0) { cocons_fit_destroy(f); return nullptr; }
+    if (fit_alloc_matrix(f, r + p) != 0) { f->op_mu->unlock(); cocons_fit_destroy(f); return nullptr; }
     // the device keeps the lower triangle of the pattern only (the upper half is never evaluated)
     {
         int w2 = 0;
@@ -758,6 +778,7 @@ extern "C" cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double
              hipMemcpy(f->d_thi, f->taper_hi->data(), (size_t)f->nt * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) {
         fail(-100, "cocons_fit_create_taper: device allocation or upload failed");
+        f->op_mu->unlock();
         cocons_fit_destroy(f);
         return nullptr;
     }
@@ -765,6 +786,7 @@ extern "C" cocons_fit *cocons_fit_create_taper(int n, int p, int r, const double
     // inside a narrow envelope the trailing updates are too short to hide the engine's hand-offs behind (4.9 against
     // 4.7 ms at n = 10^4): plain schedule
     if (!f->taper_hi->empty()) f->engine_ok = false;
+    f->op_mu->unlock();
     return f;
 }
 
@@ -788,7 +810,7 @@ extern "C" void *cocons_fit_stream(cocons_fit *f) { return f ? (void *)f->stream
 
 extern "C" int cocons_fit_set_stream(cocons_fit *f, void *stream)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     // both streams idle before the swap: no event wait of the panel stream may refer to work on a
     // stream that is about to be destroyed
     HIPCHK(hipStreamSynchronize(f->stream));
@@ -800,7 +822,7 @@ extern "C" int cocons_fit_set_stream(cocons_fit *f, void *stream)
 
 extern "C" int cocons_fit_sync(cocons_fit *f)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     HIPCHK(hipStreamSynchronize(f->stream));
     return 0;
 }
@@ -1166,7 +1188,7 @@ static void count_update_flops(cocons_fit *f, int kw, int t0)
 // a whole update to drain; with workgroups that wait for the engine on every CU it would never be placed.)
 static bool engine_wanted(cocons_fit *f, const FactorView &v)
 {
-    return engine_enabled() && f->engine_ok && f->engine_skip == 0 && v.nt > 4;
+    return engine_enabled() && f->engine_ok && f->stream2 != nullptr && f->engine_skip == 0 && v.nt > 4;
 }
 
 // the hand-off words and tile counters of one factorisation with nt tiles, zeroed on the main stream
@@ -1250,16 +1272,25 @@ static int engine_warm(cocons_fit *f)
         // four most recent other handles are looked at, and a handle that finds no clash-free draw KEEPS its engine: four
         // hardware queues cannot keep a dozen live handles apart, and a clash only matters between handles that work at
         // the same moment (a test that holds twelve idle handles must not lose the engine on four of them).
+        // Threads (round 6, the advisor's finding): the probe launches kernels on ANOTHER handle's streams.  It takes that handle's
+        // operation lock first -- try_lock, under the registry's lock: a handle some thread is working on is busy and not probed, a
+        // handle being destroyed has left the registry, and a handle that IS probed can neither be used nor destroyed until the
+        // probe is over (cocons_fit_destroy waits for the lock) --, and it leaves streams the library does not own alone
+        // (cocons_fit_set_stream: a caller's stream may carry the caller's own work).  This handle is not in the registry yet and
+        // not in anybody's hands: redrawing ITS streams is safe here, and nowhere later.
         unsigned *words = f->dflags + 3 * (size_t)f->flags_cap + 8;
         for (int round = 0; ok == 1 && round < 8; ++round) {
             std::vector<cocons_fit *> others;
             {
                 std::lock_guard<std::mutex> lk(g_reg_mutex);
-                for (cocons_fit *o : g_registry)
-                    if (o != f && o->pid == f->pid && o->device == f->device && o->stream && o->stream2 && o->engine_ok &&
-                        hipStreamQuery(o->stream) == hipSuccess && hipStreamQuery(o->stream2) == hipSuccess)
-                        others.push_back(o);
-                if (others.size() > 4) others.erase(others.begin(), others.end() - 4);
+                for (size_t i = g_registry.size(); i-- > 0 && others.size() < 4;) {      // the four most recent ones
+                    cocons_fit *o = g_registry[i];
+                    if (o == f || o->pid != f->pid || o->device != f->device || !o->own_stream || !o->stream || !o->stream2 ||
+                        !o->engine_ok || !o->op_mu->try_lock())
+                        continue;
+                    if (hipStreamQuery(o->stream) == hipSuccess && hipStreamQuery(o->stream2) == hipSuccess) others.push_back(o);
+                    else o->op_mu->unlock();
+                }
             }
             (void)hipGetLastError();
             int clash = 0;                 // 1: this engine stream beside another main stream; 2: this main stream beside another engine
@@ -1273,6 +1304,7 @@ static int engine_warm(cocons_fit *f)
                     if (b == 0) { clash = 2; break; }
                 }
             }
+            for (cocons_fit *o : others) o->op_mu->unlock();      // (streams_run_concurrently drains both streams before it returns)
             if (ok != 1 || clash == 0) break;
             hipStream_t &mine = clash == 1 ? f->stream2 : f->stream;
             losers.push_back(mine);
@@ -1393,7 +1425,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
 extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int *steps_out, unsigned long long *stamps_out,
                                             unsigned long long *engine_out)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (!f->ddag_steps) return fail(-1, "cocons_debug_dag_trace: no DAG factorisation on this handle yet");
     if (nsteps_out) *nsteps_out = f->dag_nsteps;
     HIPCHK(hipStreamSynchronize(f->stream));
@@ -1418,7 +1450,7 @@ extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int 
 // Returns the number of chain tasks (0: classic layout); null output: the count only.
 extern "C" long long cocons_debug_chain_trace(cocons_fit *f, unsigned long long *stamps_out)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (!f->ddag_steps) return fail(-1, "cocons_debug_chain_trace: no DAG factorisation on this handle yet");
     if (stamps_out && f->dag_nctasks) {
         if (!f->ddag_trace || f->dag_trace_tasks != f->dag_ntasks) return fail(-1, "cocons_debug_chain_trace: tracing was off");
@@ -1837,7 +1869,7 @@ static int sharded_eval(cocons_fit *f, const double *theta, const double *mean, 
 extern "C" int cocons_neg2loglik_dense(cocons_fit *f, const double *theta, const double *mean,
                                        double *sum_logliks, double *parts)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (!theta || !mean || !sum_logliks) return fail(-1, "cocons_neg2loglik_dense: null argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_dense: fit has no z");
     if (f->coll_kind < 0) return fail(-7, "cocons_neg2loglik_dense: the communicator of this fit was aborted after an error");
@@ -1907,24 +1939,30 @@ static void slot_stream_apart(cocons_fit *f, cocons_fit *c)
 
 static cocons_fit *clone_for_slot(cocons_fit *f, bool want_engine)
 {
+    // (a clone enters the registry with its operation lock held -- fit_create_impl(..., return_locked) -- and keeps it until it
+    // is complete: its main stream may still be redrawn below, which no other thread's stream self-test may see half done)
     if (f->taper_nnz <= 0) {
         cocons_fit *c = fit_create_impl(f->n_user, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
-                                        f->smooth_limits, f->device, true, false, want_engine);
+                                        f->smooth_limits, f->device, true, false, want_engine, true);
         if (c) {
-            if (!c->dflags && flags_reset(c, c->nt) != 0) { cocons_fit_destroy(c); return nullptr; }
+            if (!c->dflags && flags_reset(c, c->nt) != 0) { c->op_mu->unlock(); cocons_fit_destroy(c); return nullptr; }
             hipStreamSynchronize(c->stream);
             slot_stream_apart(f, c);
+            c->engine_ok = c->engine_ok && c->stream2 != nullptr;
+            c->op_mu->unlock();
         }
         return c;
     }
     cocons_fit *c = fit_create_impl(f->n_user, f->p, f->r, 0, f->h_locs->data(), f->h_X->data(), f->h_z->data(), nullptr,
-                                    f->smooth_limits, f->device, false, true, false);      // h_* of a taper handle are in ITS order;
+                                    f->smooth_limits, f->device, false, true, false, true);      // h_* of a taper handle are in ITS order;
     if (!c) return nullptr;                                                                  // band-limited: never an engine
-    if (!c->dflags && flags_reset(c, c->nt) != 0) { cocons_fit_destroy(c); return nullptr; }
+    struct Unlock { cocons_fit *c; ~Unlock() { if (c) c->op_mu->unlock(); } } unlock{c};
+    auto drop = [&]() { unlock.c = nullptr; c->op_mu->unlock(); cocons_fit_destroy(c); return (cocons_fit *)nullptr; };
+    if (!c->dflags && flags_reset(c, c->nt) != 0) return drop();
     hipStreamSynchronize(c->stream);
     slot_stream_apart(f, c);
     c->skew = f->skew;                        // the same (packed) buffer layout as the original
-    if (fit_alloc_matrix(c, f->r + f->p) != 0) { cocons_fit_destroy(c); return nullptr; }
+    if (fit_alloc_matrix(c, f->r + f->p) != 0) return drop();
     const size_t nnz = (size_t)f->taper_nnz;
     bool ok = hipMalloc(&c->d_tci, nnz * sizeof(int)) == hipSuccess &&
               hipMalloc(&c->d_trp, (size_t)(f->n + 1) * sizeof(int)) == hipSuccess &&
@@ -1940,16 +1978,19 @@ static cocons_fit *clone_for_slot(cocons_fit *f, bool want_engine)
         ok = hipMalloc(&c->d_thi, (size_t)f->nt * sizeof(int)) == hipSuccess &&
              hipMemcpyAsync(c->d_thi, f->d_thi, (size_t)f->nt * sizeof(int), hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
     if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
-    if (!ok) { cocons_fit_destroy(c); return nullptr; }
+    if (!ok) return drop();
     c->taper_nnz = f->taper_nnz;
-    c->engine_ok = f->engine_ok;              // a band-limited handle never uses the engine, nor do its clones
+    // a band-limited handle never uses the engine, nor do its clones; a taper handle WITHOUT an envelope (COCONS_TAPER_BAND=0)
+    // may -- but this clone was created without an engine stream (want_engine = false), and an engine launched on a null
+    // stream would land on the NULL stream the library never touches (round 5's regression, the advisor's finding)
+    c->engine_ok = f->engine_ok && c->stream2 != nullptr;
     return c;
 }
 
 extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thetas, const double *means,
                                        double *values, int *status)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (nb < 0 || (nb > 0 && (!thetas || !means || !values || !status)))
         return fail(-1, "cocons_neg2loglik_batch: bad argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_batch: fit has no z");
@@ -1978,9 +2019,14 @@ extern "C" int cocons_neg2loglik_batch(cocons_fit *f, int nb, const double *thet
     // every extra slot is a clone of the handle with its own n x n factorisation buffer
     // (lda * npad * 8 bytes: 0.83 GB at n = 10^4); if one cannot be created (out of memory) the
     // batch runs on the slots that exist -- slot 0 is the fit itself, so it always completes
+    // (the slots are handles of their own in the registry: held for the whole call, like the handle itself, so that no other
+    // thread's stream self-test launches probe kernels between their evaluations)
+    std::vector<std::unique_lock<std::recursive_mutex>> slot_locks;
+    for (cocons_fit *c : *f->slots) slot_locks.emplace_back(*c->op_mu);
     while ((int)f->slots->size() < S - 1) {
         cocons_fit *c = clone_for_slot(f, eng_mode);
         if (!c) { (void)hipGetLastError(); break; }
+        slot_locks.emplace_back(*c->op_mu);
         f->slots->push_back(c);
     }
     const bool engine_saved = f->engine_ok;
@@ -2101,7 +2147,7 @@ static int profile_tail(cocons_fit *f, int nxb, double n_eff, bool reml, double 
 
 extern "C" int cocons_neg2loglik_profile(cocons_fit *f, const double *theta, double *sum_logliks, double *parts)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (int rc = no_taper(f, "cocons_neg2loglik_profile")) return rc;
     if (!theta || !sum_logliks) return fail(-1, "cocons_neg2loglik_profile: null argument");
     if (f->r < 1 || f->q < 1) return fail(-1, "cocons_neg2loglik_profile: fit needs z and x_betas");
@@ -2118,7 +2164,7 @@ extern "C" int cocons_neg2loglik_profile(cocons_fit *f, const double *theta, dou
 
 extern "C" int cocons_neg2loglik_reml(cocons_fit *f, const double *theta, int rank, double *sum_logliks, double *parts)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (int rc = no_taper(f, "cocons_neg2loglik_reml")) return rc;
     if (!theta || !sum_logliks) return fail(-1, "cocons_neg2loglik_reml: null argument");
     if (f->r < 1) return fail(-1, "cocons_neg2loglik_reml: fit has no z");
@@ -2136,7 +2182,7 @@ extern "C" int cocons_neg2loglik_reml(cocons_fit *f, const double *theta, int ra
 // ---------------------------------------------------------------------------
 extern "C" int cocons_fit_profile(cocons_fit *f, const double *theta, const double *mean, int reps, double *ms)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (int rc = no_taper(f, "cocons_fit_profile")) return rc;
     if (!theta || !mean || !ms || reps < 1) return fail(-1, "cocons_fit_profile: bad argument");
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -2358,7 +2404,7 @@ extern "C" int cocons_cov_rns_taper_pred(int n, int m, int p, const double *thet
 extern "C" int cocons_cov_rows(cocons_fit *f, const double *theta, int classic, int nidx, const int *idx, int cor,
                                double *out)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (int rc = no_taper(f, "cocons_cov_rows")) return rc;
     if (!theta || nidx <= 0 || !idx || !out) return fail(-1, "cocons_cov_rows: bad argument");
     const int n = f->n_user, p = f->p;          // (works on the host copies: the caller's observations in the caller's order)
@@ -2404,7 +2450,7 @@ extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const do
                                     int m, const double *locs_pred, const double *X_pred,
                                     double *stochastic, double *quadform)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (int rc = no_taper(f, "cocons_predict_dense")) return rc;
     if (!theta || !mean || m <= 0 || !locs_pred || !X_pred || !stochastic || !quadform || z_col < 0 || z_col >= f->r)
         return fail(-1, "cocons_predict_dense: bad argument");
@@ -2481,7 +2527,7 @@ extern "C" int cocons_predict_taper(cocons_fit *f, const double *theta, const do
                                     const int *colindices_pred, const int *rowpointers_pred,
                                     const double *taper_entries_pred, double *stochastic, double *quadform)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (f->taper_nnz <= 0) return fail(-1, "cocons_predict_taper: not a taper fit");
     if (!theta || !mean || m <= 0 || !locs_pred || !X_pred || !stochastic || !quadform || z_col < 0 || z_col >= f->r ||
         nnz_pred < 0 || !rowpointers_pred || (nnz_pred > 0 && (!colindices_pred || !taper_entries_pred)))
@@ -2577,7 +2623,7 @@ extern "C" int cocons_predict_taper(cocons_fit *f, const double *theta, const do
 extern "C" int cocons_sim_dense(cocons_fit *f, const double *theta, const double *mean, int classic,
                                 int nsim, const double *iiderrors, double *out)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (int rc = no_taper(f, "cocons_sim_dense")) return rc;
     if (!theta || !mean || nsim <= 0 || !iiderrors || !out) return fail(-1, "cocons_sim_dense: bad argument");
     if (f->sorted) {
@@ -2646,7 +2692,7 @@ extern "C" int cocons_sim_cond_dense(cocons_fit *f, const double *theta, const d
                                      int m, const double *locs_pred, const double *X_pred,
                                      const double *locs_unobs, int nsim, const double *iiderrors, double *out)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (int rc = no_taper(f, "cocons_sim_cond_dense")) return rc;
     if (!theta || !mean || m <= 0 || !locs_pred || !X_pred || !locs_unobs || nsim <= 0 || !iiderrors || !out ||
         z_col < 0 || z_col >= f->r)
@@ -3048,7 +3094,7 @@ extern "C" int cocons_comm_unique_id(void *id_out)
 
 extern "C" int cocons_fit_comm_init(cocons_fit *f, int nranks, int rank, const void *idp)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (int rc = no_taper(f, "cocons_fit_comm_init")) return rc;
     if (!idp || nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "cocons_fit_comm_init: bad argument");
     if (f->coll_kind) return fail(-1, "cocons_fit_comm_init: the fit already has collectives");
@@ -3076,7 +3122,7 @@ extern "C" int cocons_fit_comm_init(cocons_fit *f, int nranks, int rank, const v
 extern "C" int cocons_fit_set_collectives(cocons_fit *f, int rank, int world, cocons_bcast_fn bcast,
                                           cocons_allreduce_fn allreduce, void *user)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (int rc = no_taper(f, "cocons_fit_set_collectives")) return rc;
     if (world < 1 || rank < 0 || rank >= world || !bcast || !allreduce)
         return fail(-1, "cocons_fit_set_collectives: bad argument");
@@ -3088,7 +3134,7 @@ extern "C" int cocons_fit_set_collectives(cocons_fit *f, int rank, int world, co
 
 extern "C" int cocons_fit_set_allgather(cocons_fit *f, cocons_allgather_fn allgather)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (f->coll_kind != 2) return fail(-1, "cocons_fit_set_allgather: call cocons_fit_set_collectives first");
     f->cb_allgather = allgather;
     return 0;
@@ -3382,6 +3428,8 @@ extern "C" int cocons_multi_neg2loglik_dense(cocons_multi *m, const double *thet
     RcclApi *R = rccl_api();
     if (!R) return -1;
     const int W = m->ndev;
+    std::vector<std::unique_lock<std::recursive_mutex>> op_locks;       // (this entry point drives the ranks' handles directly)
+    for (int d = 0; d < W; ++d) op_locks.emplace_back(*m->fits[d]->op_mu);
     for (int d = 0; d < W; ++d) {
         if (int rc = fit_check(m->fits[d])) return rc;
         if (int rc = shard_begin(m->fits[d], theta, mean, d, W)) return rc;
@@ -3585,7 +3633,7 @@ panel_diff_kernel(const double *P, const double *L, size_t lda, int c0, int c1, 
 
 extern "C" int cocons_debug_dag_replay(cocons_fit *f, const double *theta, const double *mean, int reps, double *out)
 {
-    if (int rc = fit_check(f)) return rc;
+    FIT_ENTER(f);
     if (int rc = no_taper(f, "cocons_debug_dag_replay")) return rc;
     if (!theta || !mean || !out || reps < 1) return fail(-1, "cocons_debug_dag_replay: bad argument");
     if (f->r < 1 || f->coll_kind) return fail(-1, "cocons_debug_dag_replay: needs a plain dense fit with z");
