@@ -48,9 +48,25 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (= fp64 vector 
 #                                  x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 issues every 64 cycles
 MFMA_UTIL_PROFILE = "r03_update_kernel_mfma_util.json"      # matrix pipe busy fraction of the update kernel (rocprofv3 --pmc)
 TRAFFIC_PROFILE = "r03_update_kernel_hbm_traffic.json"
-# the persistent launch (dag_kernel) replayed alone under the counters (round 5: tools/dag_replay.py, tools/r5_pmc_dag.sh)
-DAG_UTIL_PROFILE = "r05_dag_kernel_mfma_util.json"
-DAG_TRAFFIC_PROFILE = "r05_dag_kernel_hbm_traffic.json"
+# the persistent launch (dag_kernel) replayed alone under the counters (tools/dag_replay.py, `tools/gpu_run.sh pmc_dag`): the newest
+# round's pair that is committed under profiles/
+def _newest_profile(suffix):
+    for tag in ("r06", "r05"):
+        if os.path.exists(os.path.join(ROOT, "profiles", tag + suffix)):
+            return tag + suffix
+    return "r05" + suffix
+
+
+DAG_UTIL_PROFILE = _newest_profile("_dag_kernel_mfma_util.json")
+DAG_TRAFFIC_PROFILE = _newest_profile("_dag_kernel_hbm_traffic.json")
+
+
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) of the source of the factorisation kernels: a stored counter profile records it
+    (tools/summarize_pmc_dag.py), and the roofline block says whether the profile still describes the kernel being timed."""
+    import hashlib
+    with open(os.path.join(ROOT, "cocons_amd", "csrc", "chol.hip"), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
 
 
 def chol_flops(n):
@@ -559,6 +575,9 @@ def main():
                         dj = json.load(fh)
                     with open(dmu) as fh:
                         uj = json.load(fh)
+                    # the stored counters describe the kernel source they were taken with: say so when that is not this tree's
+                    prof_sha = dj.get("kernel_source_sha16")
+                    roofline["counter_profile_matches_kernel_source"] = (prof_sha == kernel_source_sha16()) if prof_sha else None
                     roofline["traffic"] = dj.get("hbm_bytes_per_launch")
                     roofline["traffic_high"] = dj.get("hbm_bytes_per_launch_high")
                     roofline["traffic_l2_hit_rate"] = dj.get("l2_hit_rate")
@@ -566,7 +585,7 @@ def main():
                     # and step) + the panels once
                     roofline["traffic_algorithmic"] = round(16.0 * st["dag_flops"] / (2.0 * 256.0), 1)
                     roofline["traffic_source"] = ("NOT measured in this run: profiles/%s (FETCH_SIZE raw + WRITE_SIZE of cocons::dag_kernel "
-                                                  "replayed alone, tools/r5_pmc_dag.sh, commit %s); `traffic_high` applies the guide's "
+                                                  "replayed alone, `tools/gpu_run.sh pmc_dag`, commit %s); `traffic_high` applies the guide's "
                                                   "x2 to FETCH_SIZE (calibrated for 16 B/lane reads; the C tiles are read 8 B/lane); "
                                                   "`traffic_algorithmic` = C read + write once per step at K = 256"
                                                   % (DAG_TRAFFIC_PROFILE, dj.get("commit", "?")))

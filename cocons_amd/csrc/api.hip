@@ -283,14 +283,11 @@ struct cocons_fit {
     double *dpart;                // early halves of the split diagonal-block tiles (2 x 16 x 64 x 64 doubles)
     unsigned *ddag; size_t ddag_words;      // [queue (64 words)] [tdone] [pdone]
     void *ddag_steps; int dag_nsteps; unsigned dag_ntasks;
-    unsigned dag_nctasks;         // chain layout: tasks of the chain helpers (0: classic layout -- everything in the one list)
-    void *ddag_chain;             // chain layout: device copy of the launch's task words for the helpers (launch_chain_args)
-    int dag_key[10];              // (nt, mt, trim, kskip, lead, min_tiles, split, lead2, lead3, chain) the step table was built for
+    int dag_key[10];              // (nt, mt, trim, kskip, lead, min_tiles, split, lead2, lead3, 0) the step table was built for
     unsigned long long *ddag_trace; size_t dag_trace_tasks;   // diagnostics (cocons_debug_tune("dag_trace", 1)): 4 stamps per task
     size_t dag_trace_elems;       // allocated 64-bit words of ddag_trace (5 per task + 8 per tile pair)
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
-    int dag_helpers_live;         // chain helpers in the engine launch of the factorisation being enqueued (0: none)
-    int engine_pair_live;         // 1: the engine launched for the next factorisation has a pair partner (counts itself like a helper)
+    int engine_pair_live;         // 1: the engine launched for the next factorisation has a pair partner (it counts itself in alive[2])
     int engine_t0;                // first tile of the engine launched for the next factorisation: 0 (it factors the first diagonal block too) or 2
     size_t smb_off, smb_elems;           // inside dmbox: strip mailboxes, one per diagonal block (the panel launch's next-diagonal-block
                                          // update), and xmb_off: the panel launch's exchange mailboxes, one per 64-row strip (split panel)
@@ -411,7 +408,6 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         hipFree(f->dflags);
         if (f->dmbox) hipFree(f->dmbox);
         hipFree(f->dP); hipFree(f->dWt); hipFree(f->ddag); hipFree(f->ddag_steps); hipFree(f->ddag_trace); hipFree(f->dpart);
-        hipFree(f->ddag_chain);
         hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_thi);
         if (f->cstream_l && f->cstream_l != f->cstream) { hipStreamSynchronize(f->cstream_l); hipStreamDestroy(f->cstream_l); }
         if (f->cstream) { hipStreamSynchronize(f->cstream); hipStreamDestroy(f->cstream); }
@@ -1015,12 +1011,6 @@ struct Tunables {
     int dag_split = 1;       // COCONS_DAG_SPLIT: the diagonal-block tiles of a DAG step in two halves, the first one off the chain
     int dag_xcc_quota = -1;  // workgroups of the DAG launch that take part on the engine's XCD (of the 255 that land there; 0: all;
                              // -1: derived from the device, dag_xcc_quota() -- 208 on MI355X)
-    int dag_chain = 0;       // COCONS_DAG_CHAIN: 1 = the tasks on the chain between two diagonal blocks are drawn by chain helpers --
-                             // workgroups of the engine's launch, a CU each -- instead of sitting in the persistent launch's list.
-                             // Built and measured in round 5: a chain-bound step takes 116 us instead of
-                             // the classic schedule's 125, and the eleven CUs it holds cost the chip-bound head as much again:
-                             // +0.1 .. +0.4 % at n = 10^4 (alternated in one process) -- not the default.
-    int dag_helpers = 10;    // COCONS_DAG_HELPERS: that many of them (one round of the ten tiles of a diagonal block)
     int engine_block0 = 1;   // COCONS_ENGINE_BLOCK0: 1 = the engine factors the FIRST diagonal block too (its input words raised by the gate
                              // kernel) and that block's panel is the one-launch panel of every other block; 0 = the first block on the
                              // plain schedule (tile | solve | in-panel update | tile | solve on the main stream), the engine from block 1
@@ -1044,6 +1034,11 @@ struct Tunables {
     int dag_trace = 0;       // (diagnostics) time stamps per task, cocons_debug_dag_trace
     int gate_sabotage = 0;   // (tests) the next N engine-schedule factorisations wait at the gate for a word nobody raises:
                              // a genuine 5 ms time-out, abort code 0x600, to exercise the fall-back and its book-keeping
+    // (tests) a LATE HOST: the thread that enqueues a factorisation sleeps host_delay_us microseconds in front of the launches that
+    // raise the engine's input word in[host_delay_tile] (COCONS_DEBUG_HOST_DELAY_US / _TILE) -- what a host thread throttled in
+    // mid-enqueue looks like to the resident engine (round 5's recorded time-out 0x112) --, and
+    // engine_in_wait_ms > 0 puts the bound of the engine's input waits back to that many milliseconds (rounds 2-4: 100)
+    int host_delay_us = 0, host_delay_tile = -1, engine_in_wait_ms = 0;
     bool init = false;
 };
 static Tunables &tun()
@@ -1060,8 +1055,6 @@ static Tunables &tun()
         rd("COCONS_DAG_MIN_TILES", t.dag_min_tiles);
         rd("COCONS_DAG_SPLIT", t.dag_split);
         rd("COCONS_DAG_XCC_QUOTA", t.dag_xcc_quota);
-        rd("COCONS_DAG_CHAIN", t.dag_chain);
-        rd("COCONS_DAG_HELPERS", t.dag_helpers);
         rd("COCONS_ENGINE_PAIR", t.engine_pair);
         rd("COCONS_ENGINE_BLOCK0", t.engine_block0);
         rd("COCONS_PANEL_FUSED", t.panel_fused);
@@ -1069,8 +1062,8 @@ static Tunables &tun()
         rd("COCONS_PANEL_FOLLOW", t.panel_follow);
         rd("COCONS_PANEL_DIAG", t.panel_diag);
         rd("COCONS_PANEL_SPLIT", t.panel_split);
-        if (t.dag_helpers < 1) t.dag_helpers = 1;
-        if (t.dag_helpers > 24) t.dag_helpers = 24;
+        rd("COCONS_DEBUG_HOST_DELAY_US", t.host_delay_us);
+        rd("COCONS_DEBUG_HOST_DELAY_TILE", t.host_delay_tile);
         t.init = true;
     }
     return t;
@@ -1097,8 +1090,6 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "dag_split") t.dag_split = value;
     else if (k == "dag_xcc_quota") t.dag_xcc_quota = value;
     else if (k == "dag_trace") t.dag_trace = value;
-    else if (k == "dag_chain") t.dag_chain = value;
-    else if (k == "dag_helpers") t.dag_helpers = value < 1 ? 1 : (value > 24 ? 24 : value);
     else if (k == "engine_pair") t.engine_pair = value;
     else if (k == "engine_block0") t.engine_block0 = value;
     else if (k == "panel_fused") t.panel_fused = value;
@@ -1107,6 +1098,9 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "panel_diag") t.panel_diag = value;
     else if (k == "panel_split") t.panel_split = value;
     else if (k == "gate_sabotage") t.gate_sabotage = value;
+    else if (k == "host_delay_us") t.host_delay_us = value;
+    else if (k == "host_delay_tile") t.host_delay_tile = value;
+    else if (k == "engine_in_wait_ms") t.engine_in_wait_ms = value;
     else if (k == "upd_waves") set_update_waves(value);
     else if (k == "w8_max_tiles") set_update_w8_max_tiles(value);
     else if (k == "c_wt") set_update_c_wt(value);
@@ -1375,13 +1369,11 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         f->dWt_tiles = v.nt;
     }
     const int kskip = (f->pad0 / 16) * 16;
-    const int chain = tun().dag_chain ? 1 : 0;
-    const int key[10] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, tun().dag_lead2, tun().dag_lead3, chain};
+    const int key[10] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, tun().dag_lead2, tun().dag_lead3, 0};
     if (memcmp(key, f->dag_key, sizeof key) != 0 || !f->ddag_steps) {
         std::vector<DagStepHost> steps;
-        unsigned nctasks = 0;
         const unsigned ntasks = dag_build_steps(v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, steps,
-                                                tun().dag_lead2, tun().dag_lead3, chain, &nctasks);
+                                                tun().dag_lead2, tun().dag_lead3);
         HIPCHK(hipStreamSynchronize(f->stream));
         if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->ddag_steps) { HIPCHK(hipFree(f->ddag_steps)); f->ddag_steps = nullptr; }
@@ -1390,8 +1382,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         // hardware queue of its own and shifted every later stream's assignment)
         HIPCHK(hipMemcpyAsync(f->ddag_steps, steps.data(), steps.size() * sizeof(DagStepHost), hipMemcpyHostToDevice, f->stream));
         HIPCHK(hipStreamSynchronize(f->stream));
-        f->dag_nsteps = (int)steps.size(); f->dag_ntasks = ntasks; f->dag_nctasks = nctasks;
-        if (!f->ddag_chain) HIPCHK(hipMalloc(&f->ddag_chain, dag_chain_args_bytes()));
+        f->dag_nsteps = (int)steps.size(); f->dag_ntasks = ntasks;
         memcpy(f->dag_key, key, sizeof key);
         const size_t T64 = 2 * (size_t)v.mt;
         const size_t words = 64 + T64 * (T64 + 1) / 2 + (steps.size() + 2) * T64 + steps.size() + 64 + 16 * (steps.size() + 2);
@@ -1404,7 +1395,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
     HIPCHK(hipMemsetAsync(f->ddag, 0, f->ddag_words * sizeof(unsigned), f->stream));
     // trace buffer: 4 stamps + one word of hw_where() pairs per task, 8 stamps per tile pair of the engine -- sized by BOTH
     // the task count and the tile count of THIS step table (a later table with fewer tasks and more tiles must not run past it)
-    const size_t trace_elems = (size_t)f->dag_ntasks * 5 + 8 * (size_t)(v.nt + 2) + 4 * (size_t)f->dag_nctasks;     // (+ 4 stamps per chain task)
+    const size_t trace_elems = (size_t)f->dag_ntasks * 5 + 8 * (size_t)(v.nt + 2);
     if (tun().dag_trace && f->dag_trace_elems < trace_elems) {
         HIPCHK(hipStreamSynchronize(f->stream));
         if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
@@ -1446,22 +1437,6 @@ extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int 
     return (long long)f->dag_ntasks;
 }
 
-// ... and of the chain helpers' tasks (chain layout): stamps_out = nctasks x 4 ticks (drawn, inputs complete, product done, stored).
-// Returns the number of chain tasks (0: classic layout); null output: the count only.
-extern "C" long long cocons_debug_chain_trace(cocons_fit *f, unsigned long long *stamps_out)
-{
-    FIT_ENTER(f);
-    if (!f->ddag_steps) return fail(-1, "cocons_debug_chain_trace: no DAG factorisation on this handle yet");
-    if (stamps_out && f->dag_nctasks) {
-        if (!f->ddag_trace || f->dag_trace_tasks != f->dag_ntasks) return fail(-1, "cocons_debug_chain_trace: tracing was off");
-        HIPCHK(hipStreamSynchronize(f->stream));
-        HIPCHK(hipMemcpyAsync(stamps_out, f->ddag_trace + 5 * (size_t)f->dag_ntasks + 8 * (size_t)(f->nt + 2),
-                              4 * (size_t)f->dag_nctasks * sizeof(unsigned long long), hipMemcpyDeviceToHost, f->stream));
-        HIPCHK(hipStreamSynchronize(f->stream));
-    }
-    return (long long)f->dag_nctasks;
-}
-
 static int engine_start(cocons_fit *f, const FactorView &v)
 {
     if (f->engine_live) return 0;
@@ -1480,24 +1455,12 @@ static int engine_start(cocons_fit *f, const FactorView &v)
     HIPCHK(hipEventRecord(f->ev_eng, M));                    // (behind the resets of the flag and task words, and of W / P when new)
     HIPCHK(hipStreamWaitEvent(f->stream2, f->ev_eng, 0));
     unsigned *alive_w = f->dflags + 3 * (size_t)f->flags_cap;
-    const bool helpers = f->dag_next && f->dag_nctasks > 0;
-    if (helpers) {
-        const size_t T64 = 2 * (size_t)v.mt;
-        unsigned *queue = f->ddag, *tdone = f->ddag + 64, *pdone = tdone + T64 * (T64 + 1) / 2;
-        unsigned *pall = pdone + ((size_t)f->dag_nsteps + 2) * T64;
-        unsigned *dcount = pall + (size_t)f->dag_nsteps + 64;
-        launch_chain_args(f->ddag_chain, v.A, v.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_nctasks,
-                          queue, tdone, pdone, (int)T64, pall, f->dpart, dcount, in, out, xr, (unsigned *)(f->dinfo + 1), alive_w,
-                          f->stream2, f->dag_trace_tasks ? f->ddag_trace + 5 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2) : nullptr);
-    }
-    f->dag_helpers_live = helpers ? tun().dag_helpers : 0;
     f->engine_t0 = (tun().engine_block0 && !v.hi) ? 0 : 2;
     launch_potrf_engine(v.A, v.lda, f->engine_t0, nt, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
                         alive_w, f->stream2, f->dag_next ? f->dWt : nullptr,
                         f->dag_next ? f->dP : nullptr, f->dag_next ? 2 * f->dag_nsteps : 0,
                         (f->dag_next && f->dag_trace_tasks) ? f->ddag_trace + 4 * (size_t)f->dag_ntasks : nullptr,
-                        helpers ? f->ddag_chain : nullptr, f->dag_helpers_live,
-                        f->engine_pair_live ? f->dmbox : nullptr);
+                        f->engine_pair_live ? f->dmbox : nullptr, tun().engine_in_wait_ms);
     f->engine_live = true;
     return 0;
 }
@@ -1572,7 +1535,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     if (tun().gate_sabotage > 0) { --tun().gate_sabotage; alive += 1; }      // (tests: a word that stays zero)
     const bool block0 = f->engine_t0 == 0;           // the engine factors the first diagonal block too: the gate raises its input words
     launch_engine_gate(alive, abort_word, M, false, f->engine_ops++ == 0,
-                       (f->dag_next ? f->dag_helpers_live : 0) + f->engine_pair_live,       // (chain helpers and the pair partner count themselves)
+                       f->engine_pair_live,       // (the pair partner counts itself)
                        (block0 && tun().gate_sabotage == 0 && alive == f->dflags + 3 * (size_t)f->flags_cap) ? in : nullptr);
     const int rend = mt * TILE - 64 * v.trim;         // one past the last row any panel kernel touches
     // the panel of the block at tile t (behind the engine's factorisation of it): one launch or three; returns the tiles of the NEXT
@@ -1612,7 +1575,6 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     int diag_done = 0;                                // tiles of the diagonal block at t that the previous panel's launch has updated
     if (block0) diag_done = panel_for(0, !f->dag_next);          // (the persistent launch updates its first diagonal block itself)
     else panel_ops(f, v, 0, M);
-    if (f->dag_next && f->dag_helpers_live > 0) launch_raise_word(alive + 3, M);      // the chain helpers may touch the matrix now
     f->dag_used = f->dag_next;
     int k_first = 0;                 // first block step the classic loop below runs in full
     if (f->dag_next) {
@@ -1635,8 +1597,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         }
         launch_dag(v.A, v.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
                    pdone, (int)T64, pall, f->dpart, dcount, in, out, xr, abort_word, M, f->dag_trace_tasks ? f->ddag_trace : nullptr,
-                   alive, dag_xcc_quota(), f->dag_trace_tasks ? (unsigned *)(f->ddag_trace + 4 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2)) : nullptr,
-                   f->dag_helpers_live > 0 ? f->dag_nctasks : 0u);
+                   alive, dag_xcc_quota(), f->dag_trace_tasks ? (unsigned *)(f->ddag_trace + 4 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2)) : nullptr);
         if (ev_upd) { hipEventRecord(eb, M); ev_upd->push_back(ea); ev_upd->push_back(eb); f->dag_events = 1; }
         k_first = 2 * f->dag_nsteps;
     }
@@ -1647,6 +1608,9 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
     // in round 4))
     for (int k = k_first > 0 ? k_first - 2 : 0; k + 2 < nt; k += 2) {
         const int t = k + 2;
+        // (tests: a late host -- whatever raises in[host_delay_tile], the panel launch of block t or the update launch behind it,
+        // is enqueued host_delay_us late, while the engine has everything it needs to get there and wait)
+        if (tun().host_delay_us > 0 && t + 2 == tun().host_delay_tile) usleep((useconds_t)tun().host_delay_us);
         if (k >= k_first) {                          // (the update with the last DAG step's panel was that launch's)
             if (ev_upd) count_update_flops(f, 2, t);
             timed_update(f, v, k, 2, t, nt, M, ev_upd, in, t, tile_queue(f, k), diag_done);
@@ -1737,17 +1701,6 @@ static int info_status(cocons_fit *f)
     // 0x800 panel product (mode 3), 0x900 the reductions waiting for the engine's last tile)
     if (f->hinfo[1] != 0 && getenv("COCONS_DEBUG_ABORT")) {
         fprintf(stderr, "cocons: hand-off time-out, code 0x%x\n", f->hinfo[1]);
-        if (f->dag_used && f->dag_helpers_live > 0 && f->dflags) {
-            // where the chain helpers stand (chain_helper_loop's progress words) and the engine's flag words
-            unsigned w[64], cq[64];
-            hipMemcpyAsync(w, f->dflags + 3 * (size_t)f->flags_cap, sizeof w, hipMemcpyDeviceToHost, f->stream);
-            hipMemcpyAsync(cq, f->ddag, sizeof cq, hipMemcpyDeviceToHost, f->stream);
-            hipStreamSynchronize(f->stream);
-            fprintf(stderr, "cocons: chain helpers: alive %u, resident %u, go %u, chain counter %u of %u; per helper (task, stage):", w[0], w[2], w[3],
-                    cq[32], f->dag_nctasks);
-            for (int h = 1; h <= f->dag_helpers_live && h < 32; ++h) fprintf(stderr, " (%u,%u)", w[24 + h] >> 4, w[24 + h] & 15u);
-            fprintf(stderr, "\n");
-        }
         if (f->dag_used && f->ddag && (f->hinfo[1] & 0xf00) >= 0xa00) {
             // a wait of the DAG launch: what it waited for (dag_wait's record) and what the word holds NOW
             unsigned rec[7] = {0, 0, 0, 0, 0, 0, 0}, now = 0, qn = 0;
@@ -3037,7 +2990,7 @@ static int shard_factor_diag(cocons_fit *f, int k)
         // instead of behind the strip solve and the tile update: 78 -> ~56 us for the block)
         const bool pair = w == 2 && tun().engine_pair && f->dmbox && f->smb_off >= ((size_t)f->nt + 2) * ENGINE_MBOX_DOUBLES;
         launch_potrf_engine(A, f->lda, t, t + w, f->dinv, f->dinfo, in, out, xr, (unsigned *)(f->dinfo + 1),
-                            f->dflags + 3 * (size_t)f->flags_cap, s, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                            f->dflags + 3 * (size_t)f->flags_cap, s, nullptr, nullptr, 0, nullptr,
                             pair ? f->dmbox : nullptr);
     } else {
         launch_potrf_tile(A, f->lda, t * TILE, q0, f->dinfo, s);
@@ -3060,9 +3013,14 @@ static int shard_factor_diag(cocons_fit *f, int k)
 // ---- collectives: RCCL on the communication stream, or the caller's transport ----
 // COCONS_SHARD_COMM2 (default 1): the broadcasts of the factored diagonal blocks get a stream -- and, under RCCL, a
 // communicator -- of their own, so that the chain from one diagonal block to the next never queues behind the bulk exchange
+// COCONS_SHARD_COMM2=1: the broadcasts of the factored diagonal blocks get a stream -- and under RCCL a communicator
+// (ncclCommSplit) -- of their own.  OPT-IN since round 6 (the advisor's finding): two RCCL communicators working side by side,
+// one of them with receivers that sit resident until their owner has factored, have never run with more than one rank (a GPU
+// box of this pool has one GPU) -- default: one communicator, one communication stream, the broadcast still issued IN FRONT
+// of the all-gather.  tests/test_gpu_configs.py::test_native_sharded_rccl_two_gpus runs both forms where two devices exist.
 static bool shard_comm2()
 {
-    static const int v = [] { const char *e = getenv("COCONS_SHARD_COMM2"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char *e = getenv("COCONS_SHARD_COMM2"); return e ? atoi(e) : 0; }();
     return v != 0;
 }
 
@@ -3651,13 +3609,7 @@ extern "C" int cocons_debug_dag_replay(cocons_fit *f, const double *theta, const
     fv.dag_ok = true;
     if (!(tun().dag != 0 && !fv.hi && !fv.skew && fv.nt > 4)) return fail(-1, "cocons_debug_dag_replay: the DAG schedule does not apply to this fit");
     if (int rc = flags_reset(f, fv.nt)) return rc;
-    // (the replayed launch runs EVERY task itself -- the classic layout: under the counters no chain helper could run beside it;
-    // the handle's next evaluation rebuilds its own table)
-    const int chain_saved = tun().dag_chain;
-    tun().dag_chain = 0;
-    const int prc = dag_prepare(f, fv);
-    tun().dag_chain = chain_saved;
-    if (prc) return prc;
+    if (int prc = dag_prepare(f, fv)) return prc;
     if (f->dag_nsteps < 2) return fail(-1, "cocons_debug_dag_replay: problem too small for a DAG head");
     hipStream_t M = f->stream;
     const size_t lda = fv.lda;

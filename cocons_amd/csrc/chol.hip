@@ -640,14 +640,11 @@ struct EngineArgs {
                              // chain-bound rest the classic one, which needs neither)
     unsigned long long *trace;   // diagnostics (may be null): 8 stamps of the 100 MHz clock per tile pair t / 2 -- in[t] seen,
                              // tile t factored, out[t] raised, in[t+1] seen, xr[t] raised, tile t+1 updated, factored, out[t+1] raised
-    const struct DagArgs *chain; // DAG schedule, chain layout (round 5): device copy of the launch's task words -- the workgroups
-    int nhelp;                   // 8, 16, ... 8 nhelp of this launch are CHAIN HELPERS (chain_helper_loop); null / 0: none
+    unsigned long long in_ticks; // bound of the waits for the INPUT words in[t] / in[t+1]: they are paced by the host (the launch that
+                                 // raises them may not be enqueued yet), HOST_PACED_TICKS unless a test shortens it
     double *mbox;                // pair mode: the tiles' mailboxes, 44 x 256 doubles each (index: tile), filled with ~0 (potrf_tile_body)
     int partner;                 // pair mode: index of the PAIR PARTNER's workgroup in this launch (engine_partner_loop); 0: none
 };
-
-struct DagArgs;
-__device__ __forceinline__ void chain_helper_loop(const DagArgs *ap);
 
 // Following a tile's factorisation through its mailbox (potrf_tile_body: mbox), shared by the engine's partner and the followers of
 // potrf_follow_kernel.  In scope: tid, lane, half = tid >> 8 (wave-uniform), mb = the tile's mailbox, double v[5], int *okp (LDS).
@@ -762,7 +759,7 @@ __device__ __forceinline__ void engine_partner_loop(const EngineArgs &e, double 
         __hip_atomic_fetch_add(e.alive + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int t = e.t0; t + 1 < e.nt; t += 2) {
-        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t, HOST_PACED_TICKS) ? 1 : 0;
+        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t, e.in_ticks) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
@@ -909,24 +906,22 @@ potrf_engine_kernel(EngineArgs e)
     double *A = e.A;
     const size_t lda = e.lda;
     if (blockIdx.x != 0) {
-        // Chain helpers (round 5): workgroups 8, 16, ... of this launch -- the ones the dispatcher deals to the same XCD as
-        // workgroup 0 (round robin over the eight XCDs; affinity only: chain_helper_loop registers where it really runs) -- each
-        // on a CU of its own like the engine (the launch's LDS request keeps everything else off it); behind them the pair
-        // partner.  The others leave at once.
+        // The pair partner: workgroup 8 of this launch -- the one the dispatcher deals to the same XCD as workgroup 0 (round robin
+        // over the eight XCDs; affinity only: the partner registers where it really runs) --, on a CU of its own like the engine
+        // (the launch's LDS request keeps everything else off it).  The others leave at once.
         if (e.partner != 0 && (int)blockIdx.x == e.partner) engine_partner_loop<DAG>(e, smem);
-        else if (DAG && e.chain && (blockIdx.x & 7u) == 0u && (int)(blockIdx.x >> 3) <= e.nhelp) chain_helper_loop(e.chain);
         return;
     }
     const bool pair = e.partner != 0;
-    // (the word also says WHERE: 1 + the id of the XCD the workgroup runs on; word 16 + XCD counts the engine's and the chain
-    // helpers' workgroups per XCD -- dag_kernel keeps those XCDs less than full)
+    // (the word also says WHERE: 1 + the id of the XCD the workgroup runs on; word 16 + XCD counts the workgroups of this launch
+    // per XCD -- the engine, its partner --: dag_kernel keeps those XCDs less than full)
     if (tid == 0) {
         const unsigned x = hw_where() >> 28;
         __hip_atomic_fetch_add(e.alive + 16 + (x & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(e.alive, 1u + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int t = e.t0; t < e.nt; t += 2) {
-        if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t, HOST_PACED_TICKS) ? 1 : 0;
+        if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t, e.in_ticks) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
@@ -952,7 +947,7 @@ potrf_engine_kernel(EngineArgs e)
         if (t + 1 >= e.nt) return;
         if (pair) continue;              // (the rest of the block is the partner's)
 
-        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t, HOST_PACED_TICKS) ? 1 : 0;
+        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t, e.in_ticks) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
@@ -1545,8 +1540,8 @@ __global__ void __launch_bounds__(64)
 engine_gate_kernel(unsigned *alive, unsigned *abort_word, unsigned code, unsigned long long ticks, unsigned nhelp,
                    unsigned *raise_in)
 {
-    // (nhelp > 0: the launch also holds chain helpers, which count themselves in alive[2] once resident: a chain task nobody
-    // resident can draw would stop the persistent launch as surely as a missing engine)
+    // (nhelp > 0: the engine's launch holds that many further workgroups -- the pair partner --, which count themselves in
+    // alive[2] once resident: a partner that found no CU would stop the factorisation as surely as a missing engine)
     // (raise_in: the engine also factors the FIRST diagonal block -- nobody updates it, so its input words are raised here, behind
     // everything the main stream did to the matrix before the factorisation: in[0] = 3, in[1] = 7)
     if (threadIdx.x == 0) {
@@ -1904,15 +1899,6 @@ struct DagStep {
     int split;              // this step's diagonal-block tiles only take the last 128 panel columns and add the early half's result
     unsigned p2, p3;        // positions inside the step of the T2 block and of the T3 block (T1 and the early halves sit at tpos):
                             // each group is placed where the chip gets to it about when the engine publishes what it waits for
-    // CHAIN LAYOUT (round 5, nc > 0): what lies on the chain from one diagonal block to the next is taken OUT of this list and
-    // drawn, from a counter of its own, by the chain helpers -- workgroups of the engine's launch, each on a CU of its own:
-    //   the nc (nc + 1) / 2 update tiles inside the next diagonal block, the panel tasks of the first `cs` strips (the rows of
-    //   the diagonal block AFTER that one) and the early halves.
-    // The bulk list then holds: the nc x (H - nc) tiles below the diagonal block in its columns ("near"), the trapezoid from
-    // column nc on, and the panel tasks of the strips cs .. nstrip - 1.
-    int nc;                 // 64-tiles across the next diagonal block (4; 2 for a last block of one tile); 0: classic layout
-    int cs;                 // strips of the next panel that belong to the chain helpers (min(nstrip, 4))
-    unsigned cbase, cnt;    // first chain task of the step, chain tasks of the step: diagonal tiles | T1 | early halves | T2 | T3
 };
 
 struct DagArgs {
@@ -1935,7 +1921,6 @@ struct DagArgs {
     unsigned *hw;                    // diagnostics (may be null): per task hw_where() when drawn and when stored
     unsigned long long *trace;       // diagnostics (may be null): per task 4 stamps of the 100 MHz clock -- drawn, inputs
                                      // complete, product done and previous C version there, stored and signalled
-    unsigned nctasks;                // chain layout: chain tasks in all (drawn by the helpers off queue[32]); 0: classic layout
 };
 
 // a bounded wait of dag_kernel: like wait_ge<false>, and when it runs out the waiter leaves a record in words 8 .. 13 of the
@@ -1996,7 +1981,7 @@ dag_kernel(DagArgs a)
     if (tid == 0) {
         bool take = true;
         if (a.xcc_quota) {
-            // (alive[16 + x]: workgroups of the engine's launch -- the engine, the chain helpers -- resident on XCD x; every one of
+            // (alive[16 + x]: workgroups of the engine's launch -- the engine, its partner -- resident on XCD x; every one of
             // them takes a CU, and an XCD that runs two queues holds seven of these workgroups per CU rather than eight)
             const unsigned myx = (hw_where() >> 28) & 7u;
             const unsigned c = __hip_atomic_load(a.alive + 16 + myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2028,7 +2013,7 @@ dag_kernel(DagArgs a)
         }
         const int t = st.tj0 >> 1;                           // first 128-tile of the next block
         // where in the step's list: tiles | T1, early halves | tiles | T2 | tiles | T3 | tiles
-        const unsigned per_u = 2u * (unsigned)(st.nstrip - st.cs), nA = per_u + (st.nc ? 0u : (unsigned)st.nd_next), perBC = st.two ? per_u : 0u;
+        const unsigned per_u = 2u * (unsigned)st.nstrip, nA = per_u + (unsigned)st.nd_next, perBC = st.two ? per_u : 0u;
         int tkind = -1;                                      // -1: update tile; 0, 1, 2: T1, T2, T3; 3: early half
         unsigned tu = 0, qt_u = q;                           // index inside its group; index among the step's update tiles
         if (q >= st.tpos) {
@@ -2052,26 +2037,7 @@ dag_kernel(DagArgs a)
         if (!isT) {
             const int qt = (int)qt_u;
             int ti, tj;
-            if (st.nc) {
-                // chain layout: first the nc x (H - nc) tiles below the diagonal block, column by column, then the trapezoid
-                // from column nc on (the tiles inside the diagonal block are the chain helpers')
-                const int Hn = st.H - st.nc, nrect = st.nc * Hn;
-                if (qt < nrect) {
-                    int jl = 0, r = qt;
-                    if (r >= Hn) { r -= Hn; ++jl; }
-                    if (r >= Hn) { r -= Hn; ++jl; }
-                    if (r >= Hn) { r -= Hn; ++jl; }
-                    tj = st.tj0 + jl; ti = st.tj0 + st.nc + r;
-                } else {
-                    const int q2 = qt - nrect;
-                    int jl = 0, jh = st.W - st.nc - 1;
-                    while (jl < jh) {
-                        const int mid = (jl + jh + 1) >> 1;
-                        if (mid * Hn - mid * (mid - 1) / 2 <= q2) jl = mid; else jh = mid - 1;
-                    }
-                    tj = st.tj0 + st.nc + jl; ti = tj + (q2 - (jl * Hn - jl * (jl - 1) / 2));
-                }
-            } else {
+            {
                 int jl = 0, jh = st.W - 1;
                 while (jl < jh) {
                     const int mid = (jl + jh + 1) >> 1;
@@ -2109,13 +2075,13 @@ dag_kernel(DagArgs a)
                 }
             }
         } else {
-            const int per = 2 * (st.nstrip - st.cs);
+            const int per = 2 * st.nstrip;
             const size_t c_t = (size_t)t * TILE, c_t1 = c_t + TILE;
             prio = 2;
             const int stage = tkind;     // (3: early half of a diagonal-block tile of the NEXT step)
             int strip = 0, h = 0, row64 = 0;
             if (stage != 3) {
-                strip = st.cs + (int)(tu >> 1); h = (int)(tu & 1u);
+                strip = (int)(tu >> 1); h = (int)(tu & 1u);
                 row64 = st.tj0 + (st.two ? 4 : 2) + strip;
                 strip_task = 1;
             }
@@ -2300,266 +2266,6 @@ dag_kernel(DagArgs a)
         }
         L = (unsigned)__builtin_amdgcn_readfirstlane((int)Lnext);
         if (L >= a.ntasks) break;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Chain helpers (round 5).  What lies on the chain from one diagonal block to the next under the dependency-driven schedule --
-//   the update tiles inside the next diagonal block (they feed the engine), and for the 256 rows of the diagonal block AFTER
-//   that one: T1 (X0 = B0 W(t)^T), the early halves of its tiles, T2 (B1 -= X0 X(t+1,t)^T), T3 (X1 = B1 W(t+1)^T)
-// -- were tile tasks of dag_kernel like everything else until round 4: drawn by workgroups that share their CU with seven
-// others, where a 64 x 64 x 256 product is memory latency per 8-column chunk (60 us under load, 15-20 alone), and placed in the
-// list "about where the chip gets to them".  The per-task trace showed the result: where the chain binds -- from step 13 on at
-// n = 10^4 -- a step took 167-241 us against the engine's 81.  Here they are drawn, off a counter of their own and in chain
-// order, by `nhelp` workgroups of the ENGINE's launch: 512 threads (a tile is split over 8 waves), a CU of their own each (the
-// launch's LDS request keeps everything else off it), 32-column chunks with the next chunk in flight during the products, all
-// on the engine's XCD when the dispatcher deals round robin.  Same task definitions, same words, same fixed summation order as
-// dag_kernel's (the tile tasks are bit-for-bit the same sums: K-order within a task is ascending in both).
-// Every load of handed-off data is an L2-bypassing load and every store write-through: the helpers' launch began before the
-// persistent launch wrote anything, and they read what workgroups on other XCDs produce.
-__device__ __forceinline__ void chain_helper_loop(const DagArgs *ap)
-{
-    extern __shared__ double smem[];
-    constexpr int TM = 64, KC = 32, LDT = TM + 16, NT = 512, TPC = NT / KC, RPT = TM / TPC;
-    static_assert(RPT == 4, "four rows per thread, side and chunk");
-    double *sI = smem, *sJ = smem + 2 * KC * LDT;              // [2][KC * LDT] each: 40 KB + 40 KB
-    unsigned *share = (unsigned *)(smem + 4 * KC * LDT);
-    const DagArgs a = *ap;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const DagStep *__restrict__ steps = a.steps;
-    const unsigned ldab = 8u * (unsigned)a.lda;
-    unsigned *alive = const_cast<unsigned *>(a.alive);
-    if (tid == 0) {
-        __hip_atomic_fetch_add(alive + 16 + ((hw_where() >> 28) & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(alive + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    unsigned *cqueue = a.queue + 32;
-    // (diagnostics: alive[24 + helper] = last chain task drawn << 4 | how far it got -- 1 drawn, 2 inputs complete, 3 product done,
-    // 4 previous version there, 5 stored and signalled, 15 left; printed by the host when a wait ran out, COCONS_DEBUG_ABORT)
-    unsigned *dbg = alive + 24 + ((blockIdx.x >> 3) & 31u);
-    // The first panel is formed by classic kernels on the MAIN stream, behind the gate that waits for this workgroup to be
-    // resident: nothing of the matrix may be touched before the word that a one-lane kernel behind those kernels raises
-    // (alive[3]; paced by the host's enqueueing like the engine's input words)
-    if (tid == 0) share[0] = wait_ge<false>(alive + 3, 1u, a.abort_word, 0xf00u, HOST_PACED_TICKS) ? 1u : 0u;
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane((int)share[0]) == 0) return;
-    __syncthreads();
-    for (unsigned round = 0; round <= a.nctasks; ++round) {       // (a workgroup draws at most every task once: no open-ended loop)
-        if (tid == 0) {
-            unsigned Ln = __hip_atomic_fetch_add(cqueue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) Ln = 0xffffffffu;
-            share[1] = Ln;
-            __hip_atomic_store(dbg, Ln >= a.nctasks ? 15u : ((Ln << 4) | 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.trace && Ln < a.nctasks) a.trace[4 * (size_t)Ln] = __builtin_amdgcn_s_memrealtime();
-        }
-        __syncthreads();
-        const unsigned L = (unsigned)__builtin_amdgcn_readfirstlane((int)share[1]);
-        __syncthreads();
-        if (L >= a.nctasks) return;
-        int lo = 0, hi = a.nsteps - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (steps[mid].cbase <= L) lo = mid; else hi = mid - 1;
-        }
-        const int s = lo;
-        const DagStep st = steps[s];
-        const int q = (int)(L - st.cbase);
-        const int t = st.tj0 >> 1;
-        const int nd = st.nc * (st.nc + 1) / 2, nB = 2 * st.cs, nBC = st.two ? nB : 0;
-        const size_t c_t = (size_t)t * TILE, c_t1 = c_t + TILE;
-        const double *gIb, *gJb;
-        unsigned ldib = ldab, ldjb = ldab, ldob = ldab;
-        int K, store_only = 0, strip_task = 0, sigT = -1;
-        double *Cb;
-        const double *pa = nullptr;
-        unsigned *w0 = nullptr, *w1 = nullptr, *w2 = nullptr, *we = nullptr, *we2 = nullptr, *dn;
-        unsigned n0 = 0, n1 = 0, n2 = 0, ne = 0, dval = 0;
-        if (q < nd) {
-            // an update tile inside the next diagonal block (step s; the late half of it when the step is split)
-            const int ta = c_tri_ib[q], tb = q - ta * (ta + 1) / 2;
-            const int ti = st.tj0 + ta, tj = st.tj0 + tb;
-            const double *Ps = s == 0 ? a.A : a.P;
-            gIb = Ps + (size_t)ti * TM + (size_t)st.k0 * a.lda;
-            gJb = Ps + (size_t)tj * TM + (size_t)st.k0 * a.lda;
-            K = st.K;
-            Cb = a.A + (size_t)ti * TM + (size_t)tj * TM * a.lda;
-            if (s > 0) {
-                w1 = a.pdone + (size_t)s * a.pstride + ta; n1 = (unsigned)st.need;
-                w2 = a.pdone + (size_t)s * a.pstride + tb; n2 = (unsigned)st.need;
-            }
-            we = a.tdone + (ti * (ti + 1) / 2 + tj); ne = (unsigned)s;
-            dn = we; dval = (unsigned)s + 1u;
-            sigT = t + (ta >> 1);
-            if (st.split) {
-                gIb += (size_t)TILE * a.lda; gJb += (size_t)TILE * a.lda; K = TILE;
-                pa = a.partbuf + ((size_t)(s & 1) * 16 + q) * (TM * TM);
-                we2 = a.dcount + (size_t)s * 16 + q;
-            }
-        } else if (q >= nd + nB && q < nd + nB + st.nd_next) {
-            // early half of a diagonal-block tile of the NEXT step: first 128 columns of panel s + 1 (X0), into the side buffer
-            const int dd = q - nd - nB;
-            const int ta = c_tri_ib[dd], tb = dd - ta * (ta + 1) / 2;
-            const int tj0n = st.tj0 + 4;
-            const size_t k0n = (size_t)(s + 1) * 2 * TILE;
-            gIb = a.P + (size_t)(tj0n + ta) * TM + k0n * a.lda;
-            gJb = a.P + (size_t)(tj0n + tb) * TM + k0n * a.lda;
-            K = TILE;
-            Cb = a.partbuf + ((size_t)((s + 1) & 1) * 16 + dd) * (TM * TM); store_only = 1; ldob = 8u * TM;
-            w0 = a.pdone + (size_t)(s + 1) * a.pstride + ta; n0 = 2u;
-            w1 = a.pdone + (size_t)(s + 1) * a.pstride + tb; n1 = 2u;
-            dn = a.dcount + (size_t)(s + 1) * 16 + dd;
-        } else {
-            // a panel task of one of the first cs strips below the next diagonal block
-            int stage, tu;
-            if (q < nd + nB) { stage = 0; tu = q - nd; }
-            else if (q < nd + nB + st.nd_next + nBC) { stage = 1; tu = q - nd - nB - st.nd_next; }
-            else { stage = 2; tu = q - nd - nB - st.nd_next - nBC; }
-            const int strip = tu >> 1, h = tu & 1;
-            const int row64 = st.tj0 + (st.two ? 4 : 2) + strip;
-            strip_task = 1;
-            dn = a.pdone + (size_t)(s + 1) * a.pstride + strip;
-            if (stage == 0) {            // T1: X0(:, half h of tile t) = B0 W(t)^T
-                gIb = a.A + (size_t)row64 * TM + c_t * a.lda;
-                gJb = a.Wt + (size_t)t * TILE * TILE + TM * h; ldjb = 8u * TILE;
-                K = TM * (h + 1);
-                Cb = a.P + (size_t)row64 * TM + (c_t + TM * h) * a.lda; store_only = 1;
-                w0 = a.out + t; n0 = 1u;
-                w1 = a.tdone + (row64 * (row64 + 1) / 2 + 2 * t); n1 = (unsigned)s + 1u;
-                w2 = w1 + 1; n2 = n1;
-            } else if (stage == 1) {     // T2: B1(:, half h of tile t + 1) -= X0 X(t+1,t)^T
-                gIb = a.P + (size_t)row64 * TM + c_t * a.lda;
-                gJb = a.P + (c_t1 + TM * h) + c_t * a.lda;
-                K = TILE;
-                Cb = a.A + (size_t)row64 * TM + (c_t1 + TM * h) * a.lda;
-                w0 = dn; n0 = 2u;
-                w1 = a.xr + t; n1 = 1u;
-                we = a.tdone + (row64 * (row64 + 1) / 2 + 2 * (t + 1) + h); ne = (unsigned)s + 1u;
-            } else {                     // T3: X1(:, half h of tile t + 1) = B1 W(t+1)^T
-                gIb = a.A + (size_t)row64 * TM + c_t1 * a.lda;
-                gJb = a.Wt + (size_t)(t + 1) * TILE * TILE + TM * h; ldjb = 8u * TILE;
-                K = TM * (h + 1);
-                Cb = a.P + (size_t)row64 * TM + (c_t1 + TM * h) * a.lda; store_only = 1;
-                w0 = dn; n0 = 4u;
-                w1 = a.out + t + 1; n1 = 1u;
-            }
-        }
-        // ---- inputs of the product complete?
-        if (tid == 0) {
-            const unsigned code = 0xf00u + (unsigned)(s & 0xff);
-            bool o = true;
-            if (w0) o = wait_ge<false>(w0, n0, a.abort_word, code);
-            if (o && w1) o = wait_ge<false>(w1, n1, a.abort_word, code);
-            if (o && w2) o = wait_ge<false>(w2, n2, a.abort_word, code);
-            share[0] = o ? 1u : 0u;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const unsigned ok = (unsigned)__builtin_amdgcn_readfirstlane((int)share[0]);
-        __syncthreads();
-        if (!ok) return;
-        if (tid == 0) {
-            __hip_atomic_store(dbg, (L << 4) | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.trace) a.trace[4 * (size_t)L + 1] = __builtin_amdgcn_s_memrealtime();
-        }
-        // ---- product: 8 waves as a 2 x 4 grid, each a 32 x 16 part of the tile; chunks of 32 panel columns, register-staged
-        const int wi = wave & 1, wj = wave >> 1;
-        const int kc = tid / TPC, rg = (tid % TPC) * RPT;
-        const int ro = (lane >> 4) * LDT + (lane & 15);
-        const char *pI = (const char *)gIb + (8u * (unsigned)rg + (unsigned)kc * ldib);
-        const char *pJ = (const char *)gJb + (8u * (unsigned)rg + (unsigned)kc * ldjb);
-        const unsigned cIb = (unsigned)KC * ldib, cJb = (unsigned)KC * ldjb;
-        const int nch = (K + KC - 1) / KC;
-        double stI[RPT], stJ[RPT];
-        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        auto fetch = [&](int ch) {
-            const bool in = ch * KC + kc < K;                    // (K is a multiple of 16, not always of 32: zeros behind it)
-#pragma unroll
-            for (int v = 0; v < RPT; ++v) {
-                stI[v] = in ? load_wt((const double *)(pI + (unsigned)ch * cIb) + v) : 0.0;
-                stJ[v] = in ? load_wt((const double *)(pJ + (unsigned)ch * cJb) + v) : 0.0;
-            }
-        };
-        auto stage_to = [&](int buf) {
-#pragma unroll
-            for (int v = 0; v < RPT; ++v) {
-                sI[buf * KC * LDT + kc * LDT + rg + v] = stI[v];
-                sJ[buf * KC * LDT + kc * LDT + rg + v] = stJ[v];
-            }
-        };
-        fetch(0);
-        stage_to(0);
-        __syncthreads();
-        for (int ch = 0; ch < nch; ++ch) {
-            const int cur = ch & 1;
-            if (ch + 1 < nch) fetch(ch + 1);
-            const double *bI = sI + cur * KC * LDT + ro + (TM / 2) * wi;
-            const double *bJ = sJ + cur * KC * LDT + ro + (TM / 4) * wj;
-#pragma unroll
-            for (int k4 = 0; k4 < KC / 4; ++k4) {
-                const double p0 = bI[k4 * 4 * LDT], p1 = bI[k4 * 4 * LDT + 16];
-                const double q0 = bJ[k4 * 4 * LDT];
-                acc0 = MFMA64(q0, p0, acc0);
-                acc1 = MFMA64(q0, p1, acc1);
-            }
-            if (ch + 1 < nch) stage_to(cur ^ 1);
-            __syncthreads();
-        }
-        // ---- the C tile's previous version (and the early half of a split tile) must be there
-        if (tid == 0) {
-            __hip_atomic_store(dbg, (L << 4) | 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.trace) a.trace[4 * (size_t)L + 2] = __builtin_amdgcn_s_memrealtime();
-            const unsigned code = 0xf00u + (unsigned)(s & 0xff);
-            bool o = true;
-            if (we) o = wait_ge<false>(we, ne, a.abort_word, code);
-            if (o && we2) o = wait_ge<false>(we2, 1u, a.abort_word, code);
-            share[0] = o ? 1u : 0u;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const unsigned okE = (unsigned)__builtin_amdgcn_readfirstlane((int)share[0]);
-        if (!okE) return;
-        // ---- epilogue: this wave's 32 x 16 part (two accumulator blocks)
-        {
-            double *Cw = (double *)((char *)(Cb + (TM / 2) * wi) + (size_t)((TM / 4) * wj) * ldob);
-            const unsigned cve = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * ldob;
-            d4 cv0, cv1;
-            if (store_only) { cv0 = acc0; cv1 = acc1; }
-            else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    cv0[r] = load_wt((const double *)((const char *)Cw + (cve + (unsigned)(4 * r) * ldob)));
-                    cv1[r] = load_wt((const double *)((const char *)(Cw + 16) + (cve + (unsigned)(4 * r) * ldob)));
-                }
-                if (pa) {
-                    const double *Pw = pa + (TM / 2) * wi + (TM / 4) * wj * TM;
-                    const unsigned cvp = 8u * (unsigned)(lane & 15) + (unsigned)(lane >> 4) * (8u * TM);
-                    d4 pv0, pv1;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        pv0[r] = load_wt((const double *)((const char *)Pw + (cvp + (unsigned)(4 * r) * (8u * TM))));
-                        pv1[r] = load_wt((const double *)((const char *)(Pw + 16) + (cvp + (unsigned)(4 * r) * (8u * TM))));
-                    }
-                    cv0 -= pv0 + acc0;                  // (early half + late half, then off C: dag_kernel's order)
-                    cv1 -= pv1 + acc1;
-                } else { cv0 -= acc0; cv1 -= acc1; }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                store_wt((double *)((char *)Cw + (cve + (unsigned)(4 * r) * ldob)), cv0[r]);
-                store_wt((double *)((char *)(Cw + 16) + (cve + (unsigned)(4 * r) * ldob)), cv1[r]);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            if (sigT >= 0) signal_add(a.sig + sigT);
-            if (dval) __hip_atomic_fetch_max(dn, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else if (__hip_atomic_fetch_add(dn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (st.two ? 6u : 2u) && strip_task)
-                __hip_atomic_fetch_add(a.pall + s + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dbg, (L << 4) | 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.trace) a.trace[4 * (size_t)L + 3] = __builtin_amdgcn_s_memrealtime();
-        }
     }
 }
 
@@ -2783,51 +2489,23 @@ static size_t engine_lds_bytes()
 // t0 >= nt: the kernel is launched all the same, raises its alive word and leaves at once -- the WARM-UP launch of a
 // handle (api.hip): whatever the first dispatch of this kernel on this stream costs the runtime (queue set-up, code
 // object, LDS configuration) is paid there and not inside the bounded gate of the first engine-schedule operation.
-// the task words of a persistent launch as the chain helpers need them, written into device memory by a one-lane kernel on the
-// engine's stream in front of the engine's launch (a by-value kernel argument whose address is taken would live in scratch)
-__global__ void __launch_bounds__(64)
-set_chain_args_kernel(DagArgs a, DagArgs *dst)
-{
-    if (threadIdx.x == 0) *dst = a;
-}
-
-size_t dag_chain_args_bytes() { return sizeof(DagArgs); }
-
-void launch_chain_args(void *dev, double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps,
-                       unsigned nctasks, unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall,
-                       double *partbuf, unsigned *dcount, unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word,
-                       const unsigned *alive, hipStream_t s, unsigned long long *trace)
-{
-    DagArgs a;
-    a.A = A; a.lda = lda; a.P = P; a.Wt = Wt;
-    a.steps = (const DagStep *)dsteps; a.nsteps = nsteps; a.ntasks = 0; a.nctasks = nctasks;
-    a.queue = queue; a.tdone = tdone; a.pdone = pdone; a.pstride = pstride; a.pall = pall;
-    a.partbuf = partbuf; a.dcount = dcount;
-    a.sig = sig; a.out = out; a.xr = xr; a.abort_word = abort_word; a.trace = trace; a.hw = nullptr;
-    a.alive = alive; a.xcc_quota = 0;
-    hipLaunchKernelGGL(set_chain_args_kernel, dim3(1), dim3(64), 0, s, a, (DagArgs *)dev);
-}
-
 void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, int *info,
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
-                         double *wbuf, double *pbuf, int dag_until, unsigned long long *trace, const void *chain, int nhelp,
-                         double *mbox)
+                         double *wbuf, double *pbuf, int dag_until, unsigned long long *trace, double *mbox, int in_wait_ms)
 {
     EngineArgs e;
     e.A = A; e.lda = lda; e.t0 = t0; e.nt = nt; e.dinv = dinv; e.info = info;
     e.in = in; e.out = out; e.xr = xr; e.abort_word = abort_word; e.alive = alive;
     e.wbuf = wbuf; e.pbuf = pbuf; e.dag_until = dag_until; e.trace = trace;
-    e.chain = (chain && nhelp > 0) ? (const DagArgs *)chain : nullptr;
-    e.nhelp = e.chain ? nhelp : 0;
-    // (mbox: pair mode -- the partner is the workgroup behind the helpers' on workgroup 0's XCD: 8 (nhelp + 1))
+    e.in_ticks = in_wait_ms > 0 ? 100000ull * (unsigned long long)in_wait_ms : HOST_PACED_TICKS;
+    // (mbox: pair mode -- the partner is workgroup 8: with the round robin over the eight XCDs, the next one on workgroup 0's XCD)
     e.mbox = mbox;
-    e.partner = mbox ? 8 * (e.nhelp + 1) : 0;
-    const int grid = e.partner ? e.partner + 1 : (e.nhelp > 0 ? 8 * e.nhelp + 1 : 1);
+    e.partner = mbox ? 8 : 0;
+    const int grid = e.partner ? e.partner + 1 : 1;
     const size_t shm = engine_lds_bytes();
     if (wbuf && pbuf) {
         static std::atomic<unsigned long long> attr_done{0};
         set_dynamic_lds_once((const void *)potrf_engine_kernel<true>, shm, attr_done);
-        // (with helpers: workgroups 0, 8, 16, ... 8 nhelp do something -- the ones dealt to workgroup 0's XCD -- the rest leave)
         hipLaunchKernelGGL(potrf_engine_kernel<true>, dim3(grid), dim3(512), shm, s, e);
     } else {
         static std::atomic<unsigned long long> attr_done{0};
@@ -2980,10 +2658,9 @@ void launch_pack_rows(const double *A, size_t lda, int col0, int ncols, double *
 // (tiles 0, 1) already formed in place; kskip leading columns of it are unit vectors (front padding) and are skipped.
 // lead: far tiles of a step in front of its panel tasks.  Returns the number of tasks.
 unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, int split, std::vector<DagStepHost> &out,
-                         int lead2, int lead3, int chain, unsigned *nctasks_out)
+                         int lead2, int lead3)
 {
     out.clear();
-    if (chain) split = 1;              // (the chain layout always forms the diagonal-block tiles in two halves)
     unsigned base = 0;
     int prev_two = 1;
     for (int k = 0; k + 2 < nt; k += 2) {
@@ -3007,7 +2684,6 @@ unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int mi
         st.K = 2 * TILE - (k == 0 ? kskip : 0);
         st.need = prev_two ? 6 : 2;
         st.nd_next = 0; st.split = 0;
-        st.nc = 0; st.cs = 0; st.cbase = 0; st.cnt = 0;
         st.tpos = 0; st.p2 = 0; st.p3 = 0;
         st.base = 0;
         prev_two = st.two;
@@ -3018,35 +2694,19 @@ unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int mi
         DagStepHost &l = out.back();
         l.nT = 0; l.nstrip = 0;
     }
-    // the diagonal-block tiles of step s + 1 in two halves: the early one rides in step s's list behind its T1 tasks (classic
-    // layout) or in the chain helpers' list (chain layout).  (steps from 1 on: K = 256 there; step s must form the panel of
-    // s + 1, i.e. have panel tasks)
+    // the diagonal-block tiles of step s + 1 in two halves: the early one rides in step s's list behind its T1 tasks.  (steps
+    // from 1 on: K = 256 there; step s must form the panel of s + 1, i.e. have panel tasks)
     if (split)
         for (size_t s = 0; s + 1 < out.size(); ++s)
             if (out[s].nstrip > 0 && out[s].two) {
                 out[s].nd_next = out[s + 1].two ? 10 : 3;
                 out[s + 1].split = 1;
             }
-    unsigned cbase = 0;
     for (auto &st : out) {
-        const long long tiles = (long long)st.W * st.H - (long long)st.W * (st.W - 1) / 2;
-        long long ntile = tiles, nA, perBC;
-        if (chain) {
-            st.nc = st.two ? 4 : 2;
-            st.cs = std::min(st.nstrip, 4);
-            const int nd = st.nc * (st.nc + 1) / 2;
-            ntile = tiles - nd;
-            st.near = (unsigned)(st.nc * (st.H - st.nc));
-            st.nT = (unsigned)((st.nstrip - st.cs) * (st.two ? 6 : 2));
-            nA = 2LL * (st.nstrip - st.cs);
-            st.cbase = cbase;
-            st.cnt = (unsigned)(nd + 2 * st.cs + st.nd_next + (st.two ? 4 * st.cs : 0));
-            cbase += st.cnt;
-        } else {
-            st.nT += (unsigned)st.nd_next;
-            nA = 2LL * st.nstrip + st.nd_next;
-        }
-        perBC = st.two ? 2LL * (st.nstrip - st.cs) : 0;
+        const long long ntile = (long long)st.W * st.H - (long long)st.W * (st.W - 1) / 2;
+        st.nT += (unsigned)st.nd_next;
+        const long long nA = 2LL * st.nstrip + st.nd_next;
+        const long long perBC = st.two ? 2LL * st.nstrip : 0;
         const long long far = ntile - st.near;
         st.tpos = st.near + (unsigned)std::min<long long>(far, lead);
         st.base = base;
@@ -3060,19 +2720,17 @@ unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int mi
         st.p2 = (unsigned)(st.tpos + nA + d2);
         st.p3 = (unsigned)(st.p2 + perBC + d3);
     }
-    if (nctasks_out) *nctasks_out = cbase;
     return base;
 }
 
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
                 unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, double *partbuf, unsigned *dcount,
                 unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace,
-                const unsigned *alive, int xcc_quota, unsigned *hw, unsigned nctasks)
+                const unsigned *alive, int xcc_quota, unsigned *hw)
 {
     static_assert(sizeof(DagStepHost) == sizeof(DagStep), "host and device step records");
     if (nsteps <= 0 || ntasks == 0) return;
     DagArgs a;
-    a.nctasks = nctasks;
     a.A = A; a.lda = lda; a.P = P; a.Wt = Wt;
     a.steps = (const DagStep *)dsteps; a.nsteps = nsteps; a.ntasks = ntasks;
     a.queue = queue; a.tdone = tdone; a.pdone = pdone; a.pstride = pstride; a.pall = pall;

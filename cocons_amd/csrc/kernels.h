@@ -133,13 +133,13 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
                          unsigned *in, unsigned *out, unsigned *xr, unsigned *abort_word, unsigned *alive, hipStream_t s,
                          double *wbuf = nullptr, double *pbuf = nullptr, int dag_until = 0,
                          unsigned long long *trace = nullptr,
-                         const void *chain = nullptr, int nhelp = 0,    // chain helpers of the DAG schedule (chol.hip: chain_helper_loop):
-                                                                         // device copy of the task words (launch_chain_args), workgroups
-                         double *mbox = nullptr);                        // pair mode (engine_partner_loop): the tiles' mailboxes
+                         double *mbox = nullptr,                         // pair mode (engine_partner_loop): the tiles' mailboxes
                                                                          // (ENGINE_MBOX_DOUBLES each, index = tile), every byte 0xff at
                                                                          // launch; a second workgroup takes the second tile of every block
+                         int in_wait_ms = 0);                            // > 0 (tests): bound of the engine's waits for its input words
+                                                                         // in milliseconds instead of the host-paced 3 s
 constexpr size_t ENGINE_MBOX_DOUBLES = 44 * 256;
-// nhelp > 0: also waits until that many chain helpers of the engine's launch are resident
+// nhelp > 0: also waits until that many further workgroups of the engine's launch (the pair partner) are resident
 // raise_in != NULL: the gate also raises in[0] = 3, in[1] = 7 (the engine factors the first diagonal block too: launch_potrf_engine t0 = 0)
 void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bool last_tile = false, bool patient = false, int nhelp = 0,
                         unsigned *raise_in = nullptr);
@@ -212,30 +212,20 @@ struct DagStepHost {
     unsigned base, near, tpos, nT;
     int H, W, tj0, k0, K, nstrip, two, need, nd_next, split;
     unsigned p2, p3;
-    int nc, cs;               // chain layout (see DagStep)
-    unsigned cbase, cnt;
 };
 // only the leading steps with at least min_tiles update tiles are taken (the head of the factorisation); the last of them has
 // no panel tasks: the panel behind it is left to the caller's classic kernels
 // split != 0: the diagonal-block tiles of the steps from 1 on are computed in two halves (nd_next / split, see DagStep)
 // lead: far tiles of a step in front of its T1 tasks (and the early halves); lead2 / lead3: far tiles between them and the T2
 // tasks, between those and the T3 tasks
-// chain != 0: the chain layout -- the tasks on the chain between two diagonal blocks are left out of the list and counted in
-// *nctasks_out (drawn by the chain helpers of the engine's launch)
 unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, int split, std::vector<DagStepHost> &out,
-                         int lead2 = 0, int lead3 = 0, int chain = 0, unsigned *nctasks_out = nullptr);
-// device copy of a launch's task words for the chain helpers: dag_chain_args_bytes() bytes at `dev`, written on stream s
-size_t dag_chain_args_bytes();
-void launch_chain_args(void *dev, double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps,
-                       unsigned nctasks, unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall,
-                       double *partbuf, unsigned *dcount, unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word,
-                       const unsigned *alive, hipStream_t s, unsigned long long *trace = nullptr);   // trace: 4 stamps per chain task
+                         int lead2 = 0, int lead3 = 0);
 // dsteps: DEVICE copy of the table.  queue, tdone (2 mt (2 mt + 1) / 2 words), pdone ((nsteps + 1) * pstride words,
 // pstride >= 2 mt), pall (nsteps + 1 words): zero at launch.  sig / out / xr: the engine's words (launch_potrf_engine with wbuf = Wt, pbuf = P).
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
                 unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, double *partbuf, unsigned *dcount,
                 unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace = nullptr,
-                const unsigned *alive = nullptr, int xcc_quota = 0, unsigned *hw = nullptr, unsigned nctasks = 0);
+                const unsigned *alive = nullptr, int xcc_quota = 0, unsigned *hw = nullptr);
                 // alive: the engine's alive word (1 + its XCD); xcc_quota: workgroups of the launch that take part on that XCD
                 // partbuf: 2 x 16 x 64 x 64 doubles; dcount: 16 words per step (+ 1 step), zero at launch
 

@@ -18,6 +18,13 @@
  *     < 0 = bad argument or HIP error, text in cocons_last_error().
  *   - nothing throws, aborts or exits; no HIP call happens at load time
  *     (fork-safe: the device context is created lazily per process).
+ *   - threads: the reference's callers are single-threaded R interpreters, one per worker process
+ *     (R/optim.R:117-121, 234-235), and that is all the drop-in needs.  Beyond it: ONE handle serves one call
+ *     at a time (a second thread entering with the same handle waits until the first call has returned -- every
+ *     entry point holds the handle's operation lock); DIFFERENT handles may be created, used and destroyed from
+ *     different threads concurrently, the stateless entry points likewise; cocons_last_error() is per thread.
+ *     A handle must not be destroyed while another thread is inside a call on it, and a stream installed with
+ *     cocons_fit_set_stream is the caller's: the library never launches its own probe kernels on it.
  */
 #ifndef COCONS_HIP_H
 #define COCONS_HIP_H
@@ -216,8 +223,8 @@ int cocons_fit_engine_state(cocons_fit *fit, int *out3);
 /* ---- natively sharded evaluation across the GPUs of one node ----------------------
  * Sigma is ROW-BLOCK partitioned (block b = rows 256 b .. 256 b + 255; blocks dealt in groups, see
  * cocons_shard_block_owner below): a rank assembles, solves and updates ITS rows of every column.  Per 256-column
- * block the owner of the diagonal block factors it and the library broadcasts it (0.56 MB, RCCL over xGMI, on a
- * stream -- and communicator -- of its own, issued in front of the bulk exchange), every rank solves its rows of
+ * block the owner of the diagonal block factors it and the library broadcasts it (0.56 MB, RCCL over xGMI, issued in
+ * front of the bulk exchange; COCONS_SHARD_COMM2=1: on a stream -- and communicator -- of its own), every rank solves its rows of
  * the panel, the owner of the NEXT diagonal block updates and factors it from its own rows at once, the solved rows
  * are all-gathered packed by owner (second communication stream), every rank updates its rows of the trailing
  * matrix; the 1 + r^2 partial sums (+ the failing minor) are all-reduced at the end.  No

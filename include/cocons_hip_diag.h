@@ -22,22 +22,20 @@ int cocons_debug_matern(int n, const double *nu, const double *u, double *out);
 
 /* Schedule switches of the factorisation, settable at run time (the library reads the COCONS_* environment variables
  * of the same meaning once per process; DESIGN.md section 6 lists them): "engine", "engine_block0", "engine_pair", "panel_fused", "panel_follow",
- * "panel_diag", "panel_split", "potrf_follow", "upd_dynamic", "upd_waves", "w8_max_tiles", "dag", "dag_min_tiles", "dag_split", "dag_chain",
- * "dag_helpers", "dag_lead" / "dag_lead2" / "dag_lead3", "dag_xcc_quota", "dag_trace" (and, for the tests, "gate_sabotage").
+ * "panel_diag", "panel_split", "potrf_follow", "upd_dynamic", "upd_waves", "w8_max_tiles", "dag", "dag_min_tiles", "dag_split",
+ * "dag_lead" / "dag_lead2" / "dag_lead3", "dag_xcc_quota", "dag_trace" (and, for the tests, "gate_sabotage", "host_delay_us",
+ * "host_delay_tile", "engine_in_wait_ms").
  * For timing variants in alternation inside one process (tools/ab_modes.py); results do not depend on them beyond the
  * rounding of a different summation order.                                                                        */
 int cocons_debug_tune(const char *name, int value);
 
 /* Per-task time stamps of the last dependency-driven factorisation (cocons_debug_tune("dag", 1) and ("dag_trace", 1)) of a
- * fit handle: steps_out = nsteps x 20 ints (base, near, tpos, nT, H, W, tj0, k0, K, nstrip, two, need, nd_next, split, p2, p3, nc, cs, cbase, cnt), stamps_out =
+ * fit handle: steps_out = nsteps x 16 ints (base, near, tpos, nT, H, W, tj0, k0, K, nstrip, two, need, nd_next, split, p2, p3), stamps_out =
  * ntasks x 4 ticks of the 100 MHz clock (drawn, inputs complete, product done, stored).  Returns ntasks; null outputs: sizes only. */
 struct cocons_fit;
 long long cocons_debug_dag_trace(struct cocons_fit *fit, int *nsteps_out, int *steps_out, unsigned long long *stamps_out,
                                  unsigned long long *engine_out);   /* engine_out (may be null): 8 stamps per pair of tiles, room for 8 (nt + 2) */
 
-
-/* ... and of the chain helpers' tasks (chain layout): nctasks x 4 ticks (drawn, inputs complete, product done, stored); returns nctasks */
-long long cocons_debug_chain_trace(struct cocons_fit *fit, unsigned long long *stamps_out);
 
 /* host time spent ENQUEUEING evaluations on this handle and its batch slots: out2[0] = mean microseconds per evaluation, out2[1] = evaluations */
 int cocons_debug_host_enqueue(struct cocons_fit *fit, double *out2);

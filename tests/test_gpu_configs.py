@@ -363,6 +363,66 @@ def test_native_sharded_rccl_one_rank_and_multi_handle():
     mf.close()
 
 
+def _rccl_worker(rank, world, port, g, out_dir, comm2):
+    sys.path.insert(0, ROOT)
+    os.environ["COCONS_SHARD_COMM2"] = str(comm2)             # read once, when the library is first used
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch                      # noqa: F401
+    import torch.distributed as dist
+    from cocons_amd import workloads as wl
+    from cocons_amd.shard import ShardedFit
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # (moves the 128-byte unique id, nothing else)
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.1, -0.2, 0.05])
+    z = np.column_stack([wl.synthetic_z(g * g), wl.synthetic_z(g * g, seed=5)])
+    fit = ShardedFit(locs, X, z, wl.SMOOTH_LIMITS, device=rank)       # one rank per GPU
+    fit.init_rccl(dist, rank, world)
+    info = fit.comm_info()
+    assert info["count"] == world and info["rank"] == rank and info["device"] == rank, info
+    for _ in range(3):
+        val, parts = fit.neg2loglik_core(th)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([[val], parts]))
+    dist.barrier()
+    fit.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm2", [0, 1])
+def test_native_sharded_rccl_two_gpus(tmp_path, comm2):
+    """The sharded evaluation over RCCL with MORE THAN ONE RANK -- one process per GPU, ncclCommInitRank from a shared unique
+    id, broadcast / all-gather / all-reduce over xGMI -- which a one-GPU box cannot run: skipped there, and the first thing
+    to run on a node with two devices (the advisor's round-5 finding: the collective order of round 5 and the split
+    communicator, COCONS_SHARD_COMM2=1, have never met a second rank).  Both forms must reproduce the single-GPU value on
+    every rank; then the one-process handle over the device list [0, 1] (cocons_multi_neg2loglik_dense, fit_comm_init's twin)."""
+    import torch.multiprocessing as mp
+    import cocons_amd as ca
+    from cocons_amd import _lib, workloads as wl
+    if _lib.load().cocons_device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    g, world = 50, 2
+    mp.spawn(_rccl_worker, args=(world, _free_port(), g, str(tmp_path), comm2), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(res[0], res[1])
+    locs = wl.grid_locs(g)
+    X = wl.design_from_locs(locs)["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.1, -0.2, 0.05])
+    z = np.column_stack([wl.synthetic_z(g * g), wl.synthetic_z(g * g, seed=5)])
+    val, parts = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS).neg2loglik_core(th)
+    assert abs(res[0][0] - val) < 1e-10 * abs(val)
+    assert np.allclose(res[0][1:], parts, rtol=1e-10, atol=0)
+    if comm2 == 0:
+        from cocons_amd.shard import MultiFit
+        mf = MultiFit(locs, X, z, wl.SMOOTH_LIMITS, devices=[0, 1])
+        got, mparts = mf.neg2loglik_core(th)
+        assert abs(got - val) < 1e-10 * abs(val) and np.allclose(mparts, parts, rtol=1e-10, atol=0)
+        mf.close()
+
+
 def _predict_shard_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -187,49 +187,3 @@ def test_dag_xcd_quota_changes_nothing_but_who_works():
         _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
         _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "2000")))
         fit.close()
-
-
-@pytest.mark.parametrize("gx,gy,min_tiles", [(33, 31, 0), (45, 47, 0), (64, 64, 0), (72, 64, 0), (100, 100, 800)])
-def test_dag_chain_layout_vs_classic(gx, gy, min_tiles):
-    """The chain layout of the dependency-driven schedule (COCONS_DAG_CHAIN=1, round 5: the tasks on the chain between two
-    diagonal blocks drawn by chain helpers -- workgroups of the engine's launch -- instead of sitting in the persistent launch's
-    list; the tile inverses formed alongside the tile factorisation): the same tile tasks in the same summation order, so the
-    value is BIT-IDENTICAL to the one-list layout's, equal to the classic schedule's to 1e-11, reproducible run to run, and no
-    hand-off ever timed out.  Sizes: slots / a last block of one tile / right-hand sides under the matrix / n = 10^4 with the
-    launch covering the steps of at least 800 tiles."""
-    import cocons_amd as ca
-    from cocons_amd import workloads as wl
-    locs, sc = _grid(gx, gy)
-    n = locs.shape[0]
-    X = sc["std.covs"]
-    th = wl.theta_full()
-    th["mean"] = np.array([0.1, -0.2, 0.05])
-    rng = np.random.default_rng(n)
-    z = rng.standard_normal((n, 2)) + (X @ np.array([0.2, 0.3, -0.1]))[:, None]
-    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
-    try:
-        _tune("dag", 1)
-        _tune("dag_min_tiles", min_tiles)
-        _tune("dag_chain", 0)
-        _tune("dag_split", 1)          # (the chain layout always splits the diagonal-block tiles: bit-identity is with that list)
-        v_list, p_list = fit.neg2loglik_core(th)
-        _tune("dag_chain", 1)
-        v_chain, p_chain = fit.neg2loglik_core(th)
-        v_chain2 = fit.neg2loglik_core(th)[0]
-        st = fit.engine_state()
-        assert st["retries"] == 0 and st["active"]
-        assert v_chain == v_list and np.array_equal(p_chain, p_list)       # same bits
-        assert v_chain2 == v_chain
-        th2 = {k: np.array(v, dtype=float) for k, v in th.items()}
-        th2["scale"][0] += 0.3
-        a = fit.neg2loglik_core(th2)[0]
-        assert fit.neg2loglik_core(th)[0] == v_chain and fit.neg2loglik_core(th2)[0] == a
-        _tune("dag", 0)
-        v_cl = fit.neg2loglik_core(th)[0]
-        assert abs(v_chain - v_cl) <= 1e-11 * abs(v_cl)
-        assert fit.engine_state()["retries"] == 0
-    finally:
-        _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
-        _tune("dag_chain", int(os.environ.get("COCONS_DAG_CHAIN", "0")))
-        _tune("dag_split", int(os.environ.get("COCONS_DAG_SPLIT", "1")))
-        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "2000")))

@@ -203,6 +203,108 @@ def test_engine_timeout_is_survived_counted_and_backed_off():
         fit.close()
 
 
+@pytest.mark.shared_gpu          # (exempt from the autouse "no time-out" check: the second half provokes one on purpose)
+def test_late_host_is_waited_for_and_a_short_bound_records_0x112(oracle):
+    """The time-out round 5's first GPU run recorded (`test_profile_and_reml_n4096_q3_vs_oracle: retries=1 last_abort=0x112`:
+    the engine gave up waiting for tile 18's input word) was put down to a host thread throttled in the middle of enqueueing
+    an evaluation -- the launches that raise in[18] came later than the 100 ms the engine then waited.  Here the cause is
+    produced on purpose, in the same configuration (Profile at n = 4096, q = 3, two realisations): the enqueueing thread sleeps
+    250 ms in front of the launches that raise in[18] (cocons_debug_tune "host_delay_us" / "host_delay_tile").
+    (a) Under the shipped bound of the host-paced waits (3 s) the evaluation finishes ON THE ENGINE SCHEDULE, no time-out, the
+    value equal to the oracle's.  (b) With the bound put back to 100 ms the engine gives up with exactly 0x112, the operation
+    is repeated on the plain schedule (counted), and the value is still right."""
+    import time
+    import cocons_amd as ca
+    from cocons_amd import _lib, workloads as wl
+    if ENGINE_OFF:
+        pytest.skip("COCONS_ENGINE=0")
+    L = _lib.load()
+    n = 4096
+    locs, sc = _grid(64)
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    rng = np.random.default_rng(4096)
+    z = rng.standard_normal((n, 2)) + 0.5 + (X @ np.array([0.0, 0.4, -0.3]))[:, None]
+    pp = wl.par_pos_full()
+    tv = wl.theta_vector_from_lists(th, pp)
+    lam = (0.1, 0.0, 0.3)
+    want = oracle.GetNeg2loglikelihoodProfile(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam)
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS, x_betas=X)
+    try:
+        v0 = ca.GetNeg2loglikelihoodProfile(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam, fit=fit)
+        assert fit.engine_state() == {"active": True, "retries": 0, "last_abort": 0}
+        assert abs(v0 - want) <= N2LL_RTOL * abs(want)
+        _lib.check(L.cocons_debug_tune(b"host_delay_tile", 18), "tune")
+        _lib.check(L.cocons_debug_tune(b"host_delay_us", 250000), "tune")
+        t0 = time.perf_counter()
+        v1 = ca.GetNeg2loglikelihoodProfile(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam, fit=fit)
+        dt = time.perf_counter() - t0
+        assert dt >= 0.25, dt                                   # the host really was late
+        st = fit.engine_state()
+        assert st == {"active": True, "retries": 0, "last_abort": 0}, st
+        assert v1 == v0                                         # the same schedule, the same bits
+        # (b) the bound of rounds 2-4
+        _lib.check(L.cocons_debug_tune(b"engine_in_wait_ms", 100), "tune")
+        v2 = ca.GetNeg2loglikelihoodProfile(tv, pp, locs, X, wl.SMOOTH_LIMITS, z, n, X, lam, fit=fit)
+        st = fit.engine_state()
+        assert st["retries"] == 1 and st["last_abort"] == 0x112 and not st["active"], st
+        assert abs(v2 - want) <= N2LL_RTOL * abs(want)
+    finally:
+        L.cocons_debug_tune(b"host_delay_us", 0)
+        L.cocons_debug_tune(b"host_delay_tile", -1)
+        L.cocons_debug_tune(b"engine_in_wait_ms", 0)
+        fit.close()
+
+
+@pytest.mark.shared_gpu          # (seven live handles = fourteen streams on four hardware queues: a hand-off may time out and be repeated)
+def test_handles_created_used_and_destroyed_from_three_threads(record_property):
+    """The threading contract of the boundary (include/cocons_hip.h): different handles may be created, used and destroyed from
+    different threads at the same time.  A new handle's stream self-test launches probe kernels on the streams of OTHER live
+    handles (api.hip engine_warm) -- until round 5 without holding anything, so that a handle could be used or destroyed under
+    the probe (the advisor's finding); now it takes the other handle's operation lock, and a busy handle is skipped.  Three
+    threads churn through handles of engine-schedule size while each also evaluates on its own: every value must equal the
+    single-threaded one and nothing may crash or hang.  (Hand-off time-outs are recorded, not forbidden: with this many live
+    handles streams share hardware queues, and an engine that shares one with another handle's main stream is ended by its bounded
+    waits and repeated on the plain schedule -- DESIGN.md section 4a.)"""
+    import threading
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, sc = _grid(32)                         # n = 1024: 8 tiles, engine schedule
+    X = sc["std.covs"]
+    z = wl.synthetic_z(locs.shape[0])
+    th = wl.theta_full()
+    ref_fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    ref = ref_fit.neg2loglik_core(th)[0]
+    errors, retries = [], []
+
+    def churn(seed):
+        try:
+            keep = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+            for it in range(8):
+                f = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)       # (its creation probes the other threads' handles)
+                for g in (f, keep):
+                    v = g.neg2loglik_core(th)[0]
+                    if abs(v - ref) > 1e-12 * abs(ref):
+                        errors.append((seed, it, v))
+                retries.append(f.engine_state()["retries"])
+                f.close()
+            retries.append(keep.engine_state()["retries"])
+            keep.close()
+        except Exception as e:                   # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    ts = [threading.Thread(target=churn, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts), "a thread hangs"
+    assert not errors, errors
+    record_property("engine_timeouts", sum(retries))
+    assert abs(ref_fit.neg2loglik_core(th)[0] - ref) <= 1e-12 * abs(ref)
+    ref_fit.close()
+
+
 def test_front_padding_n2115_all_entry_points_vs_oracle(oracle):
     """n = 45 x 47 = 2115 is not a multiple of 128: the handle keeps 61 placeholder observations IN FRONT of the caller's
     (unit columns, api.hip fit_create_impl) instead of identity padding behind them.  Every entry point that runs on that

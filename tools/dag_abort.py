@@ -55,7 +55,7 @@ def main():
     nt, nsteps, ntasks, nwords, fcap, ntr, code, qn, now = [int(v) for v in hdr[1:10]]
     off = 64
     rec = np.frombuffer(raw, np.uint32, 7, off); off += 28
-    steps = np.frombuffer(raw, np.int32, nsteps * 20, off).reshape(nsteps, 20); off += nsteps * 80
+    steps = np.frombuffer(raw, np.int32, nsteps * 16, off).reshape(nsteps, 16); off += nsteps * 64
     words = np.frombuffer(raw, np.uint32, nwords, off); off += 4 * nwords
     flags = np.frombuffer(raw, np.uint32, 4 * fcap + 64, off); off += 4 * (4 * fcap + 64)
     print("abort code 0x%x; nt %d, %d steps, %d tasks, counter %d" % (code, nt, nsteps, ntasks, qn))
@@ -151,7 +151,7 @@ def tile_history(path, ti, tj):
     hdr = np.frombuffer(raw, np.uint32, 16, 0)
     nt, nsteps, ntasks, nwords, fcap, ntr = [int(v) for v in hdr[1:7]]
     off = 64 + 28
-    steps = np.frombuffer(raw, np.int32, nsteps * 20, off).reshape(nsteps, 20); off += nsteps * 80
+    steps = np.frombuffer(raw, np.int32, nsteps * 16, off).reshape(nsteps, 16); off += nsteps * 64
     words = np.frombuffer(raw, np.uint32, nwords, off); off += 4 * nwords + 4 * (4 * fcap + 64)
     st = np.frombuffer(raw, np.uint64, ntasks * 4, off).reshape(ntasks, 4)
     t0 = st[:, 0][st[:, 0] > 0].min()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The persistent launch of the dependency-driven schedule (cocons::dag_kernel) replayed ALONE at n = 10^4
-(cocons_debug_dag_replay): the program the counter passes of tools/r5_pmc_dag.sh run under rocprofv3 --pmc, where the real
+(cocons_debug_dag_replay): the program the counter passes of `tools/gpu_run.sh pmc_dag` run under rocprofv3 --pmc, where the real
 launch cannot run (kernels are serialised there and it waits for the diagonal-block engine on another stream).
 
   python3 tools/dag_replay.py [--n 10000] [--reps 3] [--warm 1]

@@ -37,7 +37,7 @@ def main():
     ns = ctypes.c_int(0)
     nt = L.cocons_debug_dag_trace(fit._h, ctypes.byref(ns), None, None, None)
     assert nt > 0, _lib.last_error()
-    steps = np.zeros((ns.value, 20), dtype=np.int32)     # DagStepHost: 16 words + the chain layout's 4
+    steps = np.zeros((ns.value, 16), dtype=np.int32)     # DagStepHost: 16 words
     st = np.zeros((nt, 4), dtype=np.uint64)
     eng = np.zeros((8 * (2 * ns.value + 8),), dtype=np.uint64)
     ntile = (g * g + 127) // 128

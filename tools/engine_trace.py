@@ -2,7 +2,7 @@
 """The diagonal-block engine's eight stamps per 256-column block (100 MHz clock), under the dependency-driven schedule for every
 step (the stamps exist for DAG blocks only), one-workgroup engine against the pair:
 
-  python3 tools/engine_trace.py [--n 4096] [--pair 1] [--chain 0] [--every 1]
+  python3 tools/engine_trace.py [--n 4096] [--pair 1] [--every 1]
 
 per block: first tile -- in[t] seen .. factored .. out[t]; second tile -- in[t+1] seen, xr[t], factored, out[t+1] (all relative to
 "in[t] seen"), then the gap to the next block's "in[t] seen"."""
@@ -21,14 +21,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--pair", type=int, default=1)
-    ap.add_argument("--chain", type=int, default=0)
     ap.add_argument("--min-tiles", type=int, default=0)
     ap.add_argument("--every", type=int, default=1)
     a = ap.parse_args()
     import cocons_amd as ca
     from cocons_amd import _lib, workloads as wl
     L = _lib.load()
-    for k, v in (("dag", 1), ("dag_chain", a.chain), ("dag_min_tiles", a.min_tiles), ("dag_trace", 1), ("engine_pair", a.pair)):
+    for k, v in (("dag", 1), ("dag_min_tiles", a.min_tiles), ("dag_trace", 1), ("engine_pair", a.pair)):
         _lib.check(L.cocons_debug_tune(k.encode(), v), "tune")
     g = int(round(math.sqrt(a.n)))
     locs = wl.grid_locs(g)
@@ -39,13 +38,13 @@ def main():
         fit.neg2loglik_core(th)
     ns = ctypes.c_int(0)
     nt_tasks = L.cocons_debug_dag_trace(fit._h, ctypes.byref(ns), None, None, None)
-    steps = np.zeros((ns.value, 20), dtype=np.int32)
+    steps = np.zeros((ns.value, 16), dtype=np.int32)
     stamps = np.zeros((nt_tasks, 4), dtype=np.uint64)
     nt = (fit.n + 127) // 128 + 2
     eng = np.zeros((nt + 2, 8), dtype=np.uint64)
     L.cocons_debug_dag_trace(fit._h, ctypes.byref(ns), steps.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
                              stamps.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), eng.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)))
-    print("n = %d pair = %d chain = %d: %d steps; engine state %s" % (fit.n, a.pair, a.chain, ns.value, fit.engine_state()))
+    print("n = %d pair = %d: %d steps; engine state %s" % (fit.n, a.pair, ns.value, fit.engine_state()))
     print("%5s | %8s %8s | %8s %8s %8s %8s | %8s %8s" % ("block", "factored", "out[t]", "in[t+1]", "xr[t]", "factored", "out[t+1]",
                                                         "block us", "to next"))
     rows = []

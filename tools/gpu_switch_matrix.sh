@@ -7,7 +7,7 @@ PART=${PART:-1}
 part1=("COCONS_DAG=0" "COCONS_DAG_MIN_TILES=0" "COCONS_DAG_SPLIT=0" "COCONS_DAG_XCC_QUOTA=0" "COCONS_DAG_LEAD=3600 COCONS_DAG_LEAD2=0 COCONS_DAG_LEAD3=0"
        "COCONS_BATCH_ENGINE=0 COCONS_BATCH_SLOTS=3" "COCONS_ENGINE=0" "COCONS_UPD_WAVES=4" "COCONS_UPD_W8_MAX_TILES=0" "COCONS_UPD_DYNAMIC=0" "COCONS_FRONT_PAD=0")
 part2=("COCONS_RHS_SLOTS=0" "COCONS_TAPER_PACKED=0" "COCONS_SPATIAL_SORT=0" "COCONS_PAIR_BLOCKED=0" "COCONS_TAPER_RCM=0" "COCONS_TAPER_BAND=0"
-       "COCONS_BATCH_SLOTS=1" "COCONS_BATCH_SLOTS=4" "COCONS_DAG_CHAIN=1" "COCONS_DAG_CHAIN=1 COCONS_DAG_MIN_TILES=0"
+       "COCONS_BATCH_SLOTS=1" "COCONS_BATCH_SLOTS=4"
        "COCONS_ENGINE_PAIR=0" "COCONS_PANEL_FUSED=0" "COCONS_ENGINE_PAIR=0 COCONS_PANEL_FUSED=0 COCONS_DAG_MIN_TILES=0"
        "COCONS_POTRF_FOLLOW=0" "COCONS_POTRF_FOLLOW=0 COCONS_ENGINE=0" "COCONS_PANEL_FOLLOW=0"
        "COCONS_PANEL_DIAG=0" "COCONS_PANEL_SPLIT=0" "COCONS_PANEL_SPLIT=1"
@@ -15,7 +15,7 @@ part2=("COCONS_RHS_SLOTS=0" "COCONS_TAPER_PACKED=0" "COCONS_SPATIAL_SORT=0" "COC
 shard=()
 case "$PART" in
   1) cfgs=("${part1[@]}"); : > gpurun_out/switch_matrix.txt ;;
-  2) cfgs=("${part2[@]}"); shard=("COCONS_SHARD_GROUP=1" "COCONS_SHARD_GROUP=2" "COCONS_SHARD_COMM2=0") ;;
+  2) cfgs=("${part2[@]}"); shard=("COCONS_SHARD_GROUP=1" "COCONS_SHARD_GROUP=2" "COCONS_SHARD_COMM2=1") ;;
   retry) IFS=';' read -r -a cfgs <<< "$RETRY"; shard=(); IFS=';' read -r -a shard <<< "${RETRY_SHARD:-}" ;;
   *) echo "PART=1|2|retry"; exit 2 ;;
 esac

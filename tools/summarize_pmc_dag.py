@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 passes of tools/r5_pmc_dag.sh (gpurun_out/r5_dag_pmc_*/p_counter_collection.csv) into
-profiles/r05_dag_kernel_mfma_util.json and profiles/r05_dag_kernel_hbm_traffic.json (what bench.py's roofline block reads).
+"""Summarise the rocprofv3 passes of `tools/gpu_run.sh pmc_dag` (gpurun_out/<TAG>_dag_pmc_*/p_counter_collection.csv) into
+profiles/<TAG>_dag_kernel_mfma_util.json and profiles/<TAG>_dag_kernel_hbm_traffic.json (what bench.py's roofline block reads;
+TAG from the environment, default r06).
     python tools/summarize_pmc_dag.py"""
 import csv
 import glob
@@ -13,6 +14,10 @@ from collections import defaultdict
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(R, "gpurun_out")
 P = os.path.join(R, "profiles")
+TAG = os.environ.get("TAG", "r06")
+import hashlib
+with open(os.path.join(R, "cocons_amd", "csrc", "chol.hip"), "rb") as _fh:
+    SRC_SHA = hashlib.sha256(_fh.read()).hexdigest()[:16]      # bench.py compares it with the tree it runs in
 commit = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 
 
@@ -24,7 +29,7 @@ def find(d, name):
 
 
 def load(i):
-    rows = list(csv.DictReader(open(find("r5_dag_pmc_%d" % i, "p_counter_collection.csv"))))
+    rows = list(csv.DictReader(open(find("%s_dag_pmc_%d" % (TAG, i), "p_counter_collection.csv"))))
     per = defaultdict(dict)
     for r in rows:
         d = per[int(r["Dispatch_Id"])]
@@ -41,9 +46,9 @@ def last(i):
     return d[-1]            # the last replay of the run (warm)
 
 
-shutil.copy(find("r5_dag_trace", "t_kernel_stats.csv"), os.path.join(P, "r05_dag_replay_kernel_stats.csv"))
+shutil.copy(find(TAG + "_dag_trace", "t_kernel_stats.csv"), os.path.join(P, TAG + "_dag_replay_kernel_stats.csv"))
 line = None
-for ln in open(os.path.join(G, "r5_dag_trace.log")):
+for ln in open(os.path.join(G, TAG + "_dag_trace.log")):
     if ln.startswith("{"):
         line = json.loads(ln)
 a, b, fe, wr, tc = last(1), last(2), last(3), last(4), last(5)
@@ -51,7 +56,7 @@ simd_cycles = a["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
 mf = {
     "kernel": "cocons::dag_kernel, replayed alone at n = 10000 (tools/dag_replay.py: same task list, products and C traffic; the "
               "engine's outputs prepared beforehand)",
-    "commit": commit, "command": "tools/r5_pmc_dag.sh (rocprofv3 --kernel-trace --pmc, one pass per counter group)",
+    "commit": commit, "kernel_source_sha16": SRC_SHA, "command": "tools/gpu_run.sh pmc_dag (rocprofv3 --kernel-trace --pmc, one pass per counter group)",
     "launch_us_under_pmc": a["dur_us"],
     "replay_line_kernel_trace_pass": line,
     "mfma_busy_over_simd_cycles": a["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
@@ -64,11 +69,11 @@ mf = {
                          for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY")},
     "counters": {k: v for k, v in {**a, **b}.items() if k not in ("name", "dur_us")},
 }
-json.dump(mf, open(os.path.join(P, "r05_dag_kernel_mfma_util.json"), "w"), indent=1)
+json.dump(mf, open(os.path.join(P, TAG + "_dag_kernel_mfma_util.json"), "w"), indent=1)
 print(json.dumps(mf, indent=1)[:1800])
 fetch_b, write_b = fe["FETCH_SIZE"] * 1024.0, wr["WRITE_SIZE"] * 1024.0
 tr = {
-    "kernel": mf["kernel"], "commit": commit, "command": mf["command"],
+    "kernel": mf["kernel"], "commit": commit, "kernel_source_sha16": SRC_SHA, "command": mf["command"],
     "FETCH_SIZE_bytes_raw": fetch_b, "WRITE_SIZE_bytes": write_b,
     "l2_hit_rate": tc["TCC_HIT_sum"] / max(tc["TCC_HIT_sum"] + tc["TCC_MISS_sum"], 1.0),
     "hbm_bytes_per_launch": fetch_b + write_b,
@@ -78,5 +83,5 @@ tr = {
             "lane (L2-bypassing) and its operand chunks 16 B per lane, so the true read volume lies between raw and 2 x raw "
             "(`hbm_bytes_per_launch_high`); `hbm_bytes_per_launch` is the uncorrected sum.",
 }
-json.dump(tr, open(os.path.join(P, "r05_dag_kernel_hbm_traffic.json"), "w"), indent=1)
+json.dump(tr, open(os.path.join(P, TAG + "_dag_kernel_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(tr, indent=1))
