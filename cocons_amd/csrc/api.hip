@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -82,8 +83,22 @@ struct ModeSel {
     double gr;
 };
 
-static void make_theta_vecs(const double *theta, int p, ThetaVecs &tv)
+// The mailboxes of the factorisation use the all-ones bit pattern as "not written yet" (chol.hip: the data is its own flag).
+// That pattern is a quiet NaN no arithmetic PRODUCES -- the hardware's own NaN is 0x7ff8000000000000 -- but NaN payloads
+// PROPAGATE, so an all-ones NaN in the caller's data or parameters could reach a factor block and be waited for until the bounded
+// wait gives up (a time-out and a repeat, never a wrong value).  Everything that enters the device is therefore canonicalised:
+// an all-ones NaN becomes the standard quiet NaN (R's NA_real_ and NaN are other patterns and pass unchanged).
+static inline double canon_nan(double v)
 {
+    unsigned long long b;
+    memcpy(&b, &v, sizeof b);
+    return b == ~0ull ? std::numeric_limits<double>::quiet_NaN() : v;
+}
+
+static void make_theta_vecs(const double *theta_in, int p, ThetaVecs &tv)
+{
+    double theta[6 * COCONS_P_MAX];
+    for (int i = 0; i < 6 * p; ++i) theta[i] = canon_nan(theta_in[i]);
     memset(&tv, 0, sizeof tv);
     for (int i = 0; i < p; ++i) {
         double sje = (i == 0) ? 0.0 : theta[TH_SCALE * p + i];      // cocons_full.cpp:49,64
@@ -102,7 +117,7 @@ static void make_theta_vecs(const double *theta, int p, ThetaVecs &tv)
 static ModeSel select_mode(const double *theta, int p, const double *smooth_limits, int which)
 {
     ModeSel m;
-    m.gr = 1 / std::exp(-2 * theta[TH_SCALE * p + 0]);              // :62, :351, :501
+    m.gr = canon_nan(1 / std::exp(-2 * theta[TH_SCALE * p + 0]));   // :62, :351, :501
     m.nu_fixed = 0.0;
     if (which == 1) { m.mode = MODE_MEAN; m.smooth_kind = SMOOTH_EXP; return m; }
     if (which == 2) { m.mode = MODE_GEOM; m.smooth_kind = SMOOTH_LOGISTIC_SQRT; return m; }
@@ -545,8 +560,9 @@ static cocons_fit *fit_create_impl(int n, int p, int r, int q, const double *loc
     auto permute_pad = [&](const double *src, int ncol, bool zero_pad) {
         std::vector<double> out((size_t)nint * ncol);
         for (int c = 0; c < ncol; ++c) {
-            for (int i = 0; i < pad0; ++i) out[(size_t)i + (size_t)c * nint] = zero_pad ? 0.0 : src[(size_t)perm[0] + (size_t)c * n];
-            for (int i = 0; i < n; ++i) out[(size_t)(pad0 + i) + (size_t)c * nint] = src[(size_t)perm[i] + (size_t)c * n];
+            // (canon_nan: no all-ones NaN enters the device -- the mailboxes' "not written yet" pattern, see there)
+            for (int i = 0; i < pad0; ++i) out[(size_t)i + (size_t)c * nint] = zero_pad ? 0.0 : canon_nan(src[(size_t)perm[0] + (size_t)c * n]);
+            for (int i = 0; i < n; ++i) out[(size_t)(pad0 + i) + (size_t)c * nint] = canon_nan(src[(size_t)perm[i] + (size_t)c * n]);
         }
         return out;
     };
@@ -860,7 +876,7 @@ static int assemble_sigma_taper(cocons_fit *f, const double *theta)
 {
     ThetaVecs tv;
     make_theta_vecs(theta, f->p, tv);
-    for (int i = 0; i < f->p; ++i) tv.two_scale_je[i] = 2 * theta[TH_SCALE * f->p + i];
+    for (int i = 0; i < f->p; ++i) tv.two_scale_je[i] = canon_nan(2 * theta[TH_SCALE * f->p + i]);
     ModeSel ms = select_mode(theta, f->p, f->smooth_limits, 0);
     LocArgs la;
     la.n = f->n; la.p = f->p;
@@ -896,7 +912,7 @@ static void assemble_rhs(cocons_fit *f, const double *mean, bool use_trend, cons
     memset(&ra, 0, sizeof ra);
     ra.n = f->n; ra.p = f->p; ra.X = f->dX; ra.ldx = f->n;
     ra.use_trend = use_trend ? 1 : 0;
-    if (use_trend) for (int i = 0; i < f->p; ++i) ra.mean[i] = mean[i];
+    if (use_trend) for (int i = 0; i < f->p; ++i) ra.mean[i] = canon_nan(mean[i]);
     ra.src = f->dz; ra.lds = f->n;
     ra.out = f->dA; ra.ld = f->lda;
     ra.skew = f->skew; ra.npad = f->npad;
@@ -1698,7 +1714,7 @@ static int info_status(cocons_fit *f)
 {
     // COCONS_DEBUG_ABORT=1: say which wait gave up (0x1tt / 0x2tt engine waiting for tile tt, 0x3tt panel solve
     // waiting for the engine's tile tt, 0x5.. in-panel update, 0x600 the gate waiting for the engine to be resident,
-    // 0x800 panel product (mode 3), 0x900 the reductions waiting for the engine's last tile)
+    // 0x900 the reductions waiting for the engine's last tile: kernels.h, abort_code / abort_class)
     if (f->hinfo[1] != 0 && getenv("COCONS_DEBUG_ABORT")) {
         fprintf(stderr, "cocons: hand-off time-out, code 0x%x\n", f->hinfo[1]);
         if (f->dag_used && f->ddag && (f->hinfo[1] & 0xf00) >= 0xa00) {
@@ -1789,7 +1805,7 @@ static bool engine_retry(cocons_fit *f, int st)
     if (st != ENGINE_ABORT || !(f->engine_used || f->follow_used)) return false;
     f->engine_retries++;
     f->engine_last_abort = f->hinfo[1];
-    if (!f->engine_used || (f->hinfo[1] & 0xff0) == 0x7f0) f->follow_off = true;      // a follower of potrf_follow_kernel gave up: two launches from now on
+    if (!f->engine_used || abort_class((unsigned)f->hinfo[1]) == ABORT_FOLLOW) f->follow_off = true;      // a follower of potrf_follow_kernel gave up: two launches from now on
     if (f->engine_fails < 6) f->engine_fails++;
     f->engine_skip = 1 << f->engine_fails;
     f->engine_live = false;
@@ -2173,6 +2189,26 @@ extern "C" int cocons_fit_profile(cocons_fit *f, const double *theta, const doub
     int st = info_status(f);
     if (engine_retry(f, st)) return cocons_fit_profile(f, theta, mean, reps, ms);
     return st;
+}
+
+// (diagnostics) the covariance assembly of an evaluation ALONE, `reps` times back to back on the handle's stream between two
+// events: ms_out[0] = mean milliseconds per assembly.  tools/diag/overlap_probe.py runs it on one handle while another thread
+// evaluates on a second handle: what the assembly (fp64 vector work) and the factorisation (fp64 matrix work) cost each other
+// when they share the chip -- the measurement behind DESIGN.md section 8 "Assembly beside the factorisation".
+extern "C" int cocons_debug_assembly_loop(cocons_fit *f, const double *theta, int reps, double *ms_out)
+{
+    FIT_ENTER(f);
+    if (int rc = no_taper(f, "cocons_debug_assembly_loop")) return rc;
+    if (!theta || !ms_out || reps < 1) return fail(-1, "cocons_debug_assembly_loop: bad argument");
+    if (int rc = fit_alloc_matrix(f, f->r > 0 ? f->r : 1)) return rc;
+    hipEventRecord(f->ev[0], f->stream);
+    for (int i = 0; i < reps; ++i) assemble_sigma(f, theta, 0, 0, f->npad);
+    hipEventRecord(f->ev[1], f->stream);
+    HIPCHK(hipStreamSynchronize(f->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, f->ev[0], f->ev[1]));
+    ms_out[0] = (double)ms / reps;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -759,7 +759,7 @@ __device__ __forceinline__ void engine_partner_loop(const EngineArgs &e, double 
         __hip_atomic_fetch_add(e.alive + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int t = e.t0; t + 1 < e.nt; t += 2) {
-        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t, e.in_ticks) ? 1 : 0;
+        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, abort_code(ABORT_ENGINE_IN1, (unsigned)t), e.in_ticks) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
@@ -804,7 +804,7 @@ __device__ __forceinline__ void engine_partner_loop(const EngineArgs &e, double 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             double *LS = LST + (j & 1) * (9 * 256);
-            MBOX_COMPLETE(j, e.abort_word, 0x700u + (unsigned)t)
+            MBOX_COMPLETE(j, e.abort_word, abort_code(ABORT_PARTNER, (unsigned)t))
 #pragma unroll
             for (int i = 0; i < 5; ++i)
                 if (half + 2 * i <= 8 - j) LS[tid + 512 * i] = v[i];
@@ -921,7 +921,7 @@ potrf_engine_kernel(EngineArgs e)
         __hip_atomic_store(e.alive, 1u + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int t = e.t0; t < e.nt; t += 2) {
-        if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word, 0x100u + t, e.in_ticks) ? 1 : 0;
+        if (tid == 0) *okp = wait_ge<false>(e.in + t, 3u, e.abort_word, abort_code(ABORT_ENGINE_IN0, (unsigned)t), e.in_ticks) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
@@ -947,7 +947,7 @@ potrf_engine_kernel(EngineArgs e)
         if (t + 1 >= e.nt) return;
         if (pair) continue;              // (the rest of the block is the partner's)
 
-        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, 0x200u + t, e.in_ticks) ? 1 : 0;
+        if (tid == 0) *okp = wait_ge<false>(e.in + t + 1, 7u, e.abort_word, abort_code(ABORT_ENGINE_IN1, (unsigned)t), e.in_ticks) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (*okp == 0) return;
@@ -1081,7 +1081,7 @@ potrf_follow_kernel(double *A, size_t lda, int c0, double *q_out, int *info, dou
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         double *LS = LST + (j & 1) * (9 * 256);
-        MBOX_COMPLETE(j, abort_word, 0x7f0u)
+        MBOX_COMPLETE(j, abort_word, abort_code(ABORT_FOLLOW, (unsigned)(c0 / TILE)))
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             if (half + 2 * i <= 8 - j) LS[tid + 512 * i] = v[i];
@@ -1208,7 +1208,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
                 if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
                 const bool late_ = it > (unsigned)(ENGINE_TIMEOUT_TICKS / 100ull);
                 if (late_ || ((it & 7u) == 7u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                    if (late_ && lane == 0) __hip_atomic_store(abort_word, 0x7e0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (late_ && lane == 0) __hip_atomic_store(abort_word, abort_code(ABORT_XCHG, (unsigned)(c0 / TILE)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     good = false;
                     break;
                 }
@@ -1261,7 +1261,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
             B1[j] = glb_blk(A, lda, rs, c1 + 16 * j, lane);
             acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
         }
-        if (tid == 0) ok = wait_ge<false>(xrw, 1u, abort_word, 0x500u + c0 / TILE) ? 1 : 0;
+        if (tid == 0) ok = wait_ge<false>(xrw, 1u, abort_word, abort_code(ABORT_INPANEL, (unsigned)(c0 / TILE))) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (!ok) return;
@@ -1302,7 +1302,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
                     if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
                     const bool late_ = it > (unsigned)(ENGINE_TIMEOUT_TICKS / 100ull);
                     if (late_ || ((it & 7u) == 7u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                        if (late_ && lane == 0) __hip_atomic_store(abort_word, 0x7d0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (late_ && lane == 0) __hip_atomic_store(abort_word, abort_code(ABORT_STRIPBOX, (unsigned)(c0 / TILE)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         good = false;
                         break;
                     }
@@ -1347,7 +1347,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 double *LS = SM + (j & 1) * (9 * 256);
-                MBOX_COMPLETE256V(j, v9[j % 3], abort_word, 0x300u + c1 / TILE)
+                MBOX_COMPLETE256V(j, v9[j % 3], abort_word, abort_code(ABORT_PANEL, (unsigned)(c1 / TILE)))
 #pragma unroll
                 for (int i = 0; i < 9; ++i)
                     if (i <= 8 - j) LS[tid + 256 * i] = v9[j % 3][i];
@@ -1394,7 +1394,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             double *LS = SM + (j & 1) * (9 * 256);
-            MBOX_COMPLETE256V(j, v9[j % 3], abort_word, 0x300u + c0 / TILE)
+            MBOX_COMPLETE256V(j, v9[j % 3], abort_word, abort_code(ABORT_PANEL, (unsigned)(c0 / TILE)))
 #pragma unroll
             for (int i = 0; i < 9; ++i)
                 if (i <= 8 - j) LS[tid + 256 * i] = v9[j % 3][i];
@@ -1416,7 +1416,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
             }
         }
     } else {
-    if (tid == 0) ok = wait_ge<false>(out0, 1u, abort_word, 0x300u + c0 / TILE) ? 1 : 0;
+    if (tid == 0) ok = wait_ge<false>(out0, 1u, abort_word, abort_code(ABORT_PANEL, (unsigned)(c0 / TILE))) ? 1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!ok) return;
@@ -1442,7 +1442,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
     if (split) return;               // (role A: the rest of the strip is role B's)
     // ---- B1 -= X0 X(t+1,t)^T: all 64 blocks of X(t+1,t) into LDS (over the image of L(t), which is dead), four rounds of sixteen
     // loads per thread with the next round in flight while one is stored
-    if (tid == 0) ok = wait_ge<false>(xrw, 1u, abort_word, 0x500u + c0 / TILE) ? 1 : 0;
+    if (tid == 0) ok = wait_ge<false>(xrw, 1u, abort_word, abort_code(ABORT_INPANEL, (unsigned)(c0 / TILE))) ? 1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                 // (also: every wave is done with L(t))
     if (!ok) return;
@@ -1486,7 +1486,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             double *LS = SM + (j & 1) * (9 * 256);
-            MBOX_COMPLETE256V(j, v9[j % 3], abort_word, 0x300u + c1 / TILE)
+            MBOX_COMPLETE256V(j, v9[j % 3], abort_word, abort_code(ABORT_PANEL, (unsigned)(c1 / TILE)))
 #pragma unroll
             for (int i = 0; i < 9; ++i)
                 if (i <= 8 - j) LS[tid + 256 * i] = v9[j % 3][i];
@@ -1507,7 +1507,7 @@ panel_pair_kernel(double *A, size_t lda, int c0, int r0, const double *q0, const
             }
         }
     } else {
-    if (tid == 0) ok = wait_ge<false>(out1, 1u, abort_word, 0x300u + c1 / TILE) ? 1 : 0;
+    if (tid == 0) ok = wait_ge<false>(out1, 1u, abort_word, abort_code(ABORT_PANEL, (unsigned)(c1 / TILE))) ? 1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                 // (also: every wave is done with X(t+1,t))
     if (!ok) return;
@@ -1571,7 +1571,7 @@ trsm_tile_kernel(double *A, size_t lda, int c0, int r0, const double *qin, unsig
         if (((row / (2 * TILE) / own_group) % own_world) != own_rank) return;
     }
     if (wait_word) {     // the diagonal tile comes from the engine, which may still be at work
-        if (tid == 0) ok = wait_ge<false>(wait_word, 1u, abort_word, 0x300u + c0 / TILE) ? 1 : 0;
+        if (tid == 0) ok = wait_ge<false>(wait_word, 1u, abort_word, abort_code(ABORT_PANEL, (unsigned)(c0 / TILE))) ? 1 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (!ok) return;
@@ -1657,7 +1657,7 @@ update_kernel(UpdArgs a)
     const int tid = threadIdx.x;
     const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.wait_word) {     // operand tile comes from the engine
-        if (tid == 0) *share = wait_ge(a.wait_word, 1u, a.abort_word, 0x500u + a.tj0) ? 1u : 0u;
+        if (tid == 0) *share = wait_ge(a.wait_word, 1u, a.abort_word, abort_code(ABORT_INPANEL, (unsigned)a.tj0)) ? 1u : 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const unsigned ok = *share;
@@ -2134,12 +2134,12 @@ dag_kernel(DagArgs a)
                 if (!isT) {
                     // update tile: whole panel there (2)?  else its two strips (1)
                     if (__hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n0) ok = 2u;
-                    else ok = (dag_wait(a, w1, n1, 0xb00u + (unsigned)s, L) &&
-                               dag_wait(a, w2, n2, 0xc00u + (unsigned)s, L)) ? 1u : 0u;
+                    else ok = (dag_wait(a, w1, n1, abort_code(0xb00u, (unsigned)s), L) &&
+                               dag_wait(a, w2, n2, abort_code(0xc00u, (unsigned)s), L)) ? 1u : 0u;
                 } else {
-                    bool o = dag_wait(a, w0, n0, 0xa00u + (unsigned)s, L);
-                    if (o && w1) o = dag_wait(a, w1, n1, 0xb00u + (unsigned)s, L);
-                    if (o && w2) o = dag_wait(a, w2, n2, 0xc00u + (unsigned)s, L);
+                    bool o = dag_wait(a, w0, n0, abort_code(0xa00u, (unsigned)s), L);
+                    if (o && w1) o = dag_wait(a, w1, n1, abort_code(0xb00u, (unsigned)s), L);
+                    if (o && w2) o = dag_wait(a, w2, n2, abort_code(0xc00u, (unsigned)s), L);
                     ok = o ? 1u : 0u;
                 }
                 *share = ok;
@@ -2206,8 +2206,8 @@ dag_kernel(DagArgs a)
         if (t2 == 0) {
             const unsigned Ln = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight during the poll)
             unsigned ok = 1u;
-            if (we) ok = dag_wait(a, we, ne, 0xd00u + (unsigned)s, L) ? 1u : 0u;
-            if (ok && we2) ok = wait_ge<false>(we2, 1u, a.abort_word, 0xe00u + (unsigned)s) ? 1u : 0u;   // (no record: a second dag_wait costs the kernel its scratch-free allocation)
+            if (we) ok = dag_wait(a, we, ne, abort_code(0xd00u, (unsigned)s), L) ? 1u : 0u;
+            if (ok && we2) ok = wait_ge<false>(we2, 1u, a.abort_word, abort_code(0xe00u, (unsigned)s)) ? 1u : 0u;   // (no record: a second dag_wait costs the kernel its scratch-free allocation)
             share[0] = ok; share[1] = Ln;
             if (a.trace) a.trace[4 * (size_t)L + 2] = __builtin_amdgcn_s_memrealtime();
         }
@@ -2467,7 +2467,7 @@ void launch_engine_gate(unsigned *alive, unsigned *abort_word, hipStream_t s, bo
     // patient: the start-up gate of a handle's FIRST engine-schedule operation -- 50 ms instead of 5: whatever a first
     // dispatch on a fresh stream may still cost the runtime (the warm-up launch of the handle has paid what it can) must
     // not be mistaken for "every CU is taken by someone else"
-    hipLaunchKernelGGL(engine_gate_kernel, dim3(1), dim3(64), 0, s, alive, abort_word, last_tile ? 0x900u : 0x600u,
+    hipLaunchKernelGGL(engine_gate_kernel, dim3(1), dim3(64), 0, s, alive, abort_word, last_tile ? ABORT_LAST_TILE : ABORT_GATE,
                        last_tile ? ENGINE_TIMEOUT_TICKS : (patient ? 10 * GATE_TIMEOUT_TICKS : GATE_TIMEOUT_TICKS),
                        (unsigned)(last_tile || nhelp < 0 ? 0 : nhelp), last_tile ? nullptr : raise_in);
 }

@@ -138,6 +138,20 @@ void launch_potrf_engine(double *A, size_t lda, int t0, int nt, double *dinv, in
                                                                          // launch; a second workgroup takes the second tile of every block
                          int in_wait_ms = 0);                            // > 0 (tests): bound of the engine's waits for its input words
                                                                          // in milliseconds instead of the host-paced 3 s
+// Abort codes of the bounded hand-off waits (the abort word behind the info word: who gave up).  CLASS in bits 8..11, an index
+// -- the tile or, for the persistent launch, the step -- in the low byte, masked so that no index can spill into another class
+// (until round 5 the engine's partner reported 0x700 + tile while the followers used the fixed codes 0x7d0 / 0x7e0 / 0x7f0: from
+// tile 208 on a partner's time-out read as a follower's).  One decoder for the host: abort_class().
+//   0x100 / 0x200  engine waiting for in[t] / in[t+1] (host-paced)      0x300  panel solve waiting for the engine's tile
+//   0x400  split panel's second workgroup waiting in its exchange mailbox   0x500  in-panel update waiting for xr[t]
+//   0x600  start-up gate (engine / partner not resident)                 0x700  the engine's partner following tile t
+//   0x800  a follower of potrf_follow_kernel (plain / band-limited schedule)  0x900  the reductions waiting for the last tile
+//   0xa00 .. 0xe00  waits of the persistent launch (dag_kernel: index = step)  0xf00  next-diagonal-block workgroups of the
+//   panel launch waiting in the strip mailbox
+constexpr unsigned ABORT_ENGINE_IN0 = 0x100u, ABORT_ENGINE_IN1 = 0x200u, ABORT_PANEL = 0x300u, ABORT_XCHG = 0x400u, ABORT_INPANEL = 0x500u,
+                   ABORT_GATE = 0x600u, ABORT_PARTNER = 0x700u, ABORT_FOLLOW = 0x800u, ABORT_LAST_TILE = 0x900u, ABORT_STRIPBOX = 0xf00u;
+__host__ __device__ inline unsigned abort_code(unsigned cls, unsigned index) { return cls | (index & 0xffu); }
+inline unsigned abort_class(unsigned code) { return code & 0xf00u; }
 constexpr size_t ENGINE_MBOX_DOUBLES = 44 * 256;
 // nhelp > 0: also waits until that many further workgroups of the engine's launch (the pair partner) are resident
 // raise_in != NULL: the gate also raises in[0] = 3, in[1] = 7 (the engine factors the first diagonal block too: launch_potrf_engine t0 = 0)

@@ -40,6 +40,10 @@ long long cocons_debug_dag_trace(struct cocons_fit *fit, int *nsteps_out, int *s
 /* host time spent ENQUEUEING evaluations on this handle and its batch slots: out2[0] = mean microseconds per evaluation, out2[1] = evaluations */
 int cocons_debug_host_enqueue(struct cocons_fit *fit, double *out2);
 
+/* The covariance assembly of an evaluation alone, `reps` times back to back: ms_out[0] = mean milliseconds per assembly
+ * (tools/diag/overlap_probe.py: one handle assembling while another thread's handle factorises). */
+int cocons_debug_assembly_loop(struct cocons_fit *fit, const double *theta, int reps, double *ms_out);
+
 /* The persistent launch of the dependency-driven schedule replayed ALONE (counter passes: rocprofv3 --pmc serialises kernels,
  * and the real launch waits for the diagonal-block engine on another stream): what the engine would publish is prepared from
  * a plain-schedule factorisation of the same matrix, all hand-off words are raised, and dag_kernel runs the same task list --
