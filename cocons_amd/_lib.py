@@ -94,6 +94,7 @@ DIAG_SIGNATURES = {
     "cocons_debug_tune": (c_int, [ctypes.c_char_p, c_int]),
     "cocons_debug_dag_replay": (c_int, [c_vp, c_dp, c_dp, c_int, c_dp]),
     "cocons_debug_host_enqueue": (c_int, [c_vp, c_dp]),
+    "cocons_debug_dag_words": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_uint)]),
     "cocons_debug_assembly_loop": (c_int, [c_vp, c_dp, c_int, c_dp]),
     "cocons_debug_dag_trace": (ctypes.c_longlong, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                                    ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]),

@@ -298,7 +298,10 @@ struct cocons_fit {
     double *dpart;                // early halves of the split diagonal-block tiles (2 x 16 x 64 x 64 doubles)
     unsigned *ddag; size_t ddag_words;      // [queue (64 words)] [tdone] [pdone]
     void *ddag_steps; int dag_nsteps; unsigned dag_ntasks;
-    int dag_key[10];              // (nt, mt, trim, kskip, lead, min_tiles, split, lead2, lead3, 0) the step table was built for
+    int dag_key[13];              // (nt, mt, trim, kskip, lead, min_tiles, split, lead2, lead3, order, xcd, bw, bh) the step table was built for
+    unsigned *ddag_ftab; size_t ddag_ftab_words;   // which tile every far tile task is (dag_build_steps' table), device copy
+    int dag_xcd_g;                // chunk exponent of the XCD-aware deal the table was built for (0: one counter)
+    bool dag_have_ftab;           // the current step table comes with a far-tile table
     unsigned long long *ddag_trace; size_t dag_trace_tasks;   // diagnostics (cocons_debug_tune("dag_trace", 1)): 4 stamps per task
     size_t dag_trace_elems;       // allocated 64-bit words of ddag_trace (5 per task + 8 per tile pair)
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
@@ -423,6 +426,7 @@ extern "C" void cocons_fit_destroy(cocons_fit *f)
         hipFree(f->dflags);
         if (f->dmbox) hipFree(f->dmbox);
         hipFree(f->dP); hipFree(f->dWt); hipFree(f->ddag); hipFree(f->ddag_steps); hipFree(f->ddag_trace); hipFree(f->dpart);
+        hipFree(f->ddag_ftab);
         hipFree(f->d_tci); hipFree(f->d_trp); hipFree(f->d_tval); hipFree(f->d_thi);
         if (f->cstream_l && f->cstream_l != f->cstream) { hipStreamSynchronize(f->cstream_l); hipStreamDestroy(f->cstream_l); }
         if (f->cstream) { hipStreamSynchronize(f->cstream); hipStreamDestroy(f->cstream); }
@@ -1025,6 +1029,13 @@ struct Tunables {
                              // engine became a pair (round 5): with the shorter chain the break-even moved back, 1400 .. 2200
                              // measure alike, +0.4 % over 3000)
     int dag_split = 1;       // COCONS_DAG_SPLIT: the diagonal-block tiles of a DAG step in two halves, the first one off the chain
+    int dag_xcd = 1;         // COCONS_DAG_XCD: 1 = XCD-aware task order of the persistent launch (round 6; chol.hip: dag_position) -- list
+                             // positions dealt to the XCDs in chunks of 32, the far tiles of a step dealt so that one XCD's tiles in
+                             // flight form one block of dag_bw x dag_bh tiles, the same number of workgroups from every XCD; 0 = one
+                             // counter for all (rounds 4-5).  dag_order (COCONS_DAG_ORDER): 1 = far tiles in blocks (needs no XCD deal),
+                             // 0 = column-major as in rounds 4-5
+    int dag_order = 1, dag_bw = 16, dag_bh = 13;
+    int dag_xcd_lag = 1024, dag_xcd_quota_all = 1, dag_xcd_g = 5;
     int dag_xcc_quota = -1;  // workgroups of the DAG launch that take part on the engine's XCD (of the 255 that land there; 0: all;
                              // -1: derived from the device, dag_xcc_quota() -- 208 on MI355X)
     int engine_block0 = 1;   // COCONS_ENGINE_BLOCK0: 1 = the engine factors the FIRST diagonal block too (its input words raised by the gate
@@ -1071,6 +1082,10 @@ static Tunables &tun()
         rd("COCONS_DAG_MIN_TILES", t.dag_min_tiles);
         rd("COCONS_DAG_SPLIT", t.dag_split);
         rd("COCONS_DAG_XCC_QUOTA", t.dag_xcc_quota);
+        rd("COCONS_DAG_XCD", t.dag_xcd);
+        rd("COCONS_DAG_ORDER", t.dag_order);
+        rd("COCONS_DAG_BW", t.dag_bw);
+        rd("COCONS_DAG_BH", t.dag_bh);
         rd("COCONS_ENGINE_PAIR", t.engine_pair);
         rd("COCONS_ENGINE_BLOCK0", t.engine_block0);
         rd("COCONS_PANEL_FUSED", t.panel_fused);
@@ -1105,6 +1120,13 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "dag_min_tiles") t.dag_min_tiles = value;
     else if (k == "dag_split") t.dag_split = value;
     else if (k == "dag_xcc_quota") t.dag_xcc_quota = value;
+    else if (k == "dag_xcd") t.dag_xcd = value;
+    else if (k == "dag_order") t.dag_order = value;
+    else if (k == "dag_xcd_lag") t.dag_xcd_lag = value;
+    else if (k == "dag_xcd_g") t.dag_xcd_g = value < 1 ? 1 : (value > 10 ? 10 : value);
+    else if (k == "dag_xcd_quota_all") t.dag_xcd_quota_all = value;
+    else if (k == "dag_bw") t.dag_bw = value < 1 ? 1 : value;
+    else if (k == "dag_bh") t.dag_bh = value < 1 ? 1 : value;
     else if (k == "dag_trace") t.dag_trace = value;
     else if (k == "engine_pair") t.engine_pair = value;
     else if (k == "engine_block0") t.engine_block0 = value;
@@ -1130,6 +1152,14 @@ extern "C" int cocons_debug_tune(const char *name, int value)
 // moves the engine.  The quota keeps the launch below what fits in ANY placement: seven per CU on the XCD's other CUs, less
 // one CU's worth and one: (CUs per XCD - 1) x 7 - 9 = 208 for the 32 CUs per XCD of MI355X (the value of round 4's soak runs:
 // 0 time-outs in 40 000 evaluations), from hipDeviceProp instead of a constant; COCONS_DAG_XCC_QUOTA overrides.
+static int device_cus()
+{
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+}
+
 static int dag_xcc_quota()
 {
     if (tun().dag_xcc_quota >= 0) return tun().dag_xcc_quota;
@@ -1385,11 +1415,17 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         f->dWt_tiles = v.nt;
     }
     const int kskip = (f->pad0 / 16) * 16;
-    const int key[10] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, tun().dag_lead2, tun().dag_lead3, 0};
+    // (the XCD-aware deal assumes the eight XCDs of the whole chip: a partitioned device keeps the one counter)
+    const int xcd_g = (tun().dag_xcd && device_cus() == 256) ? tun().dag_xcd_g : 0;
+    const int key[13] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, tun().dag_lead2, tun().dag_lead3,
+                         tun().dag_order, xcd_g, tun().dag_bw, tun().dag_bh};
     if (memcmp(key, f->dag_key, sizeof key) != 0 || !f->ddag_steps) {
         std::vector<DagStepHost> steps;
+        std::vector<unsigned> ftab;
+        const bool want_tab = tun().dag_order != 0 || xcd_g > 0;
         const unsigned ntasks = dag_build_steps(v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, steps,
-                                                tun().dag_lead2, tun().dag_lead3);
+                                                tun().dag_lead2, tun().dag_lead3, want_tab ? &ftab : nullptr, xcd_g,
+                                                tun().dag_order ? tun().dag_bw : 0, tun().dag_bh);
         HIPCHK(hipStreamSynchronize(f->stream));
         if (f->stream2) HIPCHK(hipStreamSynchronize(f->stream2));
         if (f->ddag_steps) { HIPCHK(hipFree(f->ddag_steps)); f->ddag_steps = nullptr; }
@@ -1397,6 +1433,15 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         // (on the handle's own stream: the library never touches the NULL stream -- a synchronous hipMemcpy here gave it a
         // hardware queue of its own and shifted every later stream's assignment)
         HIPCHK(hipMemcpyAsync(f->ddag_steps, steps.data(), steps.size() * sizeof(DagStepHost), hipMemcpyHostToDevice, f->stream));
+        if (f->ddag_ftab_words < ftab.size()) {
+            if (f->ddag_ftab) { HIPCHK(hipFree(f->ddag_ftab)); f->ddag_ftab = nullptr; f->ddag_ftab_words = 0; }
+            HIPCHK(hipMalloc(&f->ddag_ftab, ftab.size() * sizeof(unsigned)));
+            f->ddag_ftab_words = ftab.size();
+        }
+        if (!ftab.empty())
+            HIPCHK(hipMemcpyAsync(f->ddag_ftab, ftab.data(), ftab.size() * sizeof(unsigned), hipMemcpyHostToDevice, f->stream));
+        f->dag_xcd_g = want_tab ? xcd_g : 0;
+        f->dag_have_ftab = want_tab && !ftab.empty();
         HIPCHK(hipStreamSynchronize(f->stream));
         f->dag_nsteps = (int)steps.size(); f->dag_ntasks = ntasks;
         memcpy(f->dag_key, key, sizeof key);
@@ -1451,6 +1496,18 @@ extern "C" long long cocons_debug_dag_trace(cocons_fit *f, int *nsteps_out, int 
     }
     HIPCHK(hipStreamSynchronize(f->stream));
     return (long long)f->dag_ntasks;
+}
+
+// (diagnostics) the first `count` task words of the handle's last dependency-driven factorisation: [0] the one task counter,
+// [8..14] the record of a wait that ran out, [16..23] workgroups that took part per XCD, [32..39] the XCDs' own task counters
+extern "C" int cocons_debug_dag_words(cocons_fit *f, int count, unsigned *out)
+{
+    FIT_ENTER(f);
+    if (!f->ddag || !out || count < 1 || (size_t)count > f->ddag_words) return fail(-1, "cocons_debug_dag_words: bad argument or no DAG factorisation yet");
+    HIPCHK(hipStreamSynchronize(f->stream));
+    HIPCHK(hipMemcpyAsync(out, f->ddag, (size_t)count * sizeof(unsigned), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return 0;
 }
 
 static int engine_start(cocons_fit *f, const FactorView &v)
@@ -1613,7 +1670,8 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         }
         launch_dag(v.A, v.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
                    pdone, (int)T64, pall, f->dpart, dcount, in, out, xr, abort_word, M, f->dag_trace_tasks ? f->ddag_trace : nullptr,
-                   alive, dag_xcc_quota(), f->dag_trace_tasks ? (unsigned *)(f->ddag_trace + 4 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2)) : nullptr);
+                   alive, dag_xcc_quota(), f->dag_trace_tasks ? (unsigned *)(f->ddag_trace + 4 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2)) : nullptr,
+                   f->dag_have_ftab ? f->ddag_ftab : nullptr, f->dag_xcd_g, tun().dag_xcd_lag, tun().dag_xcd_quota_all);
         if (ev_upd) { hipEventRecord(eb, M); ev_upd->push_back(ea); ev_upd->push_back(eb); f->dag_events = 1; }
         k_first = 2 * f->dag_nsteps;
     }
@@ -3704,9 +3762,14 @@ extern "C" int cocons_debug_dag_replay(cocons_fit *f, const double *theta, const
             panel_ops(f, fv, 0, M);
             CKR(hipMemsetAsync(f->ddag, 0, f->ddag_words * sizeof(unsigned), M));
             CKR(hipMemsetD32Async((hipDeviceptr_t)f->dflags, 0x3fffffff, 3 * (size_t)f->flags_cap, M));   // in / out / xr: all raised
+            // (as many workgroups take part as in a real evaluation: the engine and its partner are entered on XCD 0 by hand)
+            unsigned *alive_w = f->dflags + 3 * (size_t)f->flags_cap;
+            static const unsigned pair_on_xcd0 = 2u;
+            CKR(hipMemcpyAsync(alive_w + 16, &pair_on_xcd0, sizeof(unsigned), hipMemcpyHostToDevice, M));
             CKR(hipEventRecord(ea, M));
             launch_dag(fv.A, fv.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
-                       pdone, (int)T64, pall, f->dpart, dcount, in, outw, xr, abort_word, M, nullptr, nullptr, 0, nullptr);
+                       pdone, (int)T64, pall, f->dpart, dcount, in, outw, xr, abort_word, M, nullptr, alive_w, dag_xcc_quota(), nullptr,
+                       f->dag_have_ftab ? f->ddag_ftab : nullptr, f->dag_xcd_g, tun().dag_xcd_lag, tun().dag_xcd_quota_all);
             CKR(hipEventRecord(eb, M));
             CKR(hipGetLastError());
             CKR(hipStreamSynchronize(M));

@@ -1921,7 +1921,35 @@ struct DagArgs {
     unsigned *hw;                    // diagnostics (may be null): per task hw_where() when drawn and when stored
     unsigned long long *trace;       // diagnostics (may be null): per task 4 stamps of the 100 MHz clock -- drawn, inputs
                                      // complete, product done and previous C version there, stored and signalled
+    const unsigned *ftab;            // which tile a FAR tile task of a step is (dag_build_steps): ftab[s] = offset of step s's table,
+                                     // ftab[ftab[s] + q] = (ti - tj0) << 16 | (tj - tj0) for the q-th far tile of the step's list;
+                                     // null: the column-major order of rounds 4-5, decoded arithmetically
+    unsigned xcd_g;                  // > 0: tasks are dealt to the XCDs in chunks of 2^xcd_g list positions (see dag_draw); 0: one counter
+    unsigned xcd_lag;                // a class this many draws behind the drawing workgroup's own is helped out (dag_kernel)
+    unsigned xcd_quota_all;          // 1: the engine XCD's quota of workgroups applies to every XCD (equal pace of the classes)
 };
+
+// XCD-aware task order (round 6).  Until round 5 every workgroup drew its next task off ONE counter: which XCD worked on which
+// tile was arbitrary, the ~255 tiles an XCD had in flight were a random eighth of a 2000-tile window of the column-major order
+// -- 14 tile columns x 150 rows: 160 operand strips of 128 KB, five times the XCD's 4 MB L2 --, and the counters showed it: 10.6
+// GB fetched per launch against 4.7 GB of C tiles (L2 hit rate 0.51: profiles/r05_dag_kernel_hbm_traffic.json).  Now
+//   (1) list position L belongs to XCD (L >> g) & 7: a workgroup on XCD x draws c = its XCD's counter and takes position
+//       ((c >> g) << (g + 3)) | (x << g) | (c & (2^g - 1)) -- chunks of 2^g = 32 consecutive positions per XCD, eight chunks per
+//       round of 256.  One atomic per draw, as before; every XCD walks the ONE list in order (its own positions), so the
+//       argument that no placement can deadlock stands: the lowest unfinished task belongs to some XCD, whose resident
+//       workgroups hold only lower positions of its class and draw it next.  The draw order of chain-critical tasks moves by
+//       at most a chunk's worth (~1 us of chip time);
+//   (2) the host deals the far tiles of a step to those positions so that what ONE XCD draws in a row is one compact block of
+//       tiles (dag_build_steps: 16 x 13 = 208 tiles = the workgroups an XCD contributes: 29 operand strips, 3.7 MB);
+//   (3) every XCD contributes the same number of workgroups (the quota that kept only the engine's XCD less than full applies
+//       to all of them), so the eight classes are consumed at the same pace.
+// Safety net: a class that falls far behind (an XCD with few workgroups: another process's kernels on its CUs) is helped --
+// every draw also reads one other XCD's counter, and a workgroup that finds it more than xcd_lag draws behind its own takes its
+// next task from there.  Any workgroup may draw from any class: a position is handed out exactly once either way.
+__device__ __forceinline__ unsigned dag_position(unsigned c, unsigned cls, unsigned g)
+{
+    return ((c >> g) << (g + 3u)) | (cls << g) | (c & ((1u << g) - 1u));
+}
 
 // a bounded wait of dag_kernel: like wait_ge<false>, and when it runs out the waiter leaves a record in words 8 .. 13 of the
 // task-word block (a.queue + 8): task, code, index of the word it waited for, value needed, value seen, wall ticks, polls
@@ -1978,20 +2006,32 @@ dag_kernel(DagArgs a)
     // soak runs: 1 evaluation in 7000 repeated on the plain schedule; tools/dag_abort.py shows the picture).  With the
     // quota that XCD has a few CUs' worth of room in every placement, and no workgroup of the grid is ever waiting in the
     // dispatcher for a slot there (the others XCDs hold their 255 at eight per CU, before and after).
+    const unsigned myx = (hw_where() >> 28) & 7u;       // (the XCD this workgroup runs on: a save / restore keeps it there)
     if (tid == 0) {
         bool take = true;
         if (a.xcc_quota) {
             // (alive[16 + x]: workgroups of the engine's launch -- the engine, its partner -- resident on XCD x; every one of
-            // them takes a CU, and an XCD that runs two queues holds seven of these workgroups per CU rather than eight)
-            const unsigned myx = (hw_where() >> 28) & 7u;
-            const unsigned c = __hip_atomic_load(a.alive + 16 + myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // them takes a CU, and an XCD that runs two queues holds seven of these workgroups per CU rather than eight.
+            // XCD-aware order: the SAME quota on every XCD -- that of the fullest one -- so that all classes keep one pace)
+            unsigned c = __hip_atomic_load(a.alive + 16 + myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.xcd_g && a.xcd_quota_all)
+                for (unsigned y = 0; y < 8u; ++y) {
+                    const unsigned cy = __hip_atomic_load(a.alive + 16 + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    c = cy > c ? cy : c;
+                }
             if (c) {
                 const unsigned less = 7u * (c - 1u);
                 const unsigned quota = a.xcc_quota > less + 8u ? a.xcc_quota - less : 8u;
                 take = __hip_atomic_fetch_add(a.queue + 16 + myx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota;
             }
         }
-        share[1] = take ? __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        unsigned first = 0xffffffffu;
+        if (take) {
+            if (a.xcd_g) first = dag_position(__hip_atomic_fetch_add(a.queue + 32 + myx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), myx, a.xcd_g);
+            else first = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        share[1] = first;
+        share[2] = 0u;                                  // (XCD-aware order: 1 + the class the NEXT draw helps out; 0: its own)
     }
     __syncthreads();
     unsigned L = (unsigned)__builtin_amdgcn_readfirstlane((int)share[1]);
@@ -2037,7 +2077,11 @@ dag_kernel(DagArgs a)
         if (!isT) {
             const int qt = (int)qt_u;
             int ti, tj;
-            {
+            if (a.ftab && qt >= (int)st.near) {
+                // a far tile: the host's table says which (XCD-aware order: what one XCD draws in a row is a compact block)
+                const unsigned e = a.ftab[a.ftab[s] + (unsigned)(qt - (int)st.near)];
+                tj = st.tj0 + (int)(e & 0xffffu); ti = st.tj0 + (int)(e >> 16);
+            } else {
                 int jl = 0, jh = st.W - 1;
                 while (jl < jh) {
                     const int mid = (jl + jh + 1) >> 1;
@@ -2204,7 +2248,28 @@ dag_kernel(DagArgs a)
         }
         // ---- the next task is asked for now (see update_kernel), and the C tile's previous version must be there
         if (t2 == 0) {
-            const unsigned Ln = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight during the poll)
+            unsigned Ln;
+            if (a.xcd_g) {
+                // this XCD's next list position -- or, when the last look found another class far behind, that class's
+                const unsigned help = share[2];
+                const unsigned cls = help ? help - 1u : myx;
+                const unsigned c = __hip_atomic_fetch_add(a.queue + 32 + cls, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned y = (myx + 1u + c % 7u) & 7u;
+                const unsigned cy = a.xcd_lag == 0xffffffffu ? c : __hip_atomic_load(a.queue + 32 + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                Ln = dag_position(c, cls, a.xcd_g);
+                // (a class is behind when its counter is: all classes hold the same share of every stretch of the list; a class
+                // that has run off the end of the list needs no help)
+                share[2] = (cls == myx && c > cy + a.xcd_lag && dag_position(cy, y, a.xcd_g) < a.ntasks) ? y + 1u : 0u;
+                if (Ln >= a.ntasks && cls == myx) {
+                    // this XCD's positions are used up: the tail of the list belongs to whoever has workgroups left
+                    for (unsigned d = 1; d < 8u && Ln >= a.ntasks; ++d) {
+                        const unsigned z = (myx + d) & 7u;
+                        if (dag_position(__hip_atomic_load(a.queue + 32 + z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), z, a.xcd_g) < a.ntasks)
+                            Ln = dag_position(__hip_atomic_fetch_add(a.queue + 32 + z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), z, a.xcd_g);
+                    }
+                }
+            } else
+                Ln = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight during the poll)
             unsigned ok = 1u;
             if (we) ok = dag_wait(a, we, ne, abort_code(0xd00u, (unsigned)s), L) ? 1u : 0u;
             if (ok && we2) ok = wait_ge<false>(we2, 1u, a.abort_word, abort_code(0xe00u, (unsigned)s)) ? 1u : 0u;   // (no record: a second dag_wait costs the kernel its scratch-free allocation)
@@ -2653,14 +2718,92 @@ void launch_pack_rows(const double *A, size_t lda, int col0, int ncols, double *
                        slot_lo, slot_hi);
 }
 
+// Which tile the q-th FAR tile task of a step is (DagArgs::ftab).  The far tiles of a step -- the trapezoid behind the next
+// panel's columns -- are cut into blocks of bw tile columns x bh tile rows (the block on the diagonal first in every block column,
+// then down), and the blocks are dealt to the XCDs as they come: with tasks dealt to XCDs in chunks of 2^xcd_g list positions
+// (dag_kernel: position L belongs to XCD (L >> g) & 7), the far tile tasks of ONE XCD's positions, taken in list order, walk
+// through one block after the other -- what an XCD has in flight at any moment is about one block: bw + bh operand strips of
+// 128 KB instead of an eighth of every strip of a 2000-tile window.  At the end of a step an XCD whose block runs out takes the
+// rest of the fullest block.  xcd_g = 0 (one counter for all): the blocks simply follow each other; bw = 0: column-major, the
+// order of rounds 4-5.
+static void dag_build_far_table(const std::vector<DagStepHost> &steps, std::vector<unsigned> &tab, int xcd_g, int bw, int bh)
+{
+    tab.assign(steps.size(), 0u);
+    for (size_t s = 0; s < steps.size(); ++s) {
+        const DagStepHost &st = steps[s];
+        tab[s] = (unsigned)tab.size();
+        const int nc = std::min(st.W, st.two ? 4 : 2);           // the next panel's columns: the near tiles
+        std::vector<std::vector<unsigned>> blocks;
+        if (bw <= 0) {
+            blocks.emplace_back();
+            for (int jl = nc; jl < st.W; ++jl)
+                for (int il = jl; il < st.H; ++il) blocks.back().push_back((unsigned)il << 16 | (unsigned)jl);
+        } else {
+            for (int c0 = nc; c0 < st.W; c0 += bw) {
+                const int c1 = std::min(c0 + bw, st.W);
+                for (int r0 = c0; r0 < st.H; r0 += bh) {
+                    const int r1 = std::min(r0 + bh, st.H);
+                    std::vector<unsigned> b;
+                    for (int il = r0; il < r1; ++il)
+                        for (int jl = c0; jl < c1 && jl <= il; ++jl) b.push_back((unsigned)il << 16 | (unsigned)jl);
+                    if (!b.empty()) blocks.push_back(std::move(b));
+                }
+            }
+        }
+        const long long ntile = (long long)st.W * st.H - (long long)st.W * (st.W - 1) / 2;
+        const long long nfar = ntile - st.near;
+        const unsigned nA = 2u * (unsigned)st.nstrip + (unsigned)st.nd_next, perBC = st.two ? 2u * (unsigned)st.nstrip : 0u;
+        const bool panels = st.nT > 0;
+        // walk the step's list positions in order; every far tile position takes the next tile of its XCD's current block
+        size_t next_block = 0;
+        size_t cur[8], pos_in[8];
+        for (int x = 0; x < 8; ++x) { cur[x] = (size_t)-1; pos_in[x] = 0; }
+        std::vector<size_t> taken_back(blocks.size(), 0);         // tiles taken off a block's END by XCDs that ran out
+        long long q = 0;
+        const unsigned total = (unsigned)ntile + st.nT;
+        for (unsigned pos = 0; pos < total && q < ntile; ++pos) {
+            if (panels && ((pos >= st.tpos && pos < st.tpos + nA) || (pos >= st.p2 && pos < st.p2 + perBC) ||
+                           (pos >= st.p3 && pos < st.p3 + perBC)))
+                continue;                                         // a panel task
+            const long long qt = q++;                             // the position's index among the step's update tiles
+            if (qt < (long long)st.near) continue;
+            const int x = xcd_g > 0 ? (int)(((st.base + pos) >> xcd_g) & 7u) : 0;
+            unsigned tile = 0;
+            bool got = false;
+            while (!got) {
+                if (cur[x] != (size_t)-1 && pos_in[x] + taken_back[cur[x]] < blocks[cur[x]].size()) {
+                    tile = blocks[cur[x]][pos_in[x]++];
+                    got = true;
+                } else if (next_block < blocks.size()) {
+                    cur[x] = next_block++; pos_in[x] = 0;
+                } else {
+                    // no fresh block left: the last tile of the block with the most tiles still to go
+                    size_t best = (size_t)-1, left = 0;
+                    for (int y = 0; y < 8; ++y)
+                        if (cur[y] != (size_t)-1) {
+                            const size_t l = blocks[cur[y]].size() - pos_in[y] - taken_back[cur[y]];
+                            if (l > left) { left = l; best = cur[y]; }
+                        }
+                    if (best == (size_t)-1) break;                // (cannot happen: as many far positions as far tiles)
+                    tile = blocks[best][blocks[best].size() - 1 - taken_back[best]++];
+                    got = true;
+                }
+            }
+            tab.push_back(tile);
+        }
+        (void)nfar;
+    }
+}
+
 // ---- the dependency-driven schedule: table of steps (host) and launch --------------------------------------------
 // Steps for a factorisation with nt column tiles and mt row tiles (trim64: the last 64 rows hold nothing), first panel
 // (tiles 0, 1) already formed in place; kskip leading columns of it are unit vectors (front padding) and are skipped.
 // lead: far tiles of a step in front of its panel tasks.  Returns the number of tasks.
 unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, int split, std::vector<DagStepHost> &out,
-                         int lead2, int lead3)
+                         int lead2, int lead3, std::vector<unsigned> *ftab, int xcd_g, int bw, int bh)
 {
     out.clear();
+    if (ftab) ftab->clear();
     unsigned base = 0;
     int prev_two = 1;
     for (int k = 0; k + 2 < nt; k += 2) {
@@ -2720,13 +2863,14 @@ unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int mi
         st.p2 = (unsigned)(st.tpos + nA + d2);
         st.p3 = (unsigned)(st.p2 + perBC + d3);
     }
+    if (ftab) dag_build_far_table(out, *ftab, xcd_g, bw, bh);
     return base;
 }
 
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
                 unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, double *partbuf, unsigned *dcount,
                 unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace,
-                const unsigned *alive, int xcc_quota, unsigned *hw)
+                const unsigned *alive, int xcc_quota, unsigned *hw, const unsigned *ftab, int xcd_g, int xcd_lag, int xcd_quota_all)
 {
     static_assert(sizeof(DagStepHost) == sizeof(DagStep), "host and device step records");
     if (nsteps <= 0 || ntasks == 0) return;
@@ -2745,6 +2889,8 @@ void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagSte
     }
     const unsigned cap = (unsigned)(slots - 8);          // one CU's worth fewer: the engine owns a CU
     a.alive = alive; a.xcc_quota = (alive && xcc_quota > 0) ? (unsigned)xcc_quota : 0u;
+    a.ftab = ftab; a.xcd_g = (ftab && xcd_g > 0) ? (unsigned)xcd_g : 0u;
+    a.xcd_lag = xcd_lag > 0 ? (unsigned)xcd_lag : (xcd_lag < 0 ? 0xffffffffu : 1024u); a.xcd_quota_all = xcd_quota_all ? 1u : 0u;
     hipLaunchKernelGGL(dag_kernel, dim3(ntasks < cap ? ntasks : cap), dim3(256), 0, s, a);
 }
 

@@ -233,13 +233,18 @@ struct DagStepHost {
 // lead: far tiles of a step in front of its T1 tasks (and the early halves); lead2 / lead3: far tiles between them and the T2
 // tasks, between those and the T3 tasks
 unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int min_tiles, int split, std::vector<DagStepHost> &out,
-                         int lead2 = 0, int lead3 = 0);
+                         int lead2 = 0, int lead3 = 0,
+                         std::vector<unsigned> *ftab = nullptr,    // out: which tile every FAR tile task is (launch_dag's ftab; chol.hip:
+                                                                   // dag_build_far_table) for tasks dealt to the XCDs in chunks of
+                         int xcd_g = 0, int bw = 16, int bh = 13); // 2^xcd_g list positions (0: one counter), blocks of bw x bh tiles
 // dsteps: DEVICE copy of the table.  queue, tdone (2 mt (2 mt + 1) / 2 words), pdone ((nsteps + 1) * pstride words,
 // pstride >= 2 mt), pall (nsteps + 1 words): zero at launch.  sig / out / xr: the engine's words (launch_potrf_engine with wbuf = Wt, pbuf = P).
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
                 unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, double *partbuf, unsigned *dcount,
                 unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace = nullptr,
-                const unsigned *alive = nullptr, int xcc_quota = 0, unsigned *hw = nullptr);
+                const unsigned *alive = nullptr, int xcc_quota = 0, unsigned *hw = nullptr,
+                const unsigned *ftab = nullptr, int xcd_g = 0,      // DEVICE copy of dag_build_steps' far-tile table; chunk exponent
+                int xcd_lag = 0, int xcd_quota_all = 1);
                 // alive: the engine's alive word (1 + its XCD); xcc_quota: workgroups of the launch that take part on that XCD
                 // partbuf: 2 x 16 x 64 x 64 doubles; dcount: 16 words per step (+ 1 step), zero at launch
 

@@ -23,7 +23,7 @@ int cocons_debug_matern(int n, const double *nu, const double *u, double *out);
 /* Schedule switches of the factorisation, settable at run time (the library reads the COCONS_* environment variables
  * of the same meaning once per process; DESIGN.md section 6 lists them): "engine", "engine_block0", "engine_pair", "panel_fused", "panel_follow",
  * "panel_diag", "panel_split", "potrf_follow", "upd_dynamic", "upd_waves", "w8_max_tiles", "dag", "dag_min_tiles", "dag_split",
- * "dag_lead" / "dag_lead2" / "dag_lead3", "dag_xcc_quota", "dag_trace" (and, for the tests, "gate_sabotage", "host_delay_us",
+ * "dag_lead" / "dag_lead2" / "dag_lead3", "dag_xcc_quota", "dag_xcd", "dag_order", "dag_bw", "dag_bh", "dag_trace" (and, for the tests, "gate_sabotage", "host_delay_us",
  * "host_delay_tile", "engine_in_wait_ms").
  * For timing variants in alternation inside one process (tools/ab_modes.py); results do not depend on them beyond the
  * rounding of a different summation order.                                                                        */
@@ -36,6 +36,10 @@ struct cocons_fit;
 long long cocons_debug_dag_trace(struct cocons_fit *fit, int *nsteps_out, int *steps_out, unsigned long long *stamps_out,
                                  unsigned long long *engine_out);   /* engine_out (may be null): 8 stamps per pair of tiles, room for 8 (nt + 2) */
 
+
+/* the first `count` task words of the last dependency-driven factorisation of the handle (host array out): [0] the one task counter,
+ * [8..14] the record of a wait that ran out, [16..23] workgroups that took part per XCD, [32..39] the XCDs' own task counters */
+int cocons_debug_dag_words(struct cocons_fit *fit, int count, unsigned *out);
 
 /* host time spent ENQUEUEING evaluations on this handle and its batch slots: out2[0] = mean microseconds per evaluation, out2[1] = evaluations */
 int cocons_debug_host_enqueue(struct cocons_fit *fit, double *out2);

@@ -187,3 +187,46 @@ def test_dag_xcd_quota_changes_nothing_but_who_works():
         _tune("dag", int(os.environ.get("COCONS_DAG", "1")))
         _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "2000")))
         fit.close()
+
+
+@pytest.mark.parametrize("gx,gy,min_tiles", [(45, 47, 0), (72, 64, 0), (100, 100, 2000)])
+def test_dag_xcd_aware_order_same_bits(gx, gy, min_tiles):
+    """Round 6: the XCD-aware task order of the persistent launch (list positions dealt to the XCDs in chunks, the far tiles of a
+    step dealt so that one XCD's tiles in flight form a compact block, the same number of workgroups from every XCD) decides
+    WHO computes a tile and WHEN, never what is summed in which order: the value and its parts are bit-identical to the
+    one-counter, column-major order of rounds 4-5, for either far-tile order under either deal and for other block shapes;
+    no hand-off times out."""
+    import cocons_amd as ca
+    from cocons_amd import workloads as wl
+    locs, sc = _grid(gx, gy)
+    n = locs.shape[0]
+    X = sc["std.covs"]
+    th = wl.theta_full()
+    th["mean"] = np.array([0.1, -0.2, 0.05])
+    rng = np.random.default_rng(n)
+    z = rng.standard_normal((n, 2)) + (X @ np.array([0.2, 0.3, -0.1]))[:, None]
+    fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
+    try:
+        _tune("dag", 1)
+        _tune("dag_min_tiles", min_tiles)
+        _tune("dag_xcd", 0)
+        _tune("dag_order", 0)
+        v0, p0 = fit.neg2loglik_core(th)
+        assert fit.engine_state()["active"]
+        for xcd, order, bw, bh in ((0, 1, 16, 13), (1, 0, 16, 13), (1, 1, 16, 13), (1, 1, 8, 24), (1, 1, 5, 7)):
+            _tune("dag_xcd", xcd)
+            _tune("dag_order", order)
+            _tune("dag_bw", bw)
+            _tune("dag_bh", bh)
+            for _ in range(2):
+                v, p = fit.neg2loglik_core(th)
+                assert v == v0 and np.array_equal(p, p0), (xcd, order, bw, bh)
+        st = fit.engine_state()
+        assert st["retries"] == 0 and st["active"], st
+    finally:
+        _tune("dag_xcd", int(os.environ.get("COCONS_DAG_XCD", "1")))
+        _tune("dag_order", int(os.environ.get("COCONS_DAG_ORDER", "1")))
+        _tune("dag_bw", int(os.environ.get("COCONS_DAG_BW", "16")))
+        _tune("dag_bh", int(os.environ.get("COCONS_DAG_BH", "13")))
+        _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "2000")))
+        fit.close()
