@@ -302,6 +302,7 @@ struct cocons_fit {
     unsigned *ddag_ftab; size_t ddag_ftab_words;   // which tile every far tile task is (dag_build_steps' table), device copy
     int dag_xcd_g;                // chunk exponent of the XCD-aware deal the table was built for (0: one counter)
     bool dag_have_ftab;           // the current step table comes with a far-tile table
+    size_t ddag_xcnt_off;         // offset (words) of the XCDs' task counters inside ddag
     unsigned long long *ddag_trace; size_t dag_trace_tasks;   // diagnostics (cocons_debug_tune("dag_trace", 1)): 4 stamps per task
     size_t dag_trace_elems;       // allocated 64-bit words of ddag_trace (5 per task + 8 per tile pair)
     bool dag_next;                // the engine launched by engine_start is the DAG schedule's (publishes W and the second X)
@@ -388,6 +389,13 @@ static int fit_check(cocons_fit *f)
     if (int rc__ = fit_check(f)) return rc__;                          \
     std::lock_guard<std::recursive_mutex> op_guard__(*(f)->op_mu)
 
+// (experiment, round 6) extra doubles in the leading dimension of the factorisation buffer: COCONS_LDA_PAD
+static size_t lda_pad()
+{
+    static const int v = [] { const char *e = getenv("COCONS_LDA_PAD"); return e ? atoi(e) : 0; }();
+    return v > 0 ? (size_t)v : 0;
+}
+
 static int fit_alloc_matrix(cocons_fit *f, int rhs_rows)
 {
     int cap = round_up(rhs_rows > 0 ? rhs_rows : 1, TILE);
@@ -396,7 +404,7 @@ static int fit_alloc_matrix(cocons_fit *f, int rhs_rows)
     if (f->dA && cap <= f->rhs_cap) return 0;
     if (f->dA) { HIPCHK(hipFree(f->dA)); f->dA = nullptr; }
     f->rhs_cap = cap;
-    f->lda = (size_t)(f->skew > 0 ? f->skew * TILE : f->npad) + cap;
+    f->lda = (size_t)(f->skew > 0 ? f->skew * TILE : f->npad) + cap + lda_pad();
     HIPCHK(hipMalloc(&f->dA, f->lda * (size_t)f->npad * sizeof(double)));
     // never-written parts must not hold NaN bit patterns: a band-limited factorisation only clears its envelope, and
     // 0 * garbage must stay 0 whatever the allocator hands back
@@ -1035,7 +1043,7 @@ struct Tunables {
                              // counter for all (rounds 4-5).  dag_order (COCONS_DAG_ORDER): 1 = far tiles in blocks (needs no XCD deal),
                              // 0 = column-major as in rounds 4-5
     int dag_order = 1, dag_bw = 16, dag_bh = 13;
-    int dag_xcd_lag = 1024, dag_xcd_quota_all = 1, dag_xcd_g = 5;
+    int dag_xcd_lag = 64, dag_xcd_quota_all = 0, dag_xcd_g = 5;
     int dag_xcc_quota = -1;  // workgroups of the DAG launch that take part on the engine's XCD (of the 255 that land there; 0: all;
                              // -1: derived from the device, dag_xcc_quota() -- 208 on MI355X)
     int engine_block0 = 1;   // COCONS_ENGINE_BLOCK0: 1 = the engine factors the FIRST diagonal block too (its input words raised by the gate
@@ -1446,7 +1454,10 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         f->dag_nsteps = (int)steps.size(); f->dag_ntasks = ntasks;
         memcpy(f->dag_key, key, sizeof key);
         const size_t T64 = 2 * (size_t)v.mt;
-        const size_t words = 64 + T64 * (T64 + 1) / 2 + (steps.size() + 2) * T64 + steps.size() + 64 + 16 * (steps.size() + 2);
+        size_t words = 64 + T64 * (T64 + 1) / 2 + (steps.size() + 2) * T64 + steps.size() + 64 + 16 * (steps.size() + 2);
+        words = (words + 31) / 32 * 32;
+        f->ddag_xcnt_off = words;              // the XCDs' own task counters: eight cache lines behind everything else
+        words += 8 * 32;
         if (f->ddag_words < words) {
             if (f->ddag) { HIPCHK(hipFree(f->ddag)); f->ddag = nullptr; }
             HIPCHK(hipMalloc(&f->ddag, words * sizeof(unsigned)));
@@ -1671,7 +1682,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         launch_dag(v.A, v.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
                    pdone, (int)T64, pall, f->dpart, dcount, in, out, xr, abort_word, M, f->dag_trace_tasks ? f->ddag_trace : nullptr,
                    alive, dag_xcc_quota(), f->dag_trace_tasks ? (unsigned *)(f->ddag_trace + 4 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2)) : nullptr,
-                   f->dag_have_ftab ? f->ddag_ftab : nullptr, f->dag_xcd_g, tun().dag_xcd_lag, tun().dag_xcd_quota_all);
+                   f->dag_have_ftab ? f->ddag_ftab : nullptr, f->dag_xcd_g, tun().dag_xcd_lag, tun().dag_xcd_quota_all, f->ddag + f->ddag_xcnt_off);
         if (ev_upd) { hipEventRecord(eb, M); ev_upd->push_back(ea); ev_upd->push_back(eb); f->dag_events = 1; }
         k_first = 2 * f->dag_nsteps;
     }
@@ -3769,7 +3780,7 @@ extern "C" int cocons_debug_dag_replay(cocons_fit *f, const double *theta, const
             CKR(hipEventRecord(ea, M));
             launch_dag(fv.A, fv.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
                        pdone, (int)T64, pall, f->dpart, dcount, in, outw, xr, abort_word, M, nullptr, alive_w, dag_xcc_quota(), nullptr,
-                       f->dag_have_ftab ? f->ddag_ftab : nullptr, f->dag_xcd_g, tun().dag_xcd_lag, tun().dag_xcd_quota_all);
+                       f->dag_have_ftab ? f->ddag_ftab : nullptr, f->dag_xcd_g, tun().dag_xcd_lag, tun().dag_xcd_quota_all, f->ddag + f->ddag_xcnt_off);
             CKR(hipEventRecord(eb, M));
             CKR(hipGetLastError());
             CKR(hipStreamSynchronize(M));

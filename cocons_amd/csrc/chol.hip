@@ -1925,6 +1925,7 @@ struct DagArgs {
                                      // ftab[ftab[s] + q] = (ti - tj0) << 16 | (tj - tj0) for the q-th far tile of the step's list;
                                      // null: the column-major order of rounds 4-5, decoded arithmetically
     unsigned xcd_g;                  // > 0: tasks are dealt to the XCDs in chunks of 2^xcd_g list positions (see dag_draw); 0: one counter
+    unsigned *xcnt;                  // the XCDs' task counters, one cache line each (xcnt + 32 x; zero at launch)
     unsigned xcd_lag;                // a class this many draws behind the drawing workgroup's own is helped out (dag_kernel)
     unsigned xcd_quota_all;          // 1: the engine XCD's quota of workgroups applies to every XCD (equal pace of the classes)
 };
@@ -2027,7 +2028,7 @@ dag_kernel(DagArgs a)
         }
         unsigned first = 0xffffffffu;
         if (take) {
-            if (a.xcd_g) first = dag_position(__hip_atomic_fetch_add(a.queue + 32 + myx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), myx, a.xcd_g);
+            if (a.xcd_g) first = dag_position(__hip_atomic_fetch_add(a.xcnt + 32u * myx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), myx, a.xcd_g);
             else first = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         share[1] = first;
@@ -2248,14 +2249,23 @@ dag_kernel(DagArgs a)
         }
         // ---- the next task is asked for now (see update_kernel), and the C tile's previous version must be there
         if (t2 == 0) {
-            unsigned Ln;
+            // (the draw, the look at another XCD's counter and the first poll of `we` are issued back to back and waited for
+            // together: one round trip, as with the one counter of rounds 4-5)
+            unsigned Ln, c = 0u, cy = 0u, cls = 0u, y = 0u;
             if (a.xcd_g) {
-                // this XCD's next list position -- or, when the last look found another class far behind, that class's
+                // this XCD's next list position -- or, when the last look found another class behind, that class's
                 const unsigned help = share[2];
-                const unsigned cls = help ? help - 1u : myx;
-                const unsigned c = __hip_atomic_fetch_add(a.queue + 32 + cls, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned y = (myx + 1u + c % 7u) & 7u;
-                const unsigned cy = a.xcd_lag == 0xffffffffu ? c : __hip_atomic_load(a.queue + 32 + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cls = help ? help - 1u : myx;
+                y = (myx + 1u + L % 7u) & 7u;
+                c = __hip_atomic_fetch_add(a.xcnt + 32u * cls, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cy = __hip_atomic_load(a.xcnt + 32u * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                Ln = 0u;
+            } else
+                Ln = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight during the poll)
+            unsigned ok = 1u;
+            if (we) ok = dag_wait(a, we, ne, abort_code(0xd00u, (unsigned)s), L) ? 1u : 0u;
+            if (ok && we2) ok = wait_ge<false>(we2, 1u, a.abort_word, abort_code(0xe00u, (unsigned)s)) ? 1u : 0u;   // (no record: a second dag_wait costs the kernel its scratch-free allocation)
+            if (a.xcd_g) {
                 Ln = dag_position(c, cls, a.xcd_g);
                 // (a class is behind when its counter is: all classes hold the same share of every stretch of the list; a class
                 // that has run off the end of the list needs no help)
@@ -2264,15 +2274,11 @@ dag_kernel(DagArgs a)
                     // this XCD's positions are used up: the tail of the list belongs to whoever has workgroups left
                     for (unsigned d = 1; d < 8u && Ln >= a.ntasks; ++d) {
                         const unsigned z = (myx + d) & 7u;
-                        if (dag_position(__hip_atomic_load(a.queue + 32 + z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), z, a.xcd_g) < a.ntasks)
-                            Ln = dag_position(__hip_atomic_fetch_add(a.queue + 32 + z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), z, a.xcd_g);
+                        if (dag_position(__hip_atomic_load(a.xcnt + 32u * z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), z, a.xcd_g) < a.ntasks)
+                            Ln = dag_position(__hip_atomic_fetch_add(a.xcnt + 32u * z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), z, a.xcd_g);
                     }
                 }
-            } else
-                Ln = __hip_atomic_fetch_add(a.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight during the poll)
-            unsigned ok = 1u;
-            if (we) ok = dag_wait(a, we, ne, abort_code(0xd00u, (unsigned)s), L) ? 1u : 0u;
-            if (ok && we2) ok = wait_ge<false>(we2, 1u, a.abort_word, abort_code(0xe00u, (unsigned)s)) ? 1u : 0u;   // (no record: a second dag_wait costs the kernel its scratch-free allocation)
+            }
             share[0] = ok; share[1] = Ln;
             if (a.trace) a.trace[4 * (size_t)L + 2] = __builtin_amdgcn_s_memrealtime();
         }
@@ -2738,6 +2744,28 @@ static void dag_build_far_table(const std::vector<DagStepHost> &steps, std::vect
             blocks.emplace_back();
             for (int jl = nc; jl < st.W; ++jl)
                 for (int il = jl; il < st.H; ++il) blocks.back().push_back((unsigned)il << 16 | (unsigned)jl);
+        } else if (bw >= 1000) {
+            // STRIDED blocks (experiment): a block's rows are `sr` tile rows apart and its columns `sr` tile columns apart --
+            // sr = 8 tiles = 4 KB of a column: the strips of one block then lie in different pages (and, if the L2's channels are
+            // interleaved by pages, in different channels) while a block still needs only bw' + bh strips
+            const int sr = 8, bw2 = bw - 1000;
+            const int a0 = (st.tj0 % sr + sr) % sr;          // residues are taken on the GLOBAL tile index: pages are global
+            for (int sig = 0; sig < sr; ++sig)
+                for (int rho = 0; rho < sr; ++rho)
+                    for (int cb = 0; cb * sr * bw2 < st.W + sr; ++cb)
+                        for (int rb = 0; rb * sr * bh < st.H + sr; ++rb) {
+                            std::vector<unsigned> b;
+                            for (int ai = 0; ai < bh; ++ai) {
+                                const int il = (rb * bh + ai) * sr + rho - a0;
+                                if (il < 0 || il >= st.H) continue;
+                                for (int bj = 0; bj < bw2; ++bj) {
+                                    const int jl = (cb * bw2 + bj) * sr + sig - a0;
+                                    if (jl < nc || jl >= st.W || jl > il) continue;
+                                    b.push_back((unsigned)il << 16 | (unsigned)jl);
+                                }
+                            }
+                            if (!b.empty()) blocks.push_back(std::move(b));
+                        }
         } else {
             for (int c0 = nc; c0 < st.W; c0 += bw) {
                 const int c1 = std::min(c0 + bw, st.W);
@@ -2870,7 +2898,8 @@ unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int mi
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
                 unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, double *partbuf, unsigned *dcount,
                 unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace,
-                const unsigned *alive, int xcc_quota, unsigned *hw, const unsigned *ftab, int xcd_g, int xcd_lag, int xcd_quota_all)
+                const unsigned *alive, int xcc_quota, unsigned *hw, const unsigned *ftab, int xcd_g, int xcd_lag, int xcd_quota_all,
+                unsigned *xcnt)
 {
     static_assert(sizeof(DagStepHost) == sizeof(DagStep), "host and device step records");
     if (nsteps <= 0 || ntasks == 0) return;
@@ -2889,8 +2918,9 @@ void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagSte
     }
     const unsigned cap = (unsigned)(slots - 8);          // one CU's worth fewer: the engine owns a CU
     a.alive = alive; a.xcc_quota = (alive && xcc_quota > 0) ? (unsigned)xcc_quota : 0u;
-    a.ftab = ftab; a.xcd_g = (ftab && xcd_g > 0) ? (unsigned)xcd_g : 0u;
-    a.xcd_lag = xcd_lag > 0 ? (unsigned)xcd_lag : (xcd_lag < 0 ? 0xffffffffu : 1024u); a.xcd_quota_all = xcd_quota_all ? 1u : 0u;
+    a.ftab = ftab; a.xcd_g = (ftab && xcnt && xcd_g > 0) ? (unsigned)xcd_g : 0u;
+    a.xcnt = xcnt;
+    a.xcd_lag = xcd_lag > 0 ? (unsigned)xcd_lag : (xcd_lag < 0 ? 0x7fffffffu : 64u); a.xcd_quota_all = xcd_quota_all ? 1u : 0u;
     hipLaunchKernelGGL(dag_kernel, dim3(ntasks < cap ? ntasks : cap), dim3(256), 0, s, a);
 }
 
