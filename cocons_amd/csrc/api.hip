@@ -1042,7 +1042,7 @@ struct Tunables {
                              // flight form one block of dag_bw x dag_bh tiles, the same number of workgroups from every XCD; 0 = one
                              // counter for all (rounds 4-5).  dag_order (COCONS_DAG_ORDER): 1 = far tiles in blocks (needs no XCD deal),
                              // 0 = column-major as in rounds 4-5
-    int dag_order = 1, dag_bw = 16, dag_bh = 13;
+    int dag_order = 1, dag_bw = 16, dag_bh = 16;
     int dag_xcd_lag = 64, dag_xcd_quota_all = 0, dag_xcd_g = 5;
     int dag_xcc_quota = -1;  // workgroups of the DAG launch that take part on the engine's XCD (of the 255 that land there; 0: all;
                              // -1: derived from the device, dag_xcc_quota() -- 208 on MI355X)

@@ -236,7 +236,7 @@ unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int mi
                          int lead2 = 0, int lead3 = 0,
                          std::vector<unsigned> *ftab = nullptr,    // out: which tile every FAR tile task is (launch_dag's ftab; chol.hip:
                                                                    // dag_build_far_table) for tasks dealt to the XCDs in chunks of
-                         int xcd_g = 0, int bw = 16, int bh = 13); // 2^xcd_g list positions (0: one counter), blocks of bw x bh tiles
+                         int xcd_g = 0, int bw = 16, int bh = 16); // 2^xcd_g list positions (0: one counter), blocks of bw x bh tiles
 // dsteps: DEVICE copy of the table.  queue, tdone (2 mt (2 mt + 1) / 2 words), pdone ((nsteps + 1) * pstride words,
 // pstride >= 2 mt), pall (nsteps + 1 words): zero at launch.  sig / out / xr: the engine's words (launch_potrf_engine with wbuf = Wt, pbuf = P).
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,

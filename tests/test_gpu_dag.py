@@ -213,7 +213,7 @@ def test_dag_xcd_aware_order_same_bits(gx, gy, min_tiles):
         _tune("dag_order", 0)
         v0, p0 = fit.neg2loglik_core(th)
         assert fit.engine_state()["active"]
-        for xcd, order, bw, bh in ((0, 1, 16, 13), (1, 0, 16, 13), (1, 1, 16, 13), (1, 1, 8, 24), (1, 1, 5, 7)):
+        for xcd, order, bw, bh in ((0, 1, 16, 16), (1, 0, 16, 16), (1, 1, 16, 16), (1, 1, 8, 24), (1, 1, 5, 7)):
             _tune("dag_xcd", xcd)
             _tune("dag_order", order)
             _tune("dag_bw", bw)
@@ -227,6 +227,6 @@ def test_dag_xcd_aware_order_same_bits(gx, gy, min_tiles):
         _tune("dag_xcd", int(os.environ.get("COCONS_DAG_XCD", "1")))
         _tune("dag_order", int(os.environ.get("COCONS_DAG_ORDER", "1")))
         _tune("dag_bw", int(os.environ.get("COCONS_DAG_BW", "16")))
-        _tune("dag_bh", int(os.environ.get("COCONS_DAG_BH", "13")))
+        _tune("dag_bh", int(os.environ.get("COCONS_DAG_BH", "16")))
         _tune("dag_min_tiles", int(os.environ.get("COCONS_DAG_MIN_TILES", "2000")))
         fit.close()

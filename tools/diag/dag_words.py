@@ -15,5 +15,5 @@ for xcd in (0, 1):
         fit.neg2loglik_core(th)
     w = np.zeros(48, dtype=np.uint32)
     _lib.check(L.cocons_debug_dag_words(fit._h, 48, w.ctypes.data_as(ctypes.POINTER(ctypes.c_uint))), "words")
-    print("dag_xcd=%d: counter %d; took part per XCD %s (sum %d); class counters %s" % (xcd, w[0], w[16:24].tolist(), int(w[16:24].sum()), w[32:40].tolist()))
+    print("dag_xcd=%d: counter %d; arrivals counted per XCD %s" % (xcd, w[0], w[16:24].tolist()))
 fit.close()
