@@ -389,13 +389,6 @@ static int fit_check(cocons_fit *f)
     if (int rc__ = fit_check(f)) return rc__;                          \
     std::lock_guard<std::recursive_mutex> op_guard__(*(f)->op_mu)
 
-// (experiment, round 6) extra doubles in the leading dimension of the factorisation buffer: COCONS_LDA_PAD
-static size_t lda_pad()
-{
-    static const int v = [] { const char *e = getenv("COCONS_LDA_PAD"); return e ? atoi(e) : 0; }();
-    return v > 0 ? (size_t)v : 0;
-}
-
 static int fit_alloc_matrix(cocons_fit *f, int rhs_rows)
 {
     int cap = round_up(rhs_rows > 0 ? rhs_rows : 1, TILE);
@@ -404,7 +397,7 @@ static int fit_alloc_matrix(cocons_fit *f, int rhs_rows)
     if (f->dA && cap <= f->rhs_cap) return 0;
     if (f->dA) { HIPCHK(hipFree(f->dA)); f->dA = nullptr; }
     f->rhs_cap = cap;
-    f->lda = (size_t)(f->skew > 0 ? f->skew * TILE : f->npad) + cap + lda_pad();
+    f->lda = (size_t)(f->skew > 0 ? f->skew * TILE : f->npad) + cap;
     HIPCHK(hipMalloc(&f->dA, f->lda * (size_t)f->npad * sizeof(double)));
     // never-written parts must not hold NaN bit patterns: a band-limited factorisation only clears its envelope, and
     // 0 * garbage must stay 0 whatever the allocator hands back
@@ -1039,11 +1032,10 @@ struct Tunables {
     int dag_split = 1;       // COCONS_DAG_SPLIT: the diagonal-block tiles of a DAG step in two halves, the first one off the chain
     int dag_xcd = 1;         // COCONS_DAG_XCD: 1 = XCD-aware task order of the persistent launch (round 6; chol.hip: dag_position) -- list
                              // positions dealt to the XCDs in chunks of 32, the far tiles of a step dealt so that one XCD's tiles in
-                             // flight form one block of dag_bw x dag_bh tiles, the same number of workgroups from every XCD; 0 = one
-                             // counter for all (rounds 4-5).  dag_order (COCONS_DAG_ORDER): 1 = far tiles in blocks (needs no XCD deal),
-                             // 0 = column-major as in rounds 4-5
+                             // flight form one block of dag_bw x dag_bh tiles, a class that falls behind helped by the others: fetched
+                             // bytes per launch halve, +2 % evaluations/s at n = 10^4; 0 = one counter for all (rounds 4-5).
+                             // dag_order (COCONS_DAG_ORDER): 0 = far tiles column-major as in rounds 4-5
     int dag_order = 1, dag_bw = 16, dag_bh = 16;
-    int dag_xcd_lag = 64, dag_xcd_quota_all = 0, dag_xcd_g = 5;
     int dag_xcc_quota = -1;  // workgroups of the DAG launch that take part on the engine's XCD (of the 255 that land there; 0: all;
                              // -1: derived from the device, dag_xcc_quota() -- 208 on MI355X)
     int engine_block0 = 1;   // COCONS_ENGINE_BLOCK0: 1 = the engine factors the FIRST diagonal block too (its input words raised by the gate
@@ -1130,9 +1122,6 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "dag_xcc_quota") t.dag_xcc_quota = value;
     else if (k == "dag_xcd") t.dag_xcd = value;
     else if (k == "dag_order") t.dag_order = value;
-    else if (k == "dag_xcd_lag") t.dag_xcd_lag = value;
-    else if (k == "dag_xcd_g") t.dag_xcd_g = value < 1 ? 1 : (value > 10 ? 10 : value);
-    else if (k == "dag_xcd_quota_all") t.dag_xcd_quota_all = value;
     else if (k == "dag_bw") t.dag_bw = value < 1 ? 1 : value;
     else if (k == "dag_bh") t.dag_bh = value < 1 ? 1 : value;
     else if (k == "dag_trace") t.dag_trace = value;
@@ -1424,7 +1413,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
     }
     const int kskip = (f->pad0 / 16) * 16;
     // (the XCD-aware deal assumes the eight XCDs of the whole chip: a partitioned device keeps the one counter)
-    const int xcd_g = (tun().dag_xcd && device_cus() == 256) ? tun().dag_xcd_g : 0;
+    const int xcd_g = (tun().dag_xcd && device_cus() == 256) ? 5 : 0;
     const int key[13] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, tun().dag_lead2, tun().dag_lead3,
                          tun().dag_order, xcd_g, tun().dag_bw, tun().dag_bh};
     if (memcmp(key, f->dag_key, sizeof key) != 0 || !f->ddag_steps) {
@@ -1682,7 +1671,7 @@ static int factorize(cocons_fit *f, const FactorView &v, std::vector<hipEvent_t>
         launch_dag(v.A, v.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
                    pdone, (int)T64, pall, f->dpart, dcount, in, out, xr, abort_word, M, f->dag_trace_tasks ? f->ddag_trace : nullptr,
                    alive, dag_xcc_quota(), f->dag_trace_tasks ? (unsigned *)(f->ddag_trace + 4 * (size_t)f->dag_ntasks + 8 * (size_t)(v.nt + 2)) : nullptr,
-                   f->dag_have_ftab ? f->ddag_ftab : nullptr, f->dag_xcd_g, tun().dag_xcd_lag, tun().dag_xcd_quota_all, f->ddag + f->ddag_xcnt_off);
+                   f->dag_have_ftab ? f->ddag_ftab : nullptr, f->dag_xcd_g, f->ddag + f->ddag_xcnt_off);
         if (ev_upd) { hipEventRecord(eb, M); ev_upd->push_back(ea); ev_upd->push_back(eb); f->dag_events = 1; }
         k_first = 2 * f->dag_nsteps;
     }
@@ -3780,7 +3769,7 @@ extern "C" int cocons_debug_dag_replay(cocons_fit *f, const double *theta, const
             CKR(hipEventRecord(ea, M));
             launch_dag(fv.A, fv.lda, f->dP, f->dWt, (const DagStepHost *)f->ddag_steps, f->dag_nsteps, f->dag_ntasks, queue, tdone,
                        pdone, (int)T64, pall, f->dpart, dcount, in, outw, xr, abort_word, M, nullptr, alive_w, dag_xcc_quota(), nullptr,
-                       f->dag_have_ftab ? f->ddag_ftab : nullptr, f->dag_xcd_g, tun().dag_xcd_lag, tun().dag_xcd_quota_all, f->ddag + f->ddag_xcnt_off);
+                       f->dag_have_ftab ? f->ddag_ftab : nullptr, f->dag_xcd_g, f->ddag + f->ddag_xcnt_off);
             CKR(hipEventRecord(eb, M));
             CKR(hipGetLastError());
             CKR(hipStreamSynchronize(M));

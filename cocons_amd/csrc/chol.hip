@@ -1926,27 +1926,37 @@ struct DagArgs {
                                      // null: the column-major order of rounds 4-5, decoded arithmetically
     unsigned xcd_g;                  // > 0: tasks are dealt to the XCDs in chunks of 2^xcd_g list positions (see dag_draw); 0: one counter
     unsigned *xcnt;                  // the XCDs' task counters, one cache line each (xcnt + 32 x; zero at launch)
-    unsigned xcd_lag;                // a class this many draws behind the drawing workgroup's own is helped out (dag_kernel)
-    unsigned xcd_quota_all;          // 1: the engine XCD's quota of workgroups applies to every XCD (equal pace of the classes)
 };
 
 // XCD-aware task order (round 6).  Until round 5 every workgroup drew its next task off ONE counter: which XCD worked on which
 // tile was arbitrary, the ~255 tiles an XCD had in flight were a random eighth of a 2000-tile window of the column-major order
-// -- 14 tile columns x 150 rows: 160 operand strips of 128 KB, five times the XCD's 4 MB L2 --, and the counters showed it: 10.6
-// GB fetched per launch against 4.7 GB of C tiles (L2 hit rate 0.51: profiles/r05_dag_kernel_hbm_traffic.json).  Now
-//   (1) list position L belongs to XCD (L >> g) & 7: a workgroup on XCD x draws c = its XCD's counter and takes position
+// -- 14 tile columns x 150 rows: 160 operand strips of 128 KB, five times the XCD's 4 MB L2 --, and the counters showed it: 10.7
+// GB fetched per launch against 4.7 GB of C tiles, L2 hit rate 0.51 (profiles/r05_dag_kernel_hbm_traffic.json).  Now
+//   (1) list position L belongs to XCD (L >> g) & 7: a workgroup on XCD x draws c off its XCD's OWN counter and takes position
 //       ((c >> g) << (g + 3)) | (x << g) | (c & (2^g - 1)) -- chunks of 2^g = 32 consecutive positions per XCD, eight chunks per
 //       round of 256.  One atomic per draw, as before; every XCD walks the ONE list in order (its own positions), so the
 //       argument that no placement can deadlock stands: the lowest unfinished task belongs to some XCD, whose resident
 //       workgroups hold only lower positions of its class and draw it next.  The draw order of chain-critical tasks moves by
 //       at most a chunk's worth (~1 us of chip time);
 //   (2) the host deals the far tiles of a step to those positions so that what ONE XCD draws in a row is one compact block of
-//       tiles (dag_build_steps: 16 x 13 = 208 tiles = the workgroups an XCD contributes: 29 operand strips, 3.7 MB);
-//   (3) every XCD contributes the same number of workgroups (the quota that kept only the engine's XCD less than full applies
-//       to all of them), so the eight classes are consumed at the same pace.
-// Safety net: a class that falls far behind (an XCD with few workgroups: another process's kernels on its CUs) is helped --
-// every draw also reads one other XCD's counter, and a workgroup that finds it more than xcd_lag draws behind its own takes its
-// next task from there.  Any workgroup may draw from any class: a position is handed out exactly once either way.
+//       tiles (dag_build_far_table: 16 x 16 = 256 tiles, about what an XCD has in flight: 32 operand strips, 4 MB);
+//   (3) WORK SHARING is kept: the classes are consumed at the pace of their XCDs, which differ (the engine's XCD contributes
+//       208 workgroups, the others 255; an XCD further from the counters' memory draws more slowly) -- every draw also reads ONE
+//       other XCD's counter, and a workgroup that finds that class more than DAG_XCD_LAG draws behind its own takes its NEXT
+//       task from there.  Any workgroup may draw from any class: a position is handed out exactly once either way.  Without it
+//       the launch ran at the pace of its slowest XCD: matrix pipe busy 0.73 instead of 0.79 (profiles/r06_xcd_order_counters.txt).
+// Two things this cost a day to learn, both about the COUNTERS rather than the order:
+//   * the eight counters must not share a cache line with each other or with anything that is LOADED while they are being
+//     incremented: atomics and L2-bypassing loads on one line at ~30 + 30 per microsecond made every memory operation of the
+//     launch about twice as slow (the whole launch 12.9 instead of 6.1 ms, whatever the order: even one counter drawn through
+//     that line) -- each counter now owns a line (xcnt + 32 x);
+//   * the look at the other XCD's counter must not wait for the draw: both are issued together with the first poll of the C
+//       tile's previous version and waited for once -- a draw that costs two round trips instead of one costs 2.5 % of the launch.
+// Measured (the launch replayed alone under the counters, same file): fetched 10.69 -> 5.64 GB per launch, L2 hit rate 0.51 ->
+// 0.70, clock under the power limit 1.89 -> 2.02 GHz; alternated with the one counter in one process: +1.5 ... +2.6 % evaluations/s
+// at n = 10^4 (four processes on one box; +2.5 / +4.6 and +0.4 on two others).  The values do not depend on it (bit-identical:
+// tests/test_gpu_dag.py::test_dag_xcd_aware_order_same_bits).  COCONS_DAG_XCD=0 / COCONS_DAG_ORDER=0: rounds 4-5.
+constexpr unsigned DAG_XCD_LAG = 64u;
 __device__ __forceinline__ unsigned dag_position(unsigned c, unsigned cls, unsigned g)
 {
     return ((c >> g) << (g + 3u)) | (cls << g) | (c & ((1u << g) - 1u));
@@ -2012,14 +2022,8 @@ dag_kernel(DagArgs a)
         bool take = true;
         if (a.xcc_quota) {
             // (alive[16 + x]: workgroups of the engine's launch -- the engine, its partner -- resident on XCD x; every one of
-            // them takes a CU, and an XCD that runs two queues holds seven of these workgroups per CU rather than eight.
-            // XCD-aware order: the SAME quota on every XCD -- that of the fullest one -- so that all classes keep one pace)
-            unsigned c = __hip_atomic_load(a.alive + 16 + myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.xcd_g && a.xcd_quota_all)
-                for (unsigned y = 0; y < 8u; ++y) {
-                    const unsigned cy = __hip_atomic_load(a.alive + 16 + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    c = cy > c ? cy : c;
-                }
+            // them takes a CU, and an XCD that runs two queues holds seven of these workgroups per CU rather than eight)
+            const unsigned c = __hip_atomic_load(a.alive + 16 + myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c) {
                 const unsigned less = 7u * (c - 1u);
                 const unsigned quota = a.xcc_quota > less + 8u ? a.xcc_quota - less : 8u;
@@ -2269,7 +2273,7 @@ dag_kernel(DagArgs a)
                 Ln = dag_position(c, cls, a.xcd_g);
                 // (a class is behind when its counter is: all classes hold the same share of every stretch of the list; a class
                 // that has run off the end of the list needs no help)
-                share[2] = (cls == myx && c > cy + a.xcd_lag && dag_position(cy, y, a.xcd_g) < a.ntasks) ? y + 1u : 0u;
+                share[2] = (cls == myx && c > cy + DAG_XCD_LAG && dag_position(cy, y, a.xcd_g) < a.ntasks) ? y + 1u : 0u;
                 if (Ln >= a.ntasks && cls == myx) {
                     // this XCD's positions are used up: the tail of the list belongs to whoever has workgroups left
                     for (unsigned d = 1; d < 8u && Ln >= a.ntasks; ++d) {
@@ -2744,28 +2748,6 @@ static void dag_build_far_table(const std::vector<DagStepHost> &steps, std::vect
             blocks.emplace_back();
             for (int jl = nc; jl < st.W; ++jl)
                 for (int il = jl; il < st.H; ++il) blocks.back().push_back((unsigned)il << 16 | (unsigned)jl);
-        } else if (bw >= 1000) {
-            // STRIDED blocks (experiment): a block's rows are `sr` tile rows apart and its columns `sr` tile columns apart --
-            // sr = 8 tiles = 4 KB of a column: the strips of one block then lie in different pages (and, if the L2's channels are
-            // interleaved by pages, in different channels) while a block still needs only bw' + bh strips
-            const int sr = 8, bw2 = bw - 1000;
-            const int a0 = (st.tj0 % sr + sr) % sr;          // residues are taken on the GLOBAL tile index: pages are global
-            for (int sig = 0; sig < sr; ++sig)
-                for (int rho = 0; rho < sr; ++rho)
-                    for (int cb = 0; cb * sr * bw2 < st.W + sr; ++cb)
-                        for (int rb = 0; rb * sr * bh < st.H + sr; ++rb) {
-                            std::vector<unsigned> b;
-                            for (int ai = 0; ai < bh; ++ai) {
-                                const int il = (rb * bh + ai) * sr + rho - a0;
-                                if (il < 0 || il >= st.H) continue;
-                                for (int bj = 0; bj < bw2; ++bj) {
-                                    const int jl = (cb * bw2 + bj) * sr + sig - a0;
-                                    if (jl < nc || jl >= st.W || jl > il) continue;
-                                    b.push_back((unsigned)il << 16 | (unsigned)jl);
-                                }
-                            }
-                            if (!b.empty()) blocks.push_back(std::move(b));
-                        }
         } else {
             for (int c0 = nc; c0 < st.W; c0 += bw) {
                 const int c1 = std::min(c0 + bw, st.W);
@@ -2898,8 +2880,7 @@ unsigned dag_build_steps(int nt, int mt, int trim64, int kskip, int lead, int mi
 void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagStepHost *dsteps, int nsteps, unsigned ntasks,
                 unsigned *queue, unsigned *tdone, unsigned *pdone, int pstride, unsigned *pall, double *partbuf, unsigned *dcount,
                 unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace,
-                const unsigned *alive, int xcc_quota, unsigned *hw, const unsigned *ftab, int xcd_g, int xcd_lag, int xcd_quota_all,
-                unsigned *xcnt)
+                const unsigned *alive, int xcc_quota, unsigned *hw, const unsigned *ftab, int xcd_g, unsigned *xcnt)
 {
     static_assert(sizeof(DagStepHost) == sizeof(DagStep), "host and device step records");
     if (nsteps <= 0 || ntasks == 0) return;
@@ -2920,7 +2901,6 @@ void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagSte
     a.alive = alive; a.xcc_quota = (alive && xcc_quota > 0) ? (unsigned)xcc_quota : 0u;
     a.ftab = ftab; a.xcd_g = (ftab && xcnt && xcd_g > 0) ? (unsigned)xcd_g : 0u;
     a.xcnt = xcnt;
-    a.xcd_lag = xcd_lag > 0 ? (unsigned)xcd_lag : (xcd_lag < 0 ? 0x7fffffffu : 64u); a.xcd_quota_all = xcd_quota_all ? 1u : 0u;
     hipLaunchKernelGGL(dag_kernel, dim3(ntasks < cap ? ntasks : cap), dim3(256), 0, s, a);
 }
 

@@ -244,7 +244,6 @@ void launch_dag(double *A, size_t lda, double *P, const double *Wt, const DagSte
                 unsigned *sig, unsigned *out, unsigned *xr, unsigned *abort_word, hipStream_t s, unsigned long long *trace = nullptr,
                 const unsigned *alive = nullptr, int xcc_quota = 0, unsigned *hw = nullptr,
                 const unsigned *ftab = nullptr, int xcd_g = 0,      // DEVICE copy of dag_build_steps' far-tile table; chunk exponent
-                int xcd_lag = 0, int xcd_quota_all = 1,
                 unsigned *xcnt = nullptr);                          // the XCDs' task counters: 8 x 32 words (a cache line each), zero at launch
                 // alive: the engine's alive word (1 + its XCD); xcc_quota: workgroups of the launch that take part on that XCD
                 // partbuf: 2 x 16 x 64 x 64 doubles; dcount: 16 words per step (+ 1 step), zero at launch

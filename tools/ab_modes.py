@@ -40,7 +40,7 @@ def main():
         sets = [(k.split("=")[0], int(k.split("=")[1])) for k in kv.split(",") if k]
         variants.append((name, sets))
     defaults = {"engine": 1, "upd_dynamic": 1, "upd_waves": 8, "w8_max_tiles": 3500, "c_wt": 0, "dag": 1, "dag_lead": 1600, "dag_lead2": 600,
-                "dag_lead3": 1800, "dag_min_tiles": 2000, "dag_split": 1, "dag_xcd": 1, "dag_order": 1, "dag_bw": 16, "dag_bh": 16, "dag_xcd_lag": 64, "dag_xcd_quota_all": 0, "dag_xcd_g": 5, "engine_pair": 1, "panel_fused": 1, "potrf_follow": 1, "panel_follow": 1, "panel_diag": 1, "panel_split": 32, "engine_block0": 1}
+                "dag_lead3": 1800, "dag_min_tiles": 2000, "dag_split": 1, "dag_xcd": 1, "dag_order": 1, "dag_bw": 16, "dag_bh": 16, "engine_pair": 1, "panel_fused": 1, "potrf_follow": 1, "panel_follow": 1, "panel_diag": 1, "panel_split": 32, "engine_block0": 1}
 
     def apply(sets):
         for k, val in defaults.items():

@@ -4,7 +4,7 @@
 # gpurun_out/switch_matrix.txt), PART=retry the configurations named in $RETRY (separated by ';').
 mkdir -p gpurun_out
 PART=${PART:-1}
-part1=("COCONS_DAG=0" "COCONS_DAG_MIN_TILES=0" "COCONS_DAG_SPLIT=0" "COCONS_DAG_XCC_QUOTA=0" "COCONS_DAG_LEAD=3600 COCONS_DAG_LEAD2=0 COCONS_DAG_LEAD3=0"
+part1=("COCONS_DAG=0" "COCONS_DAG_XCD=0" "COCONS_DAG_XCD=0 COCONS_DAG_ORDER=0" "COCONS_DAG_MIN_TILES=0" "COCONS_DAG_SPLIT=0" "COCONS_DAG_XCC_QUOTA=0" "COCONS_DAG_LEAD=3600 COCONS_DAG_LEAD2=0 COCONS_DAG_LEAD3=0"
        "COCONS_BATCH_ENGINE=0 COCONS_BATCH_SLOTS=3" "COCONS_ENGINE=0" "COCONS_UPD_WAVES=4" "COCONS_UPD_W8_MAX_TILES=0" "COCONS_UPD_DYNAMIC=0" "COCONS_FRONT_PAD=0")
 part2=("COCONS_RHS_SLOTS=0" "COCONS_TAPER_PACKED=0" "COCONS_SPATIAL_SORT=0" "COCONS_PAIR_BLOCKED=0" "COCONS_TAPER_RCM=0" "COCONS_TAPER_BAND=0"
        "COCONS_BATCH_SLOTS=1" "COCONS_BATCH_SLOTS=4"
