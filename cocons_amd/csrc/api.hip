@@ -2553,8 +2553,13 @@ extern "C" int cocons_predict_dense(cocons_fit *f, const double *theta, const do
         if (ms0.smooth_kind != ms.smooth_kind) launch_loc_params(lo, s);
         launch_pair_rect(MODE_GEOM, pa, s);
     }
-    factorize(f, main_view(f), nullptr);
-    launch_row_reduce(f->dA, f->lda, n, f->npad, f->npad + 1, m, f->dstoch, f->dquad, f->dred, s);
+    // (the dependency-driven schedule may take the head of this factorisation too -- round 6: the row reductions below read the
+    // factor from both buffers like the objectives' do; with m rows under the matrix every step is a long one)
+    FactorView pv = main_view(f);
+    pv.dag_ok = true;
+    if (int rc = factorize(f, pv, nullptr)) return rc;
+    launch_row_reduce(f->dA, f->lda, n, f->npad, f->npad + 1, m, f->dstoch, f->dquad, f->dred, s, 0, 0,
+                      f->dag_used ? f->dP : nullptr, f->dag_used ? 2 * TILE * f->dag_nsteps : 0);
     HIPCHK(hipMemcpyAsync(stochastic, f->dstoch, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(quadform, f->dquad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(f->hinfo, f->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, s));

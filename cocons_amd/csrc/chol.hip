@@ -1942,8 +1942,9 @@ struct DagArgs {
 //       tiles (dag_build_far_table: 16 x 16 = 256 tiles, about what an XCD has in flight: 32 operand strips, 4 MB);
 //   (3) WORK SHARING is kept: the classes are consumed at the pace of their XCDs, which differ (the engine's XCD contributes
 //       208 workgroups, the others 255; an XCD further from the counters' memory draws more slowly) -- every draw also reads ONE
-//       other XCD's counter, and a workgroup that finds that class more than DAG_XCD_LAG draws behind its own takes its NEXT
-//       task from there.  Any workgroup may draw from any class: a position is handed out exactly once either way.  Without it
+//       other XCD's counter, and a workgroup that finds that class more than DAG_XCD_LAG draws behind its own draws from THERE
+//       until it has caught up (it then looks at its own class's counter).  Any workgroup may draw from any class: a position
+//       is handed out exactly once either way.  Without it
 //       the launch ran at the pace of its slowest XCD: matrix pipe busy 0.73 instead of 0.79 (profiles/r06_xcd_order_counters.txt).
 // Two things this cost a day to learn, both about the COUNTERS rather than the order:
 //   * the eight counters must not share a cache line with each other or with anything that is LOADED while they are being
@@ -2256,11 +2257,13 @@ dag_kernel(DagArgs a)
             // (the draw, the look at another XCD's counter and the first poll of `we` are issued back to back and waited for
             // together: one round trip, as with the one counter of rounds 4-5)
             unsigned Ln, c = 0u, cy = 0u, cls = 0u, y = 0u;
+            unsigned help = 0u;
             if (a.xcd_g) {
-                // this XCD's next list position -- or, when the last look found another class behind, that class's
-                const unsigned help = share[2];
+                // this XCD's next list position -- or, while another class is behind, that class's.  The look goes to one of the
+                // other seven classes in turn, and to this XCD's own while it helps another
+                help = share[2];
                 cls = help ? help - 1u : myx;
-                y = (myx + 1u + L % 7u) & 7u;
+                y = help ? myx : ((myx + 1u + L % 7u) & 7u);
                 c = __hip_atomic_fetch_add(a.xcnt + 32u * cls, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 cy = __hip_atomic_load(a.xcnt + 32u * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 Ln = 0u;
@@ -2272,8 +2275,19 @@ dag_kernel(DagArgs a)
             if (a.xcd_g) {
                 Ln = dag_position(c, cls, a.xcd_g);
                 // (a class is behind when its counter is: all classes hold the same share of every stretch of the list; a class
-                // that has run off the end of the list needs no help)
-                share[2] = (cls == myx && c > cy + DAG_XCD_LAG && dag_position(cy, y, a.xcd_g) < a.ntasks) ? y + 1u : 0u;
+                // that has run off the end of the list needs no help.  Help STICKS: a workgroup that has found a class more than
+                // DAG_XCD_LAG draws behind its own keeps drawing from it until it is within half of that -- an XCD with few
+                // workgroups (another process's kernels on its CUs; the quota test's eight) is then carried by all the others,
+                // and no class ever runs a step ahead of another, which is what keeps the dependency waits short)
+                if (!help) share[2] = (c > cy + DAG_XCD_LAG && dag_position(cy, y, a.xcd_g) < a.ntasks) ? y + 1u : 0u;
+                else {
+                    share[2] = (c + DAG_XCD_LAG / 2u < cy && dag_position(c + 1u, cls, a.xcd_g) < a.ntasks) ? help : 0u;
+                    if (Ln >= a.ntasks) {            // (the helped class has run off the end: back to this XCD's own)
+                        cls = myx;
+                        c = __hip_atomic_fetch_add(a.xcnt + 32u * cls, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        Ln = dag_position(c, cls, a.xcd_g);
+                    }
+                }
                 if (Ln >= a.ntasks && cls == myx) {
                     // this XCD's positions are used up: the tail of the list belongs to whoever has workgroups left
                     for (unsigned d = 1; d < 8u && Ln >= a.ntasks; ++d) {
@@ -2414,12 +2428,15 @@ finalize_kernel(const double *A, size_t lda, int c0, int c1, int n, int row0, in
 // stage 2: the chunks of one row summed in ascending order.
 __global__ void __launch_bounds__(256)
 row_reduce_kernel(const double *A, size_t lda, int n, int rowy, int row0, int m,
-                  double *scratch, int cchunk, int skew, int npad)
+                  double *scratch, int cchunk, int skew, int npad, const double *A2, int a2_cols)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cb = blockIdx.y * cchunk;
     const int ce = (cb + cchunk < n) ? cb + cchunk : n;
     if (i >= m) return;
+    // (A2: the factor of the dependency-driven schedule -- below the diagonal blocks the columns [256, a2_cols) live in the
+    // second buffer, launch_finalize; the rows read here lie under the matrix, and a chunk of 256 columns is one panel)
+    if (A2 && cb >= 2 * TILE && cb < a2_cols) A = A2;
     double s = 0.0, q = 0.0;
     for (int c = cb; c < ce; ++c) {
         double v = A[band_index(row0 + i, c, lda, skew, npad)];
@@ -2933,12 +2950,13 @@ size_t row_reduce_scratch_doubles(int n, int m)
 }
 
 void launch_row_reduce(const double *A, size_t lda, int n, int rowy, int row0, int m,
-                       double *stoch, double *quad, double *scratch, hipStream_t s, int skew, int npad)
+                       double *stoch, double *quad, double *scratch, hipStream_t s, int skew, int npad,
+                       const double *A2, int a2_cols)
 {
     if (m <= 0) return;
-    const int cchunk = 256, nchunks = (n + cchunk - 1) / cchunk;
+    const int cchunk = 2 * TILE, nchunks = (n + cchunk - 1) / cchunk;
     hipLaunchKernelGGL(row_reduce_kernel, dim3((m + 255) / 256, nchunks), dim3(256), 0, s,
-                       A, lda, n, rowy, row0, m, scratch, cchunk, skew, npad);
+                       A, lda, n, rowy, row0, m, scratch, cchunk, skew, npad, skew ? (const double *)nullptr : A2, a2_cols);
     hipLaunchKernelGGL(row_reduce_final_kernel, dim3((m + 255) / 256), dim3(256), 0, s,
                        scratch, m, nchunks, stoch, quad);
 }

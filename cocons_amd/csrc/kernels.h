@@ -260,7 +260,8 @@ void launch_finalize_cols(const double *A, size_t lda, int c0, int c1, int n, in
 // deterministic two-stage reduction; scratch must hold row_reduce_scratch_doubles(n, m) doubles
 size_t row_reduce_scratch_doubles(int n, int m);
 void launch_row_reduce(const double *A, size_t lda, int n, int rowy, int row0, int m,
-                       double *stoch, double *quad, double *scratch, hipStream_t s, int skew = 0, int npad = 0);
+                       double *stoch, double *quad, double *scratch, hipStream_t s, int skew = 0, int npad = 0,
+                       const double *A2 = nullptr, int a2_cols = 0);   // factor of the DAG schedule, as for launch_finalize
 
 // Y = L E + trend (lower factor L in A), E n x nsim, Y n x nsim
 void launch_trmm_lower(const double *A, size_t lda, int n, const double *E, int lde, int nsim,

@@ -562,17 +562,20 @@ def test_multi_handle_replica_batch(oracle):
 
 
 @pytest.mark.shared_gpu
-def test_worker_processes_share_one_gpu(tmp_path, record_property):
+@pytest.mark.parametrize("g,nevals", [(64, 10), (100, 6)])
+def test_worker_processes_share_one_gpu(tmp_path, record_property, g, nevals):
     """The reference's own calling pattern on the HIP path: `ncores` worker PROCESSES (here 3), each with a handle of
     its own on the one device, evaluating concurrently at n = 4096 (R/optim.R:117-121, 234-259).  Every value must
     equal the single-process value; each process's engine needs a CU to itself while the others' updates fill the
     chip, so hand-off time-outs are allowed here -- each costs one repeat on the plain schedule and is counted; the
     back-off bounds them (asserted).  Per-process count, last abort code and wall time go into the test record
-    (record_property) and DESIGN.md."""
+    (record_property) and DESIGN.md.  (Round 6: also at n = 10^4, where every process runs the PERSISTENT launch with its tasks
+    dealt to the XCDs -- three launches of 2040 workgroups compete for the chip's slots, so an XCD may hold few workgroups of
+    one of them: the classes of that launch must still be carried by the others.)"""
     import torch.multiprocessing as mp
     import cocons_amd as ca
     from cocons_amd import workloads as wl
-    world, g, nevals = 3, 64, 10
+    world = 3
     mp.spawn(_optim_worker, args=(world, _free_port(), g, nevals, str(tmp_path)), nprocs=world, join=True)
     locs, X, th, z = _grid_problem(g)
     fit = ca.CoconsFit(locs, X, z, wl.SMOOTH_LIMITS)
