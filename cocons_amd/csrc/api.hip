@@ -1412,8 +1412,13 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
         f->dWt_tiles = v.nt;
     }
     const int kskip = (f->pad0 / 16) * 16;
-    // (the XCD-aware deal assumes the eight XCDs of the whole chip: a partitioned device keeps the one counter)
-    const int xcd_g = (tun().dag_xcd && device_cus() == 256) ? 5 : 0;
+    // (the XCD-aware deal assumes the eight XCDs of the whole chip -- a partitioned device keeps the one counter -- and XCDs that
+    // contribute comparable numbers of workgroups: a class of list positions whose XCD holds almost none is carried by the
+    // others only while they are free to draw, and with everybody waiting at that class's tasks the launch crawls at the pace
+    // of its few workgroups until a bounded wait ends it (tools/diag/quota_stress.py) -- a quota below half an XCD's share, which
+    // only the tests set, keeps the one counter too)
+    const int q_all = dag_xcc_quota();
+    const int xcd_g = (tun().dag_xcd && device_cus() == 256 && (q_all == 0 || q_all >= 128)) ? 5 : 0;
     const int key[13] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, tun().dag_lead2, tun().dag_lead3,
                          tun().dag_order, xcd_g, tun().dag_bw, tun().dag_bh};
     if (memcmp(key, f->dag_key, sizeof key) != 0 || !f->ddag_steps) {

@@ -2019,6 +2019,7 @@ dag_kernel(DagArgs a)
     // quota that XCD has a few CUs' worth of room in every placement, and no workgroup of the grid is ever waiting in the
     // dispatcher for a slot there (the others XCDs hold their 255 at eight per CU, before and after).
     const unsigned myx = (hw_where() >> 28) & 7u;       // (the XCD this workgroup runs on: a save / restore keeps it there)
+    const bool loyal = ((blockIdx.x >> 3) & 1u) == 0u;  // (XCD-aware order: this workgroup never draws from another XCD's class)
     if (tid == 0) {
         bool take = true;
         if (a.xcc_quota) {
@@ -2261,7 +2262,7 @@ dag_kernel(DagArgs a)
             if (a.xcd_g) {
                 // this XCD's next list position -- or, while another class is behind, that class's.  The look goes to one of the
                 // other seven classes in turn, and to this XCD's own while it helps another
-                help = share[2];
+                help = loyal ? 0u : share[2];
                 cls = help ? help - 1u : myx;
                 y = help ? myx : ((myx + 1u + L % 7u) & 7u);
                 c = __hip_atomic_fetch_add(a.xcnt + 32u * cls, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2279,7 +2280,13 @@ dag_kernel(DagArgs a)
                 // DAG_XCD_LAG draws behind its own keeps drawing from it until it is within half of that -- an XCD with few
                 // workgroups (another process's kernels on its CUs; the quota test's eight) is then carried by all the others,
                 // and no class ever runs a step ahead of another, which is what keeps the dependency waits short)
-                if (!help) share[2] = (c > cy + DAG_XCD_LAG && dag_position(cy, y, a.xcd_g) < a.ntasks) ? y + 1u : 0u;
+                // LOYAL workgroups never help: every other workgroup of an XCD (by block index) draws from its own class only.
+                // Without them the argument of (1) fails -- all workgroups of class k may be away in other classes' tasks, blocked
+                // at dependencies on class k's undrawn head, with nobody left to draw it: a deadlock the bounded waits end, seen
+                // once in 300 evaluations of tools/diag/quota_stress.py (task 20592 waited 63 ms for a strip whose tasks nobody
+                // had drawn).  A loyal workgroup holds only positions of its own class below the class's head; if that head is the
+                // lowest unfinished task everything below it is finished, so the loyal workgroup is free and draws it.
+                if (!help) share[2] = (!loyal && c > cy + DAG_XCD_LAG && dag_position(cy, y, a.xcd_g) < a.ntasks) ? y + 1u : 0u;
                 else {
                     share[2] = (c + DAG_XCD_LAG / 2u < cy && dag_position(c + 1u, cls, a.xcd_g) < a.ntasks) ? help : 0u;
                     if (Ln >= a.ntasks) {            // (the helped class has run off the end: back to this XCD's own)
