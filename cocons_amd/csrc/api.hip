@@ -1036,6 +1036,7 @@ struct Tunables {
                              // bytes per launch halve, +2 % evaluations/s at n = 10^4; 0 = one counter for all (rounds 4-5).
                              // dag_order (COCONS_DAG_ORDER): 0 = far tiles column-major as in rounds 4-5
     int dag_order = 1, dag_bw = 16, dag_bh = 16;
+    int dag_xcd_min_quota = 128;
     int dag_xcc_quota = -1;  // workgroups of the DAG launch that take part on the engine's XCD (of the 255 that land there; 0: all;
                              // -1: derived from the device, dag_xcc_quota() -- 208 on MI355X)
     int engine_block0 = 1;   // COCONS_ENGINE_BLOCK0: 1 = the engine factors the FIRST diagonal block too (its input words raised by the gate
@@ -1122,6 +1123,7 @@ extern "C" int cocons_debug_tune(const char *name, int value)
     else if (k == "dag_xcc_quota") t.dag_xcc_quota = value;
     else if (k == "dag_xcd") t.dag_xcd = value;
     else if (k == "dag_order") t.dag_order = value;
+    else if (k == "dag_xcd_min_quota") t.dag_xcd_min_quota = value;
     else if (k == "dag_bw") t.dag_bw = value < 1 ? 1 : value;
     else if (k == "dag_bh") t.dag_bh = value < 1 ? 1 : value;
     else if (k == "dag_trace") t.dag_trace = value;
@@ -1418,7 +1420,7 @@ static int dag_prepare(cocons_fit *f, const FactorView &v)
     // of its few workgroups until a bounded wait ends it (tools/diag/quota_stress.py) -- a quota below half an XCD's share, which
     // only the tests set, keeps the one counter too)
     const int q_all = dag_xcc_quota();
-    const int xcd_g = (tun().dag_xcd && device_cus() == 256 && (q_all == 0 || q_all >= 128)) ? 5 : 0;
+    const int xcd_g = (tun().dag_xcd && device_cus() == 256 && (q_all == 0 || q_all >= tun().dag_xcd_min_quota)) ? 5 : 0;
     const int key[13] = {v.nt, v.mt, v.trim, kskip, tun().dag_lead, tun().dag_min_tiles, tun().dag_split, tun().dag_lead2, tun().dag_lead3,
                          tun().dag_order, xcd_g, tun().dag_bw, tun().dag_bh};
     if (memcmp(key, f->dag_key, sizeof key) != 0 || !f->ddag_steps) {

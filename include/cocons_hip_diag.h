@@ -24,7 +24,7 @@ int cocons_debug_matern(int n, const double *nu, const double *u, double *out);
  * of the same meaning once per process; DESIGN.md section 6 lists them): "engine", "engine_block0", "engine_pair", "panel_fused", "panel_follow",
  * "panel_diag", "panel_split", "potrf_follow", "upd_dynamic", "upd_waves", "w8_max_tiles", "dag", "dag_min_tiles", "dag_split",
  * "dag_lead" / "dag_lead2" / "dag_lead3", "dag_xcc_quota", "dag_xcd", "dag_order", "dag_bw", "dag_bh", "dag_trace" (and, for the tests, "gate_sabotage", "host_delay_us",
- * "host_delay_tile", "engine_in_wait_ms").
+ * "host_delay_tile", "engine_in_wait_ms", "dag_xcd_min_quota").
  * For timing variants in alternation inside one process (tools/ab_modes.py); results do not depend on them beyond the
  * rounding of a different summation order.                                                                        */
 int cocons_debug_tune(const char *name, int value);

@@ -14,7 +14,7 @@ g = 72
 locs = wl.grid_locs(g); X = wl.design_from_locs(locs)["std.covs"]; th = wl.theta_full()
 fit = ca.CoconsFit(locs, X, wl.synthetic_z(g * g), wl.SMOOTH_LIMITS)
 quota = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-for k, v in (("dag", 1), ("dag_min_tiles", 0), ("dag_xcc_quota", quota)):
+for k, v in (("dag", 1), ("dag_min_tiles", 0), ("dag_xcd_min_quota", 1), ("dag_xcc_quota", quota)):
     _lib.check(L.cocons_debug_tune(k.encode(), v), "tune")
 v0 = fit.neg2loglik_core(th)[0]
 import time
